@@ -1,0 +1,208 @@
+/*
+ * meshdiffusion_hip.h -- C ABI of libmeshdiffusion_hip.so (gfx950 / MI355X).
+ *
+ * This is the drop-in boundary underneath MeshDiffusion's Python score-model
+ * API.  The reference has NO C/FFI boundary on this path: its
+ * "kernels" are ATen calls made from Python modules.  Each entry point below
+ * therefore cites the reference Python call site it replaces
+ * (paths relative to the reference repo root).
+ *
+ * Conventions
+ *   - plain pointers + sizes only; no torch types.  All pointers are DEVICE
+ *     pointers owned by the caller (PyTorch allocator); the library never
+ *     allocates, frees or retains device memory.
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*),
+ *     re-entrant and stateless.
+ *   - return value: 0 = ok, negative = MD_ERR_*, positive = hipError_t.
+ *
+ * Device tensor layouts (see DESIGN.md "Data layout in HBM")
+ *   NCDHW : float32 [B][C][P]                      (the reference's layout, P = D*H*W)
+ *   F32B  : float32 [B][C/8][P][8]                 (8-channel blocked fp32)
+ *   S16B  : bf16    [B][C/8][2][P][8]              (8-channel blocked split-bf16:
+ *                                                   plane 0 = hi = bf16(x),
+ *                                                   plane 1 = lo = bf16(x - hi))
+ *   WPK   : bf16    [rows/NT][K/KC][taps][KC/8][2][NT][8]  packed split-bf16
+ *                                                   weight tiles (one tile = one LDS image)
+ */
+#ifndef MESHDIFFUSION_HIP_H
+#define MESHDIFFUSION_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MD_OK 0
+#define MD_ERR_BAD_ARG (-1)
+#define MD_ERR_UNSUPPORTED (-2)
+#define MD_ERR_NO_DEVICE (-3)
+
+#define MD_ABI_VERSION 1
+
+/* ---- tile configurations of md_gemm_conv (compile-time instantiations) ---- */
+enum {
+  MD_CFG_C3_128 = 0,     /* 3x3x3 s1, tile 4x8x8,  NT=128, KC=32  (main conv)        */
+  MD_CFG_C3_128_K16 = 1, /* 3x3x3 s1, tile 4x8x8,  NT=128, KC=16  (stem, Cin<=16)    */
+  MD_CFG_C3_32 = 2,      /* 3x3x3 s1, tile 4x8x8,  NT=32,  KC=32  (head, Cout<=32)   */
+  MD_CFG_C3_LOW = 3,     /* 3x3x3 s1, tile 4x4x4,  NT=128, KC=32  (4^3 level)        */
+  MD_CFG_C3_S2 = 4,      /* 3x3x3 s2 pad(0,1), tile 4x4x4, NT=128, KC=32 (Downsample)*/
+  MD_CFG_G1_128 = 5,     /* 1x1x1 / GEMM, 256 cols, NT=128, KC=32                    */
+  MD_CFG_G1_128_LOW = 6, /* 1x1x1 / GEMM, 64 cols,  NT=128, KC=32                    */
+  MD_CFG_G1_64_LOW = 7,  /* 1x1x1 / GEMM, 64 cols,  NT=64,  KC=32                    */
+  MD_CFG_COUNT = 8
+};
+
+enum { MD_OUT_F32B = 0, MD_OUT_S16B = 1, MD_OUT_NCDHW = 2 };
+enum { MD_A_PACKED = 0, MD_A_S16B = 1 };
+
+/*
+ * md_gemm_conv: out[b][i][j] = alpha * sum_{tap,k} A[i][tap][k] * B[b][k][pos_j + tap]
+ *                              + bias[b*bias_bstride + i] + residual[b][i][j]
+ * computed on the matrix cores with a bf16x3 split (hi*hi + hi*lo + lo*hi,
+ * fp32 accumulate).  i = output row (output channel), j = spatial position.
+ *
+ * Replaces: nn.Conv3d 3x3x3 (lib/diffusion/models/layers.py:118-124 used at
+ * :654,:662, ddpm_res64.py:85-87,:121), Downsample pad+stride-2 conv
+ * (layers.py:626-643), Upsample nearest x2 + conv (layers.py:611-623, `ups`=1
+ * folds the interpolate into the halo load), NIN 1x1x1 (layers.py:573-582)
+ * and the two attention einsums (layers.py:602,606; a_src = MD_A_S16B).
+ */
+typedef struct MdGemmConvArgs {
+  const void* a;         /* WPK weights (a_src=0) or S16B tensor [B][K/8][2][a_rows][8] (a_src=1) */
+  const void* b;         /* S16B activations [B][K/8][2][P_in][8]                               */
+  void* out;             /* F32B / S16B [B][rows_alloc/8].. / NCDHW [B][rows][P]                */
+  const float* bias;     /* may be NULL                                                        */
+  const float* residual; /* F32B [.][rows_alloc/8][P][8], may be NULL                          */
+  float alpha;
+  int32_t cfg;           /* MD_CFG_*                                                           */
+  int32_t batch;
+  int32_t rows;          /* logical output rows (Cout); stores are guarded by it               */
+  int32_t rows_alloc;    /* channel count of out/residual tensors (multiple of 8)              */
+  int32_t kdim;          /* K per tap (Cin), multiple of the cfg's KC                          */
+  int32_t D, H, W;       /* OUTPUT spatial dims; GEMM cfgs use D=H=1, W=P                      */
+  int32_t ups;           /* 1: input is nearest-upsampled x2 on the fly                        */
+  int32_t a_src;         /* MD_A_*                                                             */
+  int32_t out_mode;      /* MD_OUT_*                                                           */
+  int32_t a_rows;        /* a_src=1: rows (P) of the A tensor                                  */
+  int64_t a_bstride;     /* a_src=1: elements (bf16) between batches of A; 0 = shared          */
+  int64_t bias_bstride;  /* floats between batches of bias; 0 = shared                         */
+  int64_t res_bstride;   /* floats between batches of residual; 0 = shared                     */
+} MdGemmConvArgs;
+
+int md_abi_version(void);
+/* number of visible HIP devices, or negative MD_ERR */
+int md_device_count(void);
+
+int md_gemm_conv(const MdGemmConvArgs* args, void* stream);
+/* bytes of LDS and threads per workgroup of a cfg (for DESIGN/bench reporting) */
+int md_gemm_conv_cfg_info(int32_t cfg, int32_t* nt, int32_t* kc, int32_t* cols,
+                          int32_t* taps, int32_t* lds_bytes, int32_t* threads);
+
+/*
+ * md_pack_weights: fp32 weights -> WPK tiles (device side, run once per load).
+ *   w      : float32, element (row i, k, tap) at  w[i*s_row + k*s_k + tap*s_tap]
+ *            (Conv3d weight [Co][Ci][27]: s_row=Ci*27, s_k=27, s_tap=1;
+ *             NIN W [Ci][Co] (layers.py:576): s_row=1, s_k=Co, s_tap=0)
+ *   rows,kdim : logical sizes; tiles are zero-padded to NT / KC multiples.
+ */
+int md_pack_weights(const float* w, void* wpk, int32_t rows, int32_t kdim, int32_t taps,
+                    int64_t s_row, int64_t s_k, int64_t s_tap, int32_t nt, int32_t kc,
+                    void* stream);
+int64_t md_packed_weight_bytes(int32_t rows, int32_t kdim, int32_t taps, int32_t nt, int32_t kc);
+
+/*
+ * GroupNorm statistics + apply (+SiLU) + bf16 split.
+ * Replaces nn.GroupNorm(32, C, eps=1e-6) + nn.SiLU (layers.py:652,660,676,681,
+ * :589; ddpm_res64.py:120,186) and torch.cat([h, skip], 1) (ddpm_res64.py:174-176):
+ * a concatenated input is expressed as two calls with channel offsets.
+ *
+ * md_gn_stats : accumulates per-(b, channel) sum / sum-of-squares (double) of an
+ *               F32B tensor x[B][C/8][P][8] into sums[B][c_total][2] at channel
+ *               offset c_off.  `sums` must be zeroed by the caller (md_zero).
+ * md_gn_finalize: per-(b,c) params float4 = (mean(group), rstd(group)*gamma[c], beta[c], 0)
+ *               (biased variance, as torch's GroupNorm).
+ * md_gn_apply : y = (x-mean)*rstd*gamma + beta (norm=1) ; y = silu(y) (silu=1); writes the
+ *               split-bf16 S16B tensor out[B][c_total/8][2][P][8] at c_off.
+ *               norm=0 copies/splits raw x (used for the NIN shortcut input).
+ */
+int md_gn_stats(const float* x, double* sums, int32_t batch, int32_t C, int64_t P,
+                int32_t c_total, int32_t c_off, void* stream);
+int md_gn_finalize(const double* sums, const float* gamma, const float* beta,
+                   float* params, int32_t batch, int32_t c_total, int32_t groups,
+                   int64_t P, float eps, void* stream);
+int md_gn_apply(const float* x, const float* params, void* out, int32_t batch,
+                int32_t C, int64_t P, int32_t c_total, int32_t c_off, int32_t norm,
+                int32_t silu, void* stream);
+int md_zero(void* p, int64_t bytes, void* stream);
+
+/*
+ * Timestep embedding + dense layers (layers.py:542-556, ddpm_res64.py:132-136,
+ * layers.py:679-680).
+ * md_timestep_embedding: emb[b] = [sin(t_b*f_j) | cos(t_b*f_j)], f_j = exp(-ln(1e4)*j/(dim/2-1)).
+ * md_linear: y[b][o] = sum_i act(x[b][i]) * w[o*in + i] + bias[o]  (act = SiLU if silu_in).
+ */
+int md_timestep_embedding(const float* t, float* emb, int32_t batch, int32_t dim, void* stream);
+int md_linear(const float* x, const float* w, const float* bias, float* y, int32_t batch,
+              int32_t in_dim, int32_t out_dim, int32_t silu_in, void* stream);
+
+/* NCDHW fp32 [B][C][P] -> S16B [B][c_pad/8][2][P][8] (channels >= C zero filled). */
+int md_ncdhw_to_s16b(const float* x, void* out, int32_t batch, int32_t C, int32_t c_pad,
+                     int64_t P, void* stream);
+/* F32B [B][C/8][P][8] <-> NCDHW [B][C][P] (tests / debugging / parity probes). */
+int md_f32b_to_ncdhw(const float* x, float* out, int32_t batch, int32_t C, int64_t P, void* stream);
+int md_ncdhw_to_f32b(const float* x, float* out, int32_t batch, int32_t C, int64_t P, void* stream);
+int md_s16b_to_ncdhw(const void* x, float* out, int32_t batch, int32_t C, int64_t P, void* stream);
+
+/*
+ * Attention softmax over keys (layers.py:603-605).  s: F32B-like [B][N/8][N][8]
+ * holding S^T (keys blocked by 8, queries as positions); p: S16B [B][N/8][2][N][8].
+ */
+int md_softmax_keys(const float* s, void* p, int32_t batch, int32_t n_keys, int32_t n_q,
+                    void* stream);
+
+/*
+ * One DDPM ancestral-sampling update (models/utils.py:191-198 score scaling,
+ * sampling.py:222-230 predictor, sampling.py:476-478 mask), all NCDHW fp32:
+ *   x_mean = (x - beta/sigma * eps) / sqrt(1-beta);  x = x_mean + sqrt(beta)*z
+ *   x, x_mean *= mask[P]   (mask may be NULL)
+ * beta/sigma/… are passed per batch element (coef[b][4] = beta, sigma, sqrt(1-beta), sqrt(beta)).
+ */
+int md_ancestral_step(const float* x, const float* eps, const float* z, const float* mask,
+                      const float* coef, float* x_out, float* x_mean_out, int32_t batch,
+                      int32_t C, int64_t P, void* stream);
+/*
+ * Inpainting blend of one channel (sampling.py:443-467):
+ *   v = (x*(1-m) + src*m) * gm     applied in place to channel `ch` of x [B][C][P];
+ *   src has batch stride src_bstride (0 = shared partial grid).
+ */
+int md_inpaint_blend(float* x, const float* src, const float* pmask, const float* gmask,
+                     int32_t batch, int32_t C, int32_t ch, int64_t P, int64_t src_bstride,
+                     void* stream);
+
+/*
+ * Marching tetrahedra on a STATIC tet grid (nvdiffrec/lib/geometry/dmtet.py:105-163),
+ * one workgroup per mesh, n_meshes meshes per call.
+ * Static tables (built once on the host from the tet file, see meshdiffusion_amd/dmtet.py):
+ *   tets       int32 [T][4]
+ *   edges      int32 [E][2]   lexicographically sorted unique (min,max) vertex pairs of all tets
+ *   tet_edges  int32 [T][6]   edge id of each tet's 6 edges in base_tet_edges order (dmtet.py:54)
+ * Per mesh:   pos float32 [M][N][3], sdf float32 [M][N]
+ * Outputs:    verts float32 [M][E][3] (first counts[m][0] rows valid),
+ *             faces int64 [M][2T][3]  (first counts[m][1] rows valid),
+ *             face_tet int64 [M][2T]  (tet id of each face = face_to_valid_tet; may be NULL),
+ *             counts int32 [M][4] = {n_verts, n_faces, n_tets_1tri, n_tets_2tri}
+ * Face order == reference: all 1-triangle tets (tet order), then 2-triangle tets.
+ * Workspace:  md_marching_tets_workspace_bytes(M, E) bytes.
+ */
+int64_t md_marching_tets_workspace_bytes(int32_t n_meshes, int32_t n_edges);
+int md_marching_tets(const float* pos, const float* sdf, const int32_t* tets,
+                     const int32_t* edges, const int32_t* tet_edges, int32_t n_meshes,
+                     int32_t n_verts, int32_t n_edges, int32_t n_tets, float* verts,
+                     int64_t* faces, int64_t* face_tet, int32_t* counts, void* workspace,
+                     int64_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MESHDIFFUSION_HIP_H */

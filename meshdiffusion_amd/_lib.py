@@ -1,0 +1,105 @@
+"""ctypes binding of libmeshdiffusion_hip.so (the C ABI declared in include/meshdiffusion_hip.h).
+
+There is NO fallback: if the shared library is missing or an entry point fails, the caller
+gets an exception.  PyTorch is only used by the callers for device memory and streams; every
+argument that crosses this boundary is a raw device pointer or a plain integer/float.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmeshdiffusion_hip.so")
+
+# MD_CFG_* (include/meshdiffusion_hip.h)
+CFG_C3_128, CFG_C3_128_K16, CFG_C3_32, CFG_C3_LOW, CFG_C3_S2, CFG_G1_128, CFG_G1_128_LOW, CFG_G1_64_LOW = range(8)
+OUT_F32B, OUT_S16B, OUT_NCDHW = 0, 1, 2
+A_PACKED, A_S16B = 0, 1
+
+# (NT, KC) of each cfg -- must match csrc/gemm_conv.hip; checked against the library at load.
+CFG_NT_KC = {
+    CFG_C3_128: (128, 32), CFG_C3_128_K16: (128, 16), CFG_C3_32: (32, 32), CFG_C3_LOW: (128, 32),
+    CFG_C3_S2: (128, 32), CFG_G1_128: (128, 32), CFG_G1_128_LOW: (128, 32), CFG_G1_64_LOW: (64, 32),
+}
+
+
+class MdGemmConvArgs(C.Structure):
+    _fields_ = [
+        ("a", C.c_void_p), ("b", C.c_void_p), ("out", C.c_void_p), ("bias", C.c_void_p),
+        ("residual", C.c_void_p), ("alpha", C.c_float), ("cfg", C.c_int32), ("batch", C.c_int32),
+        ("rows", C.c_int32), ("rows_alloc", C.c_int32), ("kdim", C.c_int32), ("D", C.c_int32),
+        ("H", C.c_int32), ("W", C.c_int32), ("ups", C.c_int32), ("a_src", C.c_int32),
+        ("out_mode", C.c_int32), ("a_rows", C.c_int32), ("a_bstride", C.c_int64),
+        ("bias_bstride", C.c_int64), ("res_bstride", C.c_int64),
+    ]
+
+
+_P, _I32, _I64, _F = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+
+# name -> (restype, argtypes); exactly the entry points of include/meshdiffusion_hip.h
+SIGNATURES = {
+    "md_abi_version": (C.c_int, []),
+    "md_device_count": (C.c_int, []),
+    "md_gemm_conv": (C.c_int, [C.POINTER(MdGemmConvArgs), _P]),
+    "md_gemm_conv_cfg_info": (C.c_int, [_I32] + [C.POINTER(C.c_int32)] * 6),
+    "md_pack_weights": (C.c_int, [_P, _P, _I32, _I32, _I32, _I64, _I64, _I64, _I32, _I32, _P]),
+    "md_packed_weight_bytes": (_I64, [_I32, _I32, _I32, _I32, _I32]),
+    "md_gn_stats": (C.c_int, [_P, _P, _I32, _I32, _I64, _I32, _I32, _P]),
+    "md_gn_finalize": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _I64, _F, _P]),
+    "md_gn_apply": (C.c_int, [_P, _P, _P, _I32, _I32, _I64, _I32, _I32, _I32, _I32, _P]),
+    "md_zero": (C.c_int, [_P, _I64, _P]),
+    "md_timestep_embedding": (C.c_int, [_P, _P, _I32, _I32, _P]),
+    "md_linear": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _P]),
+    "md_ncdhw_to_s16b": (C.c_int, [_P, _P, _I32, _I32, _I32, _I64, _P]),
+    "md_f32b_to_ncdhw": (C.c_int, [_P, _P, _I32, _I32, _I64, _P]),
+    "md_ncdhw_to_f32b": (C.c_int, [_P, _P, _I32, _I32, _I64, _P]),
+    "md_s16b_to_ncdhw": (C.c_int, [_P, _P, _I32, _I32, _I64, _P]),
+    "md_softmax_keys": (C.c_int, [_P, _P, _I32, _I32, _I32, _P]),
+    "md_ancestral_step": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I64, _P]),
+    "md_inpaint_blend": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _I64, _I64, _P]),
+    "md_marching_tets_workspace_bytes": (_I64, [_I32, _I32]),
+    "md_marching_tets": (C.c_int, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _I64, _P]),
+}
+
+_lib = None
+
+
+class MeshDiffusionHipError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen the library (once) and attach prototypes.  Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MeshDiffusionHipError(
+            f"{LIB_PATH} not found: run `python -m meshdiffusion_amd.build` (needs hipcc). "
+            "There is no CPU fallback for the HIP path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    if lib.md_abi_version() != 1:
+        raise MeshDiffusionHipError("ABI version mismatch")
+    for cfg, (nt, kc) in CFG_NT_KC.items():
+        v = [C.c_int32() for _ in range(6)]
+        lib.md_gemm_conv_cfg_info(cfg, *[C.byref(x) for x in v])
+        if (v[0].value, v[1].value) != (nt, kc):
+            raise MeshDiffusionHipError(f"cfg {cfg} NT/KC mismatch between _lib.py and the library")
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise MeshDiffusionHipError(f"{what} failed with code {rc}")
+
+
+def cfg_info(cfg):
+    lib = load()
+    v = [C.c_int32() for _ in range(6)]
+    check(lib.md_gemm_conv_cfg_info(cfg, *[C.byref(x) for x in v]), "md_gemm_conv_cfg_info")
+    keys = ("nt", "kc", "cols", "taps", "lds_bytes", "threads")
+    return dict(zip(keys, (x.value for x in v)))

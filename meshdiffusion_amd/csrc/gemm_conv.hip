@@ -1,0 +1,403 @@
+// md_gemm_conv: implicit-GEMM 3x3x3 / 1x1x1 convolution and batched GEMM on the
+// gfx950 matrix cores with a bf16x3 operand split (hi*hi + hi*lo + lo*hi, fp32
+// accumulate in v_mfma_f32_32x32x16_bf16).
+//
+// Replaces (reference, Python/ATen): nn.Conv3d 3x3x3 lib/diffusion/models/layers.py:118-124,
+// Downsample :626-643, Upsample :611-623, NIN :573-582, attention einsums :602,:606.
+//
+// Mapping   D[i][j] = sum_{tap,k} A[i][tap][k] * B[k][pos_j + tap]
+//   i (MFMA rows)  = output channel,  A = packed weight tiles (or an S16B tensor)
+//   j (MFMA cols)  = spatial position, B = S16B activations
+//   A workgroup owns NT rows x (TZ x TY x TX) positions.  Per K-chunk of KC input
+//   channels the input tile WITH HALO is staged once in LDS ([KC/8][hi|lo][slot][8]
+//   bf16, 16 B per slot => x-runs are bank-conflict free for ds_read_b128) and is
+//   re-used by all 27 taps; per tap a [KC/8][hi|lo][NT][8] weight tile (a linear
+//   copy of one WPK tile) is double-buffered through LDS with the global loads of
+//   tap t+1 in flight behind the MFMAs of tap t.
+//   Accumulator layout (32x32): lane holds col = lane&31 (position) and rows
+//   8q + 4*(lane>>5) + {0..3}: four consecutive output channels of one position,
+//   i.e. one 16-byte store into the 8-channel blocked F32B layout.
+#include "md_common.h"
+
+template <int NT_, int KC_, int TZ_, int TY_, int TX_, int TAPS_, int STRIDE_, int WR_, int WC_>
+struct GCfg {
+  static constexpr int NT = NT_, KC = KC_, TZ = TZ_, TY = TY_, TX = TX_, TAPS = TAPS_,
+                       STRIDE = STRIDE_, WR = WR_, WC = WC_;
+  static constexpr int MT = TZ * TY * TX;
+  static constexpr int NW = WR * WC;
+  static constexpr int NTHREADS = NW * 64;
+  static constexpr int RM = NT / (32 * WR);
+  static constexpr int CM = MT / (32 * WC);
+  static constexpr int ZH = (TAPS == 27) ? (TZ - 1) * STRIDE + 3 : 1;
+  static constexpr int YH = (TAPS == 27) ? (TY - 1) * STRIDE + 3 : 1;
+  static constexpr int XH = (TAPS == 27) ? (TX - 1) * STRIDE + 3 : MT;
+  static constexpr int XHP = XH;
+  static constexpr int HS = ZH * YH * XHP;  // halo slots
+  static constexpr int KG = KC / 8;         // 8-channel groups per K chunk
+  static constexpr int W_ITEMS = KG * 2 * NT;  // uint4 items of one weight tile
+  static constexpr int A_ITEMS = KG * 2 * HS;  // uint4 items of the activation halo tile
+  static constexpr int W_PER_THREAD = (W_ITEMS + NTHREADS - 1) / NTHREADS;
+  static constexpr int A_PER_THREAD = (A_ITEMS + NTHREADS - 1) / NTHREADS;
+  static constexpr int LDS_ITEMS = 2 * W_ITEMS + A_ITEMS;
+  static constexpr int LDS_BYTES = LDS_ITEMS * 16;
+  static constexpr int PADLO = (STRIDE == 2) ? 0 : 1;
+  static_assert(RM >= 1 && CM >= 1, "tile too small for the wave grid");
+  static_assert(NT % (32 * WR) == 0 && MT % (32 * WC) == 0, "tile / wave grid mismatch");
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+};
+
+template <class C>
+__global__ __launch_bounds__(C::NTHREADS) void md_gemm_conv_kernel(const MdGemmConvArgs A) {
+  __shared__ __attribute__((aligned(16))) uint4 smem[C::LDS_ITEMS];
+  uint4* wl = smem;                   // [2][KG*2][NT]
+  uint4* al = smem + 2 * C::W_ITEMS;  // [KG*2][HS]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = tid >> 6;
+  const int wr = wid / C::WC, wc = wid % C::WC;
+  const int j = lane & 31, h = lane >> 5;
+
+  // ---- tile coordinates -------------------------------------------------
+  const int D = A.D, H = A.H, W = A.W;
+  const int64_t P = (int64_t)D * H * W;
+  int tiles, z0 = 0, y0 = 0, x0 = 0;
+  int Di = D, Hi = H, Wi = W;  // input extents
+  if constexpr (C::TAPS == 27) {
+    const int ntx = W / C::TX, nty = H / C::TY, ntz = D / C::TZ;
+    tiles = ntx * nty * ntz;
+    if constexpr (C::STRIDE == 2) { Di = 2 * D; Hi = 2 * H; Wi = 2 * W; }
+    if (A.ups) { Di = D >> 1; Hi = H >> 1; Wi = W >> 1; }
+  } else {
+    tiles = W / C::MT;
+  }
+  const int b = blockIdx.x / tiles;
+  const int t = blockIdx.x % tiles;
+  if constexpr (C::TAPS == 27) {
+    const int ntx = W / C::TX, nty = H / C::TY;
+    x0 = (t % ntx) * C::TX;
+    y0 = ((t / ntx) % nty) * C::TY;
+    z0 = (t / (ntx * nty)) * C::TZ;
+  }
+  const int64_t Pin = (int64_t)Di * Hi * Wi;
+  const int rt = blockIdx.y;
+  const int ncc = A.kdim / C::KC;
+  const int nsteps = ncc * C::TAPS;
+  const int cing = A.kdim / 8;  // 8-channel groups of the B tensor
+
+  const uint4* bptr = (const uint4*)A.b + (int64_t)b * cing * 2 * Pin;
+  const uint4* aptr = (const uint4*)A.a;
+  if (A.a_src == MD_A_S16B) aptr += (int64_t)b * (A.a_bstride / 8);
+
+  // ---- per-lane fragment addresses ---------------------------------------
+  int a_row[C::RM];
+#pragma unroll
+  for (int rm = 0; rm < C::RM; ++rm) a_row[rm] = (wr * C::RM + rm) * 32 + j;
+  int b_slot[C::CM];
+#pragma unroll
+  for (int cm = 0; cm < C::CM; ++cm) {
+    const int p = (wc * C::CM + cm) * 32 + j;
+    if constexpr (C::TAPS == 27) {
+      const int x = p % C::TX, y = (p / C::TX) % C::TY, z = p / (C::TX * C::TY);
+      b_slot[cm] = ((z * C::STRIDE) * C::YH + y * C::STRIDE) * C::XHP + x * C::STRIDE;
+    } else {
+      b_slot[cm] = p;
+    }
+  }
+
+  f32x16 acc[C::RM][C::CM];
+#pragma unroll
+  for (int rm = 0; rm < C::RM; ++rm)
+#pragma unroll
+    for (int cm = 0; cm < C::CM; ++cm)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[rm][cm][r] = 0.f;
+
+  // ---- weight-tile prefetch (global -> registers) ------------------------
+  uint4 wreg[C::W_PER_THREAD];
+  auto w_issue = [&](int cc, int tap) {
+#pragma unroll
+    for (int i = 0; i < C::W_PER_THREAD; ++i) {
+      const int item = tid + i * C::NTHREADS;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (item < C::W_ITEMS) {
+        if (A.a_src == MD_A_PACKED) {
+          v = aptr[((int64_t)(rt * ncc + cc) * C::TAPS + tap) * C::W_ITEMS + item];
+        } else {
+          const int gp = item / C::NT, r = item % C::NT;
+          const int row = rt * C::NT + r;
+          if (row < A.a_rows)
+            v = aptr[((int64_t)(cc * C::KG + (gp >> 1)) * 2 + (gp & 1)) * A.a_rows + row];
+        }
+      }
+      wreg[i] = v;
+    }
+  };
+  auto w_commit = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < C::W_PER_THREAD; ++i) {
+      const int item = tid + i * C::NTHREADS;
+      if (item < C::W_ITEMS) wl[buf * C::W_ITEMS + item] = wreg[i];
+    }
+  };
+
+  // ---- activation halo tile: global -> LDS (zero fill outside the grid) ----
+  auto act_load = [&](int cc) {
+#pragma unroll
+    for (int i = 0; i < C::A_PER_THREAD; ++i) {
+      const int item = tid + i * C::NTHREADS;
+      if (item < C::A_ITEMS) {
+        const int gp = item / C::HS, slot = item % C::HS;
+        int64_t src;
+        bool inb = true;
+        if constexpr (C::TAPS == 27) {
+          const int hx = slot % C::XHP, hy = (slot / C::XHP) % C::YH, hz = slot / (C::XHP * C::YH);
+          int uz = z0 * C::STRIDE + hz - C::PADLO;
+          int uy = y0 * C::STRIDE + hy - C::PADLO;
+          int ux = x0 * C::STRIDE + hx - C::PADLO;
+          if (A.ups) {
+            inb = (uz >= 0) & (uz < D) & (uy >= 0) & (uy < H) & (ux >= 0) & (ux < W);
+            uz >>= 1; uy >>= 1; ux >>= 1;
+          } else {
+            inb = (uz >= 0) & (uz < Di) & (uy >= 0) & (uy < Hi) & (ux >= 0) & (ux < Wi);
+          }
+          if (C::XHP != C::XH) inb = inb & (hx < C::XH);
+          src = ((int64_t)uz * Hi + uy) * Wi + ux;
+        } else {
+          src = (int64_t)t * C::MT + slot;
+        }
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (inb) v = bptr[((int64_t)(cc * C::KG + (gp >> 1)) * 2 + (gp & 1)) * Pin + src];
+        al[item] = v;
+      }
+    }
+  };
+
+  const bf16x8* wlf = (const bf16x8*)wl;
+  const bf16x8* alf = (const bf16x8*)al;
+
+  // ---- main loop over (K chunk, tap) ---------------------------------------
+  int cc = 0, tap = 0, dz = 0, dy = 0, dx = 0;
+  w_issue(0, 0);
+  for (int s = 0; s < nsteps; ++s) {
+    if (tap == 0) {
+      __syncthreads();  // everyone finished reading the previous halo tile
+      act_load(cc);
+    }
+    const int buf = s & 1;
+    w_commit(buf);
+    __syncthreads();
+    // next step's coordinates + its weight loads go in flight behind the MFMAs
+    int ncc_ = cc, ntap = tap + 1, ndz = dz, ndy = dy, ndx = dx + 1;
+    if constexpr (C::TAPS == 27) {
+      if (ndx == 3) { ndx = 0; ++ndy; }
+      if (ndy == 3) { ndy = 0; ++ndz; }
+    }
+    if (ntap == C::TAPS) { ntap = 0; ndz = ndy = ndx = 0; ++ncc_; }
+    if (s + 1 < nsteps) w_issue(ncc_, ntap);
+
+    const int toff = (C::TAPS == 27) ? (dz * C::YH + dy) * C::XHP + dx : 0;
+    const bf16x8* wb = wlf + buf * C::W_ITEMS;
+#pragma unroll
+    for (int ks = 0; ks < C::KC / 16; ++ks) {
+      const int g = ks * 2 + h;
+      bf16x8 ahi[C::RM], alo[C::RM], bhi[C::CM], blo[C::CM];
+#pragma unroll
+      for (int rm = 0; rm < C::RM; ++rm) {
+        ahi[rm] = wb[(g * 2 + 0) * C::NT + a_row[rm]];
+        alo[rm] = wb[(g * 2 + 1) * C::NT + a_row[rm]];
+      }
+#pragma unroll
+      for (int cm = 0; cm < C::CM; ++cm) {
+        bhi[cm] = alf[(g * 2 + 0) * C::HS + b_slot[cm] + toff];
+        blo[cm] = alf[(g * 2 + 1) * C::HS + b_slot[cm] + toff];
+      }
+#pragma unroll
+      for (int rm = 0; rm < C::RM; ++rm)
+#pragma unroll
+        for (int cm = 0; cm < C::CM; ++cm) {
+          acc[rm][cm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo[rm], bhi[cm], acc[rm][cm], 0, 0, 0);
+          acc[rm][cm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[rm], blo[cm], acc[rm][cm], 0, 0, 0);
+          acc[rm][cm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[rm], bhi[cm], acc[rm][cm], 0, 0, 0);
+        }
+    }
+    cc = ncc_; tap = ntap; dz = ndz; dy = ndy; dx = ndx;
+  }
+
+  // ---- epilogue --------------------------------------------------------------
+  const float alpha = A.alpha;
+  const int rows = A.rows, rows_alloc = A.rows_alloc;
+  const int rg_alloc = rows_alloc / 8;
+#pragma unroll
+  for (int cm = 0; cm < C::CM; ++cm) {
+    const int p = (wc * C::CM + cm) * 32 + j;
+    int64_t gp;
+    if constexpr (C::TAPS == 27) {
+      const int x = p % C::TX, y = (p / C::TX) % C::TY, z = p / (C::TX * C::TY);
+      gp = ((int64_t)(z0 + z) * H + (y0 + y)) * W + (x0 + x);
+    } else {
+      gp = (int64_t)t * C::MT + p;
+    }
+#pragma unroll
+    for (int rm = 0; rm < C::RM; ++rm) {
+      const int rowbase = rt * C::NT + (wr * C::RM + rm) * 32;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int row = rowbase + 8 * q + 4 * h;  // first of 4 consecutive rows
+        if (row >= rows_alloc && A.out_mode != MD_OUT_NCDHW) continue;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float x = alpha * acc[rm][cm][q * 4 + e];
+          if (A.bias != nullptr && row + e < rows) x += A.bias[(int64_t)b * A.bias_bstride + row + e];
+          v[e] = x;
+        }
+        if (A.out_mode == MD_OUT_F32B) {
+          const int64_t o = (((int64_t)b * rg_alloc + (row >> 3)) * P + gp) * 8 + (row & 7);
+          if (A.residual != nullptr) {
+            const int64_t ro = (int64_t)b * A.res_bstride + (((int64_t)(row >> 3)) * P + gp) * 8 + (row & 7);
+            const f32x4 r4 = *(const f32x4*)(A.residual + ro);
+            v[0] += r4[0]; v[1] += r4[1]; v[2] += r4[2]; v[3] += r4[3];
+          }
+          f32x4 o4 = {v[0], v[1], v[2], v[3]};
+          *(f32x4*)((float*)A.out + o) = o4;
+        } else if (A.out_mode == MD_OUT_S16B) {
+          uint32_t hi[4], lo[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) md_split(v[e], hi[e], lo[e]);
+          const int64_t o = ((((int64_t)b * rg_alloc + (row >> 3)) * 2) * P + gp) * 8 + (row & 7);
+          uint2 h2 = make_uint2(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16));
+          uint2 l2 = make_uint2(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16));
+          *(uint2*)((uint16_t*)A.out + o) = h2;
+          *(uint2*)((uint16_t*)A.out + o + P * 8) = l2;
+        } else {  // NCDHW fp32 [B][rows][P]
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (row + e < rows) ((float*)A.out)[((int64_t)b * rows + row + e) * P + gp] = v[e];
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------
+using Cfg_C3_128 = GCfg<128, 32, 4, 8, 8, 27, 1, 2, 4>;
+using Cfg_C3_128_K16 = GCfg<128, 16, 4, 8, 8, 27, 1, 2, 4>;
+using Cfg_C3_32 = GCfg<32, 32, 4, 8, 8, 27, 1, 1, 8>;
+using Cfg_C3_LOW = GCfg<128, 32, 4, 4, 4, 27, 1, 4, 2>;
+using Cfg_C3_S2 = GCfg<128, 32, 4, 4, 4, 27, 2, 4, 2>;
+using Cfg_G1_128 = GCfg<128, 32, 1, 1, 256, 1, 1, 2, 4>;
+using Cfg_G1_128_LOW = GCfg<128, 32, 1, 1, 64, 1, 1, 4, 2>;
+using Cfg_G1_64_LOW = GCfg<64, 32, 1, 1, 64, 1, 1, 2, 2>;
+
+template <class C>
+static int launch_cfg(const MdGemmConvArgs& a, hipStream_t stream) {
+  if (a.kdim % C::KC != 0 || a.kdim <= 0) return MD_ERR_BAD_ARG;
+  if (a.rows <= 0 || a.rows_alloc % 8 != 0 || a.batch <= 0) return MD_ERR_BAD_ARG;
+  int tiles;
+  if (C::TAPS == 27) {
+    if (a.D % C::TZ || a.H % C::TY || a.W % C::TX) return MD_ERR_BAD_ARG;
+    if (a.ups && ((a.D | a.H | a.W) & 1)) return MD_ERR_BAD_ARG;
+    if (a.ups && C::STRIDE != 1) return MD_ERR_BAD_ARG;
+    tiles = (a.D / C::TZ) * (a.H / C::TY) * (a.W / C::TX);
+  } else {
+    if (a.D != 1 || a.H != 1 || a.W % C::MT || a.ups) return MD_ERR_BAD_ARG;
+    tiles = a.W / C::MT;
+  }
+  if (a.a_src == MD_A_S16B && a.a_rows <= 0) return MD_ERR_BAD_ARG;
+  const int row_tiles = (a.rows + C::NT - 1) / C::NT;
+  dim3 grid((unsigned)(tiles * a.batch), (unsigned)row_tiles, 1);
+  hipLaunchKernelGGL(md_gemm_conv_kernel<C>, grid, dim3(C::NTHREADS), 0, stream, a);
+  MD_HIP_CHECK_LAUNCH();
+  return MD_OK;
+}
+
+template <class C>
+static void cfg_info(int32_t* nt, int32_t* kc, int32_t* cols, int32_t* taps, int32_t* lds, int32_t* thr) {
+  if (nt) *nt = C::NT;
+  if (kc) *kc = C::KC;
+  if (cols) *cols = C::MT;
+  if (taps) *taps = C::TAPS;
+  if (lds) *lds = C::LDS_BYTES;
+  if (thr) *thr = C::NTHREADS;
+}
+
+#define MD_CFG_SWITCH(cfg, F, ...)                                  \
+  switch (cfg) {                                                    \
+    case MD_CFG_C3_128: F<Cfg_C3_128>(__VA_ARGS__); break;          \
+    case MD_CFG_C3_128_K16: F<Cfg_C3_128_K16>(__VA_ARGS__); break;  \
+    case MD_CFG_C3_32: F<Cfg_C3_32>(__VA_ARGS__); break;            \
+    case MD_CFG_C3_LOW: F<Cfg_C3_LOW>(__VA_ARGS__); break;          \
+    case MD_CFG_C3_S2: F<Cfg_C3_S2>(__VA_ARGS__); break;            \
+    case MD_CFG_G1_128: F<Cfg_G1_128>(__VA_ARGS__); break;          \
+    case MD_CFG_G1_128_LOW: F<Cfg_G1_128_LOW>(__VA_ARGS__); break;  \
+    case MD_CFG_G1_64_LOW: F<Cfg_G1_64_LOW>(__VA_ARGS__); break;    \
+    default: return MD_ERR_UNSUPPORTED;                             \
+  }
+
+extern "C" int md_gemm_conv(const MdGemmConvArgs* args, void* stream) {
+  if (args == nullptr || args->a == nullptr || args->b == nullptr || args->out == nullptr)
+    return MD_ERR_BAD_ARG;
+  int rc = MD_OK;
+  hipStream_t st = (hipStream_t)stream;
+  MD_CFG_SWITCH(args->cfg, rc = launch_cfg, *args, st);
+  return rc;
+}
+
+extern "C" int md_gemm_conv_cfg_info(int32_t cfg, int32_t* nt, int32_t* kc, int32_t* cols,
+                                     int32_t* taps, int32_t* lds_bytes, int32_t* threads) {
+  MD_CFG_SWITCH(cfg, cfg_info, nt, kc, cols, taps, lds_bytes, threads);
+  return MD_OK;
+}
+
+// ---- weight packing: fp32 -> WPK split-bf16 tiles ------------------------------------
+__global__ void md_pack_weights_kernel(const float* __restrict__ w, uint4* __restrict__ out,
+                                       int rows, int kdim, int taps, int64_t s_row, int64_t s_k,
+                                       int64_t s_tap, int nt, int kc, int64_t n_items) {
+  const int kg = kc / 8;
+  const int ncc = (kdim + kc - 1) / kc;
+  for (int64_t item = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; item < n_items;
+       item += (int64_t)gridDim.x * blockDim.x) {
+    int64_t r = item;
+    const int rr = (int)(r % nt); r /= nt;
+    const int part = (int)(r % 2); r /= 2;
+    const int g = (int)(r % kg); r /= kg;
+    const int tap = (int)(r % taps); r /= taps;
+    const int cc = (int)(r % ncc); r /= ncc;
+    const int rt = (int)r;
+    const int row = rt * nt + rr;
+    uint32_t v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int k = cc * kc + g * 8 + e;
+      float x = 0.f;
+      if (row < rows && k < kdim) x = w[row * s_row + k * s_k + tap * s_tap];
+      uint32_t hi, lo;
+      md_split(x, hi, lo);
+      v[e] = part ? lo : hi;
+    }
+    out[item] = make_uint4(v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16),
+                           v[6] | (v[7] << 16));
+  }
+}
+
+extern "C" int64_t md_packed_weight_bytes(int32_t rows, int32_t kdim, int32_t taps, int32_t nt,
+                                          int32_t kc) {
+  if (rows <= 0 || kdim <= 0 || taps <= 0 || nt <= 0 || kc <= 0 || (kc % 8)) return MD_ERR_BAD_ARG;
+  const int64_t rt = (rows + nt - 1) / nt, ncc = (kdim + kc - 1) / kc;
+  return rt * ncc * taps * (int64_t)(kc / 8) * 2 * nt * 16;
+}
+
+extern "C" int md_pack_weights(const float* w, void* wpk, int32_t rows, int32_t kdim, int32_t taps,
+                               int64_t s_row, int64_t s_k, int64_t s_tap, int32_t nt, int32_t kc,
+                               void* stream) {
+  const int64_t bytes = md_packed_weight_bytes(rows, kdim, taps, nt, kc);
+  if (bytes < 0 || w == nullptr || wpk == nullptr) return MD_ERR_BAD_ARG;
+  const int64_t n_items = bytes / 16;
+  int blocks = (int)((n_items + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(md_pack_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w,
+                     (uint4*)wpk, rows, kdim, taps, s_row, s_k, s_tap, nt, kc, n_items);
+  MD_HIP_CHECK_LAUNCH();
+  return MD_OK;
+}

@@ -1,0 +1,42 @@
+// Shared device helpers for the gfx950 kernels (wave64, CDNA4).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "meshdiffusion_hip.h"
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8;  // 8 bf16 = 4 VGPRs (MFMA A/B fragment)
+typedef __attribute__((ext_vector_type(16))) float f32x16; // 32x32 MFMA accumulator
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+#define MD_HIP_CHECK_LAUNCH()                      \
+  do {                                             \
+    hipError_t e__ = hipGetLastError();            \
+    if (e__ != hipSuccess) return (int)e__;        \
+  } while (0)
+
+// fp32 -> bf16 bits, round to nearest even (finite inputs).
+__device__ __forceinline__ uint32_t md_f2bf(float f) {
+  uint32_t u = __float_as_uint(f);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return u >> 16;
+}
+__device__ __forceinline__ float md_bf2f(uint32_t h) { return __uint_as_float(h << 16); }
+
+// bf16x3 split: x ~= hi + lo with hi = bf16(x), lo = bf16(x - hi).
+__device__ __forceinline__ void md_split(float x, uint32_t& hi, uint32_t& lo) {
+  hi = md_f2bf(x);
+  lo = md_f2bf(x - md_bf2f(hi));
+}
+
+__device__ __forceinline__ float md_silu(float x) { return x / (1.0f + expf(-x)); }
+
+__device__ __forceinline__ float md_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float md_wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}

@@ -1,0 +1,159 @@
+// GroupNorm(32, C, eps) statistics / apply (+SiLU) / bf16x3 split, 8-channel blocked layouts.
+// Replaces nn.GroupNorm + nn.SiLU (reference lib/diffusion/models/layers.py:652,660,676,681,589;
+// ddpm_res64.py:120,186) and the torch.cat before it (ddpm_res64.py:174-176).
+// All three kernels are pure HBM streaming: 16 B per lane, consecutive lanes contiguous.
+#include "md_common.h"
+
+static constexpr int GN_BLOCK = 256;
+static constexpr int GN_ITEMS = 16;                              // float4 items per thread
+static constexpr int GN_CHUNK = GN_BLOCK * GN_ITEMS / 2;         // positions per block
+
+// x: F32B [B][C/8][P][8]; sums: double [B][c_total][2] (sum, sumsq), pre-zeroed.
+__global__ __launch_bounds__(GN_BLOCK) void md_gn_stats_kernel(const float* __restrict__ x,
+                                                               double* __restrict__ sums, int C,
+                                                               int64_t P, int c_total, int c_off) {
+  const int cg = blockIdx.y, b = blockIdx.z;
+  const int tid = threadIdx.x, half = tid & 1;
+  const int64_t p0 = (int64_t)blockIdx.x * GN_CHUNK;
+  const f32x4* xp = (const f32x4*)(x + (((int64_t)b * (C / 8) + cg) * P) * 8);
+  float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < GN_ITEMS; ++i) {
+    const int64_t pos = p0 + ((tid + i * GN_BLOCK) >> 1);
+    if (pos < P) {
+      const f32x4 v = xp[pos * 2 + half];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { s[e] += v[e]; q[e] += v[e] * v[e]; }
+    }
+  }
+  // reduce over lanes with equal parity (keeps `half`), then over the 4 waves
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+#pragma unroll
+    for (int o = 32; o > 1; o >>= 1) { s[e] += __shfl_xor(s[e], o, 64); q[e] += __shfl_xor(q[e], o, 64); }
+  }
+  __shared__ float red[GN_BLOCK / 64][2][8];
+  const int lane = tid & 63, wid = tid >> 6;
+  if (lane < 2) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { red[wid][lane][e] = s[e]; red[wid][lane][4 + e] = q[e]; }
+  }
+  __syncthreads();
+  if (tid < 16) {
+    const int hh = (tid >> 2) & 1, e = tid & 3, isq = tid >> 3;
+    double acc = 0.0;
+    for (int w = 0; w < GN_BLOCK / 64; ++w) acc += (double)red[w][hh][isq * 4 + e];
+    const int c = c_off + cg * 8 + hh * 4 + e;
+    atomicAdd(&sums[((int64_t)b * c_total + c) * 2 + isq], acc);
+  }
+}
+
+// params: float4 [B][c_total] = (mean, rstd*gamma, beta, 0)
+__global__ void md_gn_finalize_kernel(const double* __restrict__ sums, const float* __restrict__ gamma,
+                                      const float* __restrict__ beta, float* __restrict__ params,
+                                      int c_total, int groups, int64_t P, float eps) {
+  const int b = blockIdx.x / groups, g = blockIdx.x % groups;
+  const int cpg = c_total / groups;
+  const int lane = threadIdx.x;
+  double s = 0.0, q = 0.0;
+  for (int c = lane; c < cpg; c += 64) {
+    const int64_t o = ((int64_t)b * c_total + g * cpg + c) * 2;
+    s += sums[o];
+    q += sums[o + 1];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+  const double n = (double)cpg * (double)P;
+  const double mean = s / n;
+  double var = q / n - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  for (int c = lane; c < cpg; c += 64) {
+    const int ch = g * cpg + c;
+    f32x4 o4 = {(float)mean, rstd * gamma[ch], beta[ch], 0.f};
+    *(f32x4*)(params + ((int64_t)b * c_total + ch) * 4) = o4;
+  }
+}
+
+// out: S16B [B][c_total/8][2][P][8]
+__global__ __launch_bounds__(GN_BLOCK) void md_gn_apply_kernel(const float* __restrict__ x,
+                                                               const float* __restrict__ params,
+                                                               uint16_t* __restrict__ out, int C,
+                                                               int64_t P, int c_total, int c_off,
+                                                               int norm, int silu) {
+  const int cg = blockIdx.y, b = blockIdx.z;
+  const int tid = threadIdx.x, half = tid & 1;
+  const int64_t p0 = (int64_t)blockIdx.x * GN_CHUNK;
+  const f32x4* xp = (const f32x4*)(x + (((int64_t)b * (C / 8) + cg) * P) * 8);
+  float mean[4], a[4], bt[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    if (norm) {
+      const f32x4 pr = *(const f32x4*)(params + ((int64_t)b * c_total + c_off + cg * 8 + half * 4 + e) * 4);
+      mean[e] = pr[0]; a[e] = pr[1]; bt[e] = pr[2];
+    } else {
+      mean[e] = 0.f; a[e] = 1.f; bt[e] = 0.f;
+    }
+  }
+  const int64_t plane = P * 8;
+  uint16_t* ohi = out + (((int64_t)b * (c_total / 8) + (c_off / 8) + cg) * 2) * plane;
+#pragma unroll
+  for (int i = 0; i < GN_ITEMS; ++i) {
+    const int64_t pos = p0 + ((tid + i * GN_BLOCK) >> 1);
+    if (pos < P) {
+      const f32x4 v = xp[pos * 2 + half];
+      uint32_t hi[4], lo[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float y = v[e];
+        if (norm) y = (y - mean[e]) * a[e] + bt[e];
+        if (silu) y = md_silu(y);
+        md_split(y, hi[e], lo[e]);
+      }
+      const int64_t o = pos * 8 + half * 4;
+      *(uint2*)(ohi + o) = make_uint2(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16));
+      *(uint2*)(ohi + plane + o) = make_uint2(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16));
+    }
+  }
+}
+
+extern "C" int md_gn_stats(const float* x, double* sums, int32_t batch, int32_t C, int64_t P,
+                           int32_t c_total, int32_t c_off, void* stream) {
+  if (!x || !sums || batch <= 0 || C <= 0 || (C % 8) || P <= 0 || c_off < 0 || c_off + C > c_total)
+    return MD_ERR_BAD_ARG;
+  dim3 grid((unsigned)((P + GN_CHUNK - 1) / GN_CHUNK), (unsigned)(C / 8), (unsigned)batch);
+  hipLaunchKernelGGL(md_gn_stats_kernel, grid, dim3(GN_BLOCK), 0, (hipStream_t)stream, x, sums, C, P,
+                     c_total, c_off);
+  MD_HIP_CHECK_LAUNCH();
+  return MD_OK;
+}
+
+extern "C" int md_gn_finalize(const double* sums, const float* gamma, const float* beta,
+                              float* params, int32_t batch, int32_t c_total, int32_t groups,
+                              int64_t P, float eps, void* stream) {
+  if (!sums || !gamma || !beta || !params || batch <= 0 || groups <= 0 || (c_total % groups))
+    return MD_ERR_BAD_ARG;
+  hipLaunchKernelGGL(md_gn_finalize_kernel, dim3((unsigned)(batch * groups)), dim3(64), 0,
+                     (hipStream_t)stream, sums, gamma, beta, params, c_total, groups, P, eps);
+  MD_HIP_CHECK_LAUNCH();
+  return MD_OK;
+}
+
+extern "C" int md_gn_apply(const float* x, const float* params, void* out, int32_t batch, int32_t C,
+                           int64_t P, int32_t c_total, int32_t c_off, int32_t norm, int32_t silu,
+                           void* stream) {
+  if (!x || !out || (norm && !params) || batch <= 0 || C <= 0 || (C % 8) || (c_off % 8) ||
+      (c_total % 8) || c_off + C > c_total || P <= 0)
+    return MD_ERR_BAD_ARG;
+  dim3 grid((unsigned)((P + GN_CHUNK - 1) / GN_CHUNK), (unsigned)(C / 8), (unsigned)batch);
+  hipLaunchKernelGGL(md_gn_apply_kernel, grid, dim3(GN_BLOCK), 0, (hipStream_t)stream, x, params,
+                     (uint16_t*)out, C, P, c_total, c_off, norm, silu);
+  MD_HIP_CHECK_LAUNCH();
+  return MD_OK;
+}
+
+extern "C" int md_zero(void* p, int64_t bytes, void* stream) {
+  if (!p || bytes < 0) return MD_ERR_BAD_ARG;
+  hipError_t e = hipMemsetAsync(p, 0, (size_t)bytes, (hipStream_t)stream);
+  return e == hipSuccess ? MD_OK : (int)e;
+}
