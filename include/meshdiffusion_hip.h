@@ -88,6 +88,7 @@ typedef struct MdGemmConvArgs {
   int64_t a_bstride;     /* a_src=1: elements (bf16) between batches of A; 0 = shared          */
   int64_t bias_bstride;  /* floats between batches of bias; 0 = shared                         */
   int64_t res_bstride;   /* floats between batches of residual; 0 = shared                     */
+  int64_t b_bstride;     /* elements (bf16) between batches of B; 0 = shared                   */
 } MdGemmConvArgs;
 
 int md_abi_version(void);
@@ -179,6 +180,16 @@ int md_ancestral_step(const float* x, const float* eps, const float* z, const fl
 int md_inpaint_blend(float* x, const float* src, const float* pmask, const float* gmask,
                      int32_t batch, int32_t C, int32_t ch, int64_t P, int64_t src_bstride,
                      void* stream);
+
+/*
+ * Re-noise the conditioned channel to the current level (sampling.py:460-466), in place:
+ *   upd = coef[b][0]*x + coef[b][1]*z[b] ; x[ch] = (x[ch]*(1-m) + upd*m)*gm ; x_mean[ch] = x[ch]
+ * coef[b] = (exp(log_mean_coeff(t)), std(t)) of VPSDE.marginal_prob (sde_lib.py:210-214);
+ * z is [B][P]; x_mean may be NULL.
+ */
+int md_inpaint_renoise(float* x, float* x_mean, const float* z, const float* pmask,
+                       const float* gmask, const float* coef, int32_t batch, int32_t C,
+                       int32_t ch, int64_t P, void* stream);
 
 /*
  * Marching tetrahedra on a STATIC tet grid (nvdiffrec/lib/geometry/dmtet.py:105-163),

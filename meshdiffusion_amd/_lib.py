@@ -29,7 +29,7 @@ class MdGemmConvArgs(C.Structure):
         ("rows", C.c_int32), ("rows_alloc", C.c_int32), ("kdim", C.c_int32), ("D", C.c_int32),
         ("H", C.c_int32), ("W", C.c_int32), ("ups", C.c_int32), ("a_src", C.c_int32),
         ("out_mode", C.c_int32), ("a_rows", C.c_int32), ("a_bstride", C.c_int64),
-        ("bias_bstride", C.c_int64), ("res_bstride", C.c_int64),
+        ("bias_bstride", C.c_int64), ("res_bstride", C.c_int64), ("b_bstride", C.c_int64),
     ]
 
 
@@ -56,6 +56,7 @@ SIGNATURES = {
     "md_softmax_keys": (C.c_int, [_P, _P, _I32, _I32, _I32, _P]),
     "md_ancestral_step": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I64, _P]),
     "md_inpaint_blend": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _I64, _I64, _P]),
+    "md_inpaint_renoise": (C.c_int, [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I64, _P]),
     "md_marching_tets_workspace_bytes": (_I64, [_I32, _I32]),
     "md_marching_tets": (C.c_int, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _I64, _P]),
 }

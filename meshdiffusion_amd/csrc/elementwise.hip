@@ -172,6 +172,29 @@ __global__ void md_inpaint_blend_kernel(float* __restrict__ x, const float* __re
     xc[i] = v;
   }
 }
+
+// re-noise the conditioned channel to level t (reference sampling.py:460-466):
+//   upd = mean_coef[b]*x + std[b]*z ;  x = (x*(1-m) + upd*m)*gm ;  x_mean[ch] = x[ch]
+__global__ void md_inpaint_renoise_kernel(float* __restrict__ x, float* __restrict__ x_mean,
+                                          const float* __restrict__ z, const float* __restrict__ pmask,
+                                          const float* __restrict__ gmask, const float* __restrict__ coef,
+                                          int C, int ch, int64_t P) {
+  const int b = blockIdx.y;
+  const float mc = coef[b * 2 + 0], sd = coef[b * 2 + 1];
+  float* xc = x + ((int64_t)b * C + ch) * P;
+  float* xm = x_mean ? x_mean + ((int64_t)b * C + ch) * P : nullptr;
+  const float* zc = z + (int64_t)b * P;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (int64_t)gridDim.x * blockDim.x) {
+    const float m = pmask[i];
+    const float xv = xc[i];
+    const float mean = mc * xv;
+    const float upd = mean + sd * zc[i];
+    float v = xv * (1.f - m) + upd * m;
+    if (gmask) v = v * gmask[i];
+    xc[i] = v;
+    if (xm) xm[i] = v;
+  }
+}
 #pragma clang fp contract(fast)
 
 extern "C" int md_inpaint_blend(float* x, const float* src, const float* pmask, const float* gmask,
@@ -182,6 +205,18 @@ extern "C" int md_inpaint_blend(float* x, const float* src, const float* pmask, 
   if (blocks > 1024) blocks = 1024;
   hipLaunchKernelGGL(md_inpaint_blend_kernel, dim3((unsigned)blocks, (unsigned)batch), dim3(256), 0,
                      (hipStream_t)stream, x, src, pmask, gmask, C, ch, P, src_bstride);
+  MD_HIP_CHECK_LAUNCH();
+  return MD_OK;
+}
+
+extern "C" int md_inpaint_renoise(float* x, float* x_mean, const float* z, const float* pmask,
+                                  const float* gmask, const float* coef, int32_t batch, int32_t C,
+                                  int32_t ch, int64_t P, void* stream) {
+  if (!x || !z || !pmask || !coef || batch <= 0 || C <= 0 || ch < 0 || ch >= C || P <= 0) return MD_ERR_BAD_ARG;
+  int blocks = (int)((P + 255) / 256);
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(md_inpaint_renoise_kernel, dim3((unsigned)blocks, (unsigned)batch), dim3(256), 0,
+                     (hipStream_t)stream, x, x_mean, z, pmask, gmask, coef, C, ch, P);
   MD_HIP_CHECK_LAUNCH();
   return MD_OK;
 }

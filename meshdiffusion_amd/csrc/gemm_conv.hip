@@ -83,9 +83,8 @@ __global__ __launch_bounds__(C::NTHREADS) void md_gemm_conv_kernel(const MdGemmC
   const int rt = blockIdx.y;
   const int ncc = A.kdim / C::KC;
   const int nsteps = ncc * C::TAPS;
-  const int cing = A.kdim / 8;  // 8-channel groups of the B tensor
 
-  const uint4* bptr = (const uint4*)A.b + (int64_t)b * cing * 2 * Pin;
+  const uint4* bptr = (const uint4*)A.b + (int64_t)b * (A.b_bstride / 8);
   const uint4* aptr = (const uint4*)A.a;
   if (A.a_src == MD_A_S16B) aptr += (int64_t)b * (A.a_bstride / 8);
 

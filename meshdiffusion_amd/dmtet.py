@@ -1,0 +1,145 @@
+"""Marching tetrahedra on MI355X -- host side of md_marching_tets.
+
+Drop-in for the reference's nvdiffrec/lib/geometry/dmtet.py `DMTet.__call__` :105-163
+(same signature and 6-tuple result) plus the grid -> tet-vertex gather of
+nvdiffrec/eval.py:389-419 / `get_deformed` dmtet.py:293-304 and the grid-mask construction of
+data/get_tet_mask.py:9-37.
+
+Static preprocessing (once per tet grid, torch ops): the lexicographically sorted unique edge list
+of ALL tets and the [T,6] tet->edge-id table.  Per call: ONE kernel launch for M meshes.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .hip_ops import _ptr, _stream
+
+BASE_TET_EDGES = (0, 1, 0, 2, 0, 3, 1, 2, 1, 3, 2, 3)
+
+
+class TetTables:
+    """Static tables of one tet grid, resident on the device."""
+
+    def __init__(self, tets, device):
+        tets = torch.as_tensor(tets).to(device=device, dtype=torch.int64)
+        be = torch.tensor(BASE_TET_EDGES, dtype=torch.int64, device=device)
+        e = tets[:, be].reshape(-1, 2)
+        e = torch.stack([e.min(dim=1).values, e.max(dim=1).values], dim=-1)
+        uniq, inv = torch.unique(e, dim=0, return_inverse=True)  # rows sorted lexicographically
+        self.n_tets, self.n_edges = tets.shape[0], uniq.shape[0]
+        self.tets = tets.to(torch.int32).contiguous()
+        self.edges = uniq.to(torch.int32).contiguous()
+        self.tet_edges = inv.reshape(-1, 6).to(torch.int32).contiguous()
+        self.tets64 = tets
+
+
+def marching_tets_batch(pos, sdf, tables):
+    """pos [M,N,3] f32, sdf [M,N] f32 on the GPU -> list of (verts [V,3], faces [F,3] int64, face_tet [F])."""
+    lib = _lib.load()
+    if not pos.is_cuda:
+        raise _lib.MeshDiffusionHipError("marching tets runs on the GPU only (no CPU fallback)")
+    pos = pos.to(torch.float32).contiguous()
+    sdf = sdf.to(torch.float32).contiguous()
+    M, N = sdf.shape
+    E, T = tables.n_edges, tables.n_tets
+    dev = pos.device
+    verts = torch.empty((M, E, 3), dtype=torch.float32, device=dev)
+    faces = torch.empty((M, 2 * T, 3), dtype=torch.int64, device=dev)
+    face_tet = torch.empty((M, 2 * T), dtype=torch.int64, device=dev)
+    counts = torch.empty((M, 4), dtype=torch.int32, device=dev)
+    ws_bytes = lib.md_marching_tets_workspace_bytes(M, E)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    _lib.check(lib.md_marching_tets(_ptr(pos), _ptr(sdf), _ptr(tables.tets), _ptr(tables.edges),
+                                    _ptr(tables.tet_edges), M, N, E, T, _ptr(verts), _ptr(faces),
+                                    _ptr(face_tet), _ptr(counts), _ptr(ws), ws_bytes, _stream()),
+               "md_marching_tets")
+    cnt = counts.cpu().numpy()  # the only host sync: result sizes
+    return [(verts[m, :cnt[m, 0]], faces[m, :cnt[m, 1]], face_tet[m, :cnt[m, 1]]) for m in range(M)], cnt
+
+
+def _map_uv(face_tet, n1, num_tets, device):
+    """Per-tet texture atlas (dmtet.py:70-99): face_gidx = 2*tet (+1 for a tet's second triangle)."""
+    max_idx = num_tets * 2
+    Nn = int(np.ceil(np.sqrt((max_idx + 1) // 2)))
+    lin = torch.linspace(0, 1 - (1 / Nn), Nn, dtype=torch.float32, device=device)
+    tex_y, tex_x = torch.meshgrid(lin, lin, indexing="ij")
+    pad = 0.9 / Nn
+    uvs = torch.stack([tex_x, tex_y, tex_x + pad, tex_y, tex_x + pad, tex_y + pad, tex_x, tex_y + pad],
+                      dim=-1).view(-1, 2)
+    F = face_tet.shape[0]
+    tri_idx = torch.zeros(F, dtype=torch.int64, device=device)
+    if F > n1:
+        tri_idx[n1:] = torch.arange(F - n1, device=device) % 2
+    tet_idx = face_tet  # (face_gidx // 2); _idx(t, N) = (t // N) * N + t % N = t
+    uv_idx = torch.stack((tet_idx * 4, tet_idx * 4 + tri_idx + 1, tet_idx * 4 + tri_idx + 2), dim=-1).view(-1, 3)
+    return uvs, uv_idx
+
+
+class DMTet:
+    """`DMTet()(pos_nx3, sdf_n, tet_fx4) -> (verts, faces, uvs, uv_idx, face_to_valid_tet, valid_vert_idx)`."""
+
+    def __init__(self):
+        self._tables = {}
+
+    def tables_for(self, tet_fx4):
+        key = (tet_fx4.data_ptr(), tuple(tet_fx4.shape), str(tet_fx4.device), tet_fx4._version)
+        if key not in self._tables:
+            self._tables = {key: TetTables(tet_fx4, tet_fx4.device)}
+        return self._tables[key]
+
+    def __call__(self, pos_nx3, sdf_n, tet_fx4):
+        with torch.no_grad():
+            tb = self.tables_for(tet_fx4)
+            meshes, cnt = marching_tets_batch(pos_nx3[None], sdf_n[None], tb)
+            verts, faces, face_tet = meshes[0]
+            uvs, uv_idx = _map_uv(face_tet, int(cnt[0, 2]), tb.n_tets, verts.device)
+            tets_used = torch.unique(face_tet)
+            valid_vert_idx = tb.tets64[tets_used].long().unique()
+            return verts, faces, uvs, uv_idx, face_tet.long(), valid_vert_idx
+
+
+# ---- cubic grid <-> tet grid ---------------------------------------------------------------------
+def tet_vertices_to_grid_index(vertices):
+    """eval.py:389-398 / evaler.py:187-195: tet-vertex positions -> integer grid coordinates."""
+    v = torch.as_tensor(vertices)
+    uniq = v[:].unique()
+    dx = uniq[1] - uniq[0]
+    return torch.round((v - v.min()) / dx).long()
+
+
+def grid_mask_from_tets(vertices, R):
+    """data/get_tet_mask.py:9-37: 1 where a tet-grid vertex lives, else 0.  float32 [R,R,R]."""
+    idx = tet_vertices_to_grid_index(vertices)
+    m = torch.zeros(R, R, R)
+    m[idx[:, 0], idx[:, 1], idx[:, 2]] = 1.0
+    return m
+
+
+class GridMesher:
+    """`.npy` grids [M,4,R,R,R] -> meshes, the eval.py:400-431 path without the renderer."""
+
+    def __init__(self, tet_vertices, tet_indices, R, mesh_scale=2.1, deform_scale=2.0, device="cuda"):
+        self.R, self.deform_scale = R, deform_scale
+        dev = torch.device(device)
+        v = torch.as_tensor(tet_vertices, dtype=torch.float32)
+        self.idx = tet_vertices_to_grid_index(v).to(dev)
+        self.verts = (v * mesh_scale).to(dev)            # dmtet.py:219
+        self.tables = TetTables(torch.as_tensor(tet_indices), dev)
+
+    def inputs(self, grids):
+        g = torch.as_tensor(grids).to(self.verts.device, torch.float32)
+        i0, i1, i2 = self.idx[:, 0], self.idx[:, 1], self.idx[:, 2]
+        sdf = torch.sign(g[:, 0][:, i0, i1, i2])                              # [M,N]
+        deform = g[:, 1:][:, :, i0, i1, i2].transpose(1, 2).clip(-1.0, 1.0)     # [M,N,3]
+        pos = self.verts[None] + 2 / (self.R * 2) * deform * self.deform_scale  # dmtet.py:303
+        return pos.contiguous(), sdf.contiguous()
+
+    def __call__(self, grids):
+        pos, sdf = self.inputs(grids)
+        meshes, _ = marching_tets_batch(pos, sdf, self.tables)
+        return meshes
+
+
+_ = C

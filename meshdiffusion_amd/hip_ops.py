@@ -1,0 +1,262 @@
+"""Host-side wrappers of the C ABI: torch tensors provide device memory and the stream,
+every computation happens in libmeshdiffusion_hip.so.  No fallback paths.
+
+Blocked device layouts: F32B float32 [B][C/8][P][8]; S16B bf16 [B][C/8][2][P][8].
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib
+from ._lib import (A_PACKED, A_S16B, CFG_C3_128, CFG_C3_128_K16, CFG_C3_32, CFG_C3_LOW, CFG_C3_S2,
+                   CFG_G1_128, CFG_G1_128_LOW, CFG_G1_64_LOW, CFG_NT_KC, OUT_F32B, OUT_NCDHW, OUT_S16B,
+                   MdGemmConvArgs, check)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _require_cuda(t, name):
+    if not t.is_cuda:
+        raise _lib.MeshDiffusionHipError(f"{name} must live on the GPU: the HIP path has no CPU fallback")
+
+
+def f32b_empty(B, Cc, P, device):
+    return torch.empty((B, Cc // 8, P, 8), dtype=torch.float32, device=device)
+
+
+def s16b_empty(B, Cc, P, device):
+    return torch.empty((B, Cc // 8, 2, P, 8), dtype=torch.bfloat16, device=device)
+
+
+# ---------------------------------------------------------------------------------------------
+# weights
+# ---------------------------------------------------------------------------------------------
+class PackedWeight:
+    """Split-bf16 WPK tiles of one conv / NIN weight (built on the device by md_pack_weights)."""
+
+    def __init__(self, w, kind, cfg, device):
+        lib = _lib.load()
+        nt, kc = CFG_NT_KC[cfg]
+        w = w.detach().to(device=device, dtype=torch.float32).contiguous()
+        _require_cuda(w, "weight")
+        if kind == "conv":  # [Co][Ci][k][k][k]
+            rows, kdim, taps = w.shape[0], w.shape[1], w.shape[2] * w.shape[3] * w.shape[4]
+            s_row, s_k, s_tap = kdim * taps, taps, 1
+        elif kind == "nin":  # NIN W [Ci][Co]
+            rows, kdim, taps = w.shape[1], w.shape[0], 1
+            s_row, s_k, s_tap = 1, rows, 0
+        elif kind == "rows":  # plain [rows][K]
+            rows, kdim, taps = w.shape[0], w.shape[1], 1
+            s_row, s_k, s_tap = kdim, 1, 0
+        else:
+            raise ValueError(kind)
+        self.rows, self.taps, self.cfg = rows, taps, cfg
+        self.kdim = ((kdim + kc - 1) // kc) * kc  # K padded to the chunk size (zero filled)
+        nbytes = lib.md_packed_weight_bytes(rows, kdim, taps, nt, kc)
+        if nbytes <= 0:
+            raise _lib.MeshDiffusionHipError("md_packed_weight_bytes failed")
+        self.data = torch.empty(nbytes // 2, dtype=torch.bfloat16, device=device)
+        check(lib.md_pack_weights(_ptr(w), _ptr(self.data), rows, kdim, taps, s_row, s_k, s_tap, nt, kc,
+                                  _stream()), "md_pack_weights")
+
+
+def pack_s16b_from_matrix(w_kp, device):
+    """[K][P] fp32 matrix -> S16B [1][K/8][2][P][8] (used for a weight that plays the B operand)."""
+    lib = _lib.load()
+    w = w_kp.detach().to(device=device, dtype=torch.float32).contiguous()
+    K, P = w.shape
+    out = s16b_empty(1, K, P, device)
+    check(lib.md_ncdhw_to_s16b(_ptr(w), _ptr(out), 1, K, K, P, _stream()), "md_ncdhw_to_s16b")
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# GEMM / conv
+# ---------------------------------------------------------------------------------------------
+def gemm_conv(*, cfg, a, b, out, batch, rows, rows_alloc, kdim, dims, bias=None, bias_bstride=0,
+              residual=None, res_bstride=0, alpha=1.0, ups=0, a_src=A_PACKED, a_rows=0, a_bstride=0,
+              b_bstride=None, out_mode=OUT_F32B):
+    lib = _lib.load()
+    D, H, W = dims
+    args = MdGemmConvArgs()
+    args.a, args.b, args.out = a.data_ptr(), b.data_ptr(), out.data_ptr()
+    args.bias = bias.data_ptr() if bias is not None else None
+    args.residual = residual.data_ptr() if residual is not None else None
+    args.alpha = alpha
+    args.cfg, args.batch, args.rows, args.rows_alloc, args.kdim = cfg, batch, rows, rows_alloc, kdim
+    args.D, args.H, args.W, args.ups = D, H, W, ups
+    args.a_src, args.out_mode, args.a_rows = a_src, out_mode, a_rows
+    args.a_bstride, args.bias_bstride, args.res_bstride = a_bstride, bias_bstride, res_bstride
+    if b_bstride is None:
+        pin = D * H * W
+        if ups:
+            pin //= 8
+        elif cfg == CFG_C3_S2:
+            pin *= 8
+        b_bstride = (kdim // 8) * 2 * pin * 8
+    args.b_bstride = b_bstride
+    check(lib.md_gemm_conv(C.byref(args), _stream()), f"md_gemm_conv(cfg={cfg})")
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# GroupNorm (+SiLU) + split, with concatenated sources
+# ---------------------------------------------------------------------------------------------
+def gn_params(parts, gamma, beta, B, P, eps=1e-6, groups=32):
+    """parts: list of (F32B tensor, C).  Returns the float4 params tensor [B][Ctot][4]."""
+    lib = _lib.load()
+    dev = parts[0][0].device
+    ctot = sum(c for _, c in parts)
+    sums = torch.empty((B, ctot, 2), dtype=torch.float64, device=dev)
+    check(lib.md_zero(_ptr(sums), sums.numel() * 8, _stream()), "md_zero")
+    off = 0
+    for t, c in parts:
+        check(lib.md_gn_stats(_ptr(t), _ptr(sums), B, c, P, ctot, off, _stream()), "md_gn_stats")
+        off += c
+    params = torch.empty((B, ctot, 4), dtype=torch.float32, device=dev)
+    check(lib.md_gn_finalize(_ptr(sums), _ptr(gamma), _ptr(beta), _ptr(params), B, ctot, groups, P,
+                             eps, _stream()), "md_gn_finalize")
+    return params
+
+
+def gn_apply(parts, params, B, P, norm=True, silu=True, out=None):
+    lib = _lib.load()
+    dev = parts[0][0].device
+    ctot = sum(c for _, c in parts)
+    if out is None:
+        out = s16b_empty(B, ctot, P, dev)
+    off = 0
+    for t, c in parts:
+        check(lib.md_gn_apply(_ptr(t), _ptr(params) if norm else None, _ptr(out), B, c, P, ctot, off,
+                              1 if norm else 0, 1 if silu else 0, _stream()), "md_gn_apply")
+        off += c
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# small ops
+# ---------------------------------------------------------------------------------------------
+def timestep_embedding(t, dim):
+    lib = _lib.load()
+    _require_cuda(t, "timesteps")
+    t = t.to(torch.float32).contiguous()
+    emb = torch.empty((t.shape[0], dim), dtype=torch.float32, device=t.device)
+    check(lib.md_timestep_embedding(_ptr(t), _ptr(emb), t.shape[0], dim, _stream()), "md_timestep_embedding")
+    return emb
+
+
+def linear(x, w, bias, silu_in=False):
+    lib = _lib.load()
+    B, in_dim = x.shape
+    out_dim = w.shape[0]
+    y = torch.empty((B, out_dim), dtype=torch.float32, device=x.device)
+    check(lib.md_linear(_ptr(x), _ptr(w), _ptr(bias), _ptr(y), B, in_dim, out_dim, 1 if silu_in else 0,
+                        _stream()), "md_linear")
+    return y
+
+
+def ncdhw_to_s16b(x, c_pad):
+    lib = _lib.load()
+    _require_cuda(x, "x")
+    x = x.to(torch.float32).contiguous()
+    B, Cc = x.shape[0], x.shape[1]
+    P = x[0, 0].numel()
+    out = s16b_empty(B, c_pad, P, x.device)
+    check(lib.md_ncdhw_to_s16b(_ptr(x), _ptr(out), B, Cc, c_pad, P, _stream()), "md_ncdhw_to_s16b")
+    return out
+
+
+def ncdhw_to_f32b(x):
+    lib = _lib.load()
+    _require_cuda(x, "x")
+    x = x.to(torch.float32).contiguous()
+    B, Cc = x.shape[0], x.shape[1]
+    P = x[0, 0].numel()
+    out = f32b_empty(B, Cc, P, x.device)
+    check(lib.md_ncdhw_to_f32b(_ptr(x), _ptr(out), B, Cc, P, _stream()), "md_ncdhw_to_f32b")
+    return out
+
+
+def f32b_to_ncdhw(x, spatial):
+    lib = _lib.load()
+    B, CG, P, _ = x.shape
+    out = torch.empty((B, CG * 8) + tuple(spatial), dtype=torch.float32, device=x.device)
+    check(lib.md_f32b_to_ncdhw(_ptr(x), _ptr(out), B, CG * 8, P, _stream()), "md_f32b_to_ncdhw")
+    return out
+
+
+def s16b_to_ncdhw(x, spatial):
+    lib = _lib.load()
+    B, CG, _, P, _ = x.shape
+    out = torch.empty((B, CG * 8) + tuple(spatial), dtype=torch.float32, device=x.device)
+    check(lib.md_s16b_to_ncdhw(_ptr(x), _ptr(out), B, CG * 8, P, _stream()), "md_s16b_to_ncdhw")
+    return out
+
+
+def softmax_keys(s, B, nk, nq):
+    lib = _lib.load()
+    p = torch.empty((B, nk // 8, 2, nq, 8), dtype=torch.bfloat16, device=s.device)
+    check(lib.md_softmax_keys(_ptr(s), _ptr(p), B, nk, nq, _stream()), "md_softmax_keys")
+    return p
+
+
+def ancestral_step(x, eps, z, mask, coef):
+    """x, eps, z: [B,C,D,H,W] fp32; mask [P] or None; coef [B,4] = beta, sigma, sqrt(1-beta), sqrt(beta)."""
+    lib = _lib.load()
+    for name, t in (("x", x), ("eps", eps), ("z", z)):
+        _require_cuda(t, name)
+    x, eps, z = x.contiguous(), eps.contiguous(), z.contiguous()
+    B, Cc = x.shape[0], x.shape[1]
+    P = x[0, 0].numel()
+    x_out, xm_out = torch.empty_like(x), torch.empty_like(x)
+    check(lib.md_ancestral_step(_ptr(x), _ptr(eps), _ptr(z), _ptr(mask), _ptr(coef), _ptr(x_out),
+                                _ptr(xm_out), B, Cc, P, _stream()), "md_ancestral_step")
+    return x_out, xm_out
+
+
+def inpaint_blend_(x, src, pmask, gmask, ch, src_bstride=0):
+    """In place on channel `ch` of x: (x*(1-pmask) + src*pmask) * gmask."""
+    lib = _lib.load()
+    B, Cc = x.shape[0], x.shape[1]
+    P = x[0, 0].numel()
+    check(lib.md_inpaint_blend(_ptr(x), _ptr(src), _ptr(pmask), _ptr(gmask), B, Cc, ch, P, src_bstride,
+                               _stream()), "md_inpaint_blend")
+    return x
+
+
+def inpaint_renoise_(x, x_mean, z, pmask, gmask, coef, ch):
+    """In place: re-noise channel `ch` inside pmask (see md_inpaint_renoise)."""
+    lib = _lib.load()
+    B, Cc = x.shape[0], x.shape[1]
+    P = x[0, 0].numel()
+    check(lib.md_inpaint_renoise(_ptr(x), _ptr(x_mean), _ptr(z), _ptr(pmask), _ptr(gmask), _ptr(coef), B, Cc,
+                                 ch, P, _stream()), "md_inpaint_renoise")
+    return x
+
+
+def conv_cfg_for(spatial, stride=1):
+    """Pick the 3x3x3 tile configuration for an OUTPUT grid of edge `spatial`."""
+    if stride == 2:
+        return CFG_C3_S2
+    return CFG_C3_128 if spatial % 8 == 0 else CFG_C3_LOW
+
+
+def gemm_cfg_for(ncols, nrows):
+    if ncols % 256 == 0:
+        return CFG_G1_128
+    return CFG_G1_128_LOW if nrows % 128 == 0 else CFG_G1_64_LOW
+
+
+def attn_scale(channels):
+    return float(int(channels) ** (-0.5))
+
+
+__all__ = [n for n in dir() if not n.startswith("_")]
+_ = math

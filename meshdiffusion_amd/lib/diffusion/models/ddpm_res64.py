@@ -1,0 +1,174 @@
+"""DDPM 3-D U-Net score network for 64^3 x 4 DMTet grids on MI355X.
+
+Drop-in for the reference's lib/diffusion/models/ddpm_res64.py (`DDPMRes64`, __init__ :41-124,
+forward :126-199): same registry name, constructor argument (config), state-dict keys/shapes
+(`all_modules.{i}.*`, `pos_layer`, `mask_layer`, `coords`, `mask`, `sigmas`) and call signature
+`model(x[B,4,R,R,R], labels[B]) -> eps_hat[B,4,R,R,R]`.
+
+The forward never leaves the HIP library: activations stay in the 8-channel blocked layouts
+(F32B residual stream, S16B split-bf16 conv operands) between kernels; `torch.cat` of skip
+connections is expressed as multi-part GroupNorm/split calls, the nearest-neighbour upsample is
+folded into the conv's halo load, and `pos_layer(coords) + mask_layer(mask)` (input independent)
+is computed once per weight version and added in the stem conv's epilogue.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import layers, utils
+from .... import hip_ops as ops
+
+ResnetBlockDDPM = layers.ResnetBlockDDPM
+Upsample = layers.Upsample
+Downsample = layers.Downsample
+AttnBlock = layers.AttnBlock
+conv3x3 = layers.ddpm_conv3x3
+default_initializer = layers.default_init
+
+
+def _dense(in_dim, out_dim):
+    lin = nn.Linear(in_dim, out_dim)
+    lin.weight.data = default_initializer()(lin.weight.data.shape)
+    nn.init.zeros_(lin.bias)
+    return lin
+
+
+@utils.register_model(name="ddpm_res64")
+class DDPMRes64(layers.HipLayer):
+    def __init__(self, config):
+        super().__init__()
+        m = config.model
+        self.act = layers.get_act(config)
+        self.register_buffer("sigmas", torch.tensor(utils.get_sigmas(config)))
+        self.nf = nf = m.nf
+        ch_mult = m.ch_mult
+        self.num_res_blocks = nrb = m.num_res_blocks
+        self.attn_resolutions = attn_res = m.attn_resolutions
+        self.num_resolutions = nres = len(ch_mult)
+        self.all_resolutions = all_res = [config.data.image_size // (2 ** i) for i in range(nres)]
+        self.conditional = m.conditional
+        self.centered = config.data.centered
+        self.scale_by_sigma = m.scale_by_sigma
+        self.img_size = R = config.data.image_size
+        self.num_freq = int(np.log2(R))
+        channels = config.data.num_channels
+        if not self.conditional:
+            raise NotImplementedError("unconditional (no timestep) variant is not used by this path")
+        block = lambda **kw: ResnetBlockDDPM(act=self.act, temb_dim=4 * nf, dropout=m.dropout, **kw)  # noqa: E731
+
+        mods = [_dense(nf, 4 * nf), _dense(4 * nf, 4 * nf)]
+        # constant inputs kept as (frozen) parameters because they are part of the checkpoint
+        self.coords = nn.Parameter(torch.zeros(1, 3, R, R, R), requires_grad=False)
+        self.mask = nn.Parameter(torch.zeros(1, 1, R, R, R), requires_grad=False)
+        self.pos_layer = conv3x3(3, nf)
+        self.mask_layer = conv3x3(1, nf)
+        mods.append(conv3x3(channels, nf))
+        skip_ch, in_ch = [nf], nf
+        for lvl in range(nres):
+            out_ch = nf * ch_mult[lvl]
+            for _ in range(nrb):
+                mods.append(block(in_ch=in_ch, out_ch=out_ch))
+                in_ch = out_ch
+                if all_res[lvl] in attn_res:
+                    mods.append(AttnBlock(channels=in_ch))
+                skip_ch.append(in_ch)
+            if lvl != nres - 1:
+                mods.append(Downsample(channels=in_ch, with_conv=m.resamp_with_conv))
+                skip_ch.append(in_ch)
+        mods += [block(in_ch=in_ch), AttnBlock(channels=in_ch), block(in_ch=in_ch)]
+        for lvl in reversed(range(nres)):
+            out_ch = nf * ch_mult[lvl]
+            for _ in range(nrb + 1):
+                mods.append(block(in_ch=in_ch + skip_ch.pop(), out_ch=out_ch))
+                in_ch = out_ch
+            if all_res[lvl] in attn_res:
+                mods.append(AttnBlock(channels=in_ch))
+            if lvl != 0:
+                mods.append(Upsample(channels=in_ch, with_conv=m.resamp_with_conv))
+        assert not skip_ch
+        mods.append(nn.GroupNorm(num_channels=in_ch, num_groups=32, eps=1e-6))
+        mods.append(conv3x3(in_ch, channels, init_scale=0.0))
+        self.all_modules = nn.ModuleList(mods)
+        self.out_channels = channels
+
+    # ---- cached, input-independent pieces --------------------------------------------------
+    def _stem_const(self):
+        """pos_layer(coords) + mask_layer(mask) (+ both biases) as one F32B [1][nf][P] tensor."""
+        ps = [self.coords, self.mask, self.pos_layer.weight, self.pos_layer.bias,
+              self.mask_layer.weight, self.mask_layer.bias]
+
+        def build():
+            R = self.img_size
+            dev = self.coords.device
+            cfg = ops.CFG_C3_128_K16
+            wp = ops.PackedWeight(self.pos_layer.weight, "conv", cfg, dev)
+            wm = ops.PackedWeight(self.mask_layer.weight, "conv", cfg, dev)
+            c16 = ops.ncdhw_to_s16b(self.coords.detach(), 16)
+            m16 = ops.ncdhw_to_s16b(self.mask.detach(), 16)
+            t = layers.run_conv3(wp, c16, 1, R, bias=self.pos_layer.bias)
+            return layers.run_conv3(wm, m16, 1, R, bias=self.mask_layer.bias, residual=t)
+
+        return self._cached("stem_const", ps, build)
+
+    # ---- forward ------------------------------------------------------------------------------
+    def forward(self, x, labels):
+        if not x.is_cuda:
+            raise RuntimeError("DDPMRes64 (meshdiffusion_amd) runs on the GPU only: no CPU fallback")
+        if torch.is_grad_enabled() and self.training:
+            raise NotImplementedError("autograd/backward through the HIP U-Net is not implemented yet; "
+                                      "call under torch.no_grad() in eval mode")
+        mods = self.all_modules
+        B, R = x.shape[0], self.img_size
+        P = R ** 3
+        assert tuple(x.shape[1:]) == (self.out_channels, R, R, R)
+        i = 0
+        temb = layers.get_timestep_embedding(labels, self.nf)
+        temb = ops.linear(temb, mods[i].weight, mods[i].bias); i += 1
+        temb = ops.linear(temb, mods[i].weight, mods[i].bias, silu_in=True); i += 1
+
+        h_in = x if self.centered else 2 * x - 1.0
+        stem = mods[i]; i += 1
+        x16 = ops.ncdhw_to_s16b(h_in, 16)
+        pw = layers.conv3_packed(self, "stem", stem, ops.CFG_C3_128_K16)
+        h = layers.run_conv3(pw, x16, B, R, bias=stem.bias, residual=self._stem_const(), res_bstride=0)
+
+        hs = [(h, self.nf, P)]
+        for lvl in range(self.num_resolutions):
+            for _ in range(self.num_res_blocks):
+                t, c, p = hs[-1]
+                h = mods[i].forward_blocked([(t, c)], B, p, temb); c = mods[i].out_ch; i += 1
+                if self.all_resolutions[lvl] in self.attn_resolutions:
+                    h = mods[i].forward_blocked(h, B, p); i += 1
+                hs.append((h, c, p))
+            if lvl != self.num_resolutions - 1:
+                t, c, p = hs[-1]
+                hs.append((mods[i].forward_blocked(t, c, B, p), c, p // 8)); i += 1
+
+        h, c, p = hs[-1]
+        h = mods[i].forward_blocked([(h, c)], B, p, temb); i += 1
+        h = mods[i].forward_blocked(h, B, p); i += 1
+        h = mods[i].forward_blocked([(h, c)], B, p, temb); i += 1
+
+        for lvl in reversed(range(self.num_resolutions)):
+            for _ in range(self.num_res_blocks + 1):
+                st, sc, sp = hs.pop()
+                assert sp == p
+                h = mods[i].forward_blocked([(h, c), (st, sc)], B, p, temb); c = mods[i].out_ch; i += 1
+            if self.all_resolutions[lvl] in self.attn_resolutions:
+                h = mods[i].forward_blocked(h, B, p); i += 1
+            if lvl != 0:
+                h = mods[i].forward_blocked(h, c, B, p); p *= 8; i += 1
+        assert not hs
+
+        gn = mods[i]; i += 1
+        prm = ops.gn_params([(h, c)], gn.weight, gn.bias, B, p, eps=gn.eps, groups=gn.num_groups)
+        a = ops.gn_apply([(h, c)], prm, B, p, norm=True, silu=True)
+        head = mods[i]; i += 1
+        assert i == len(mods)
+        out = torch.empty((B, self.out_channels, R, R, R), dtype=torch.float32, device=x.device)
+        pw = layers.conv3_packed(self, "head", head, ops.CFG_C3_32)
+        layers.run_conv3(pw, a, B, R, bias=head.bias, out=out, out_mode=ops.OUT_NCDHW, rows_alloc=8)
+
+        if self.scale_by_sigma:
+            out = out / self.sigmas[labels.long(), None, None, None, None].to(out.dtype)
+        return out

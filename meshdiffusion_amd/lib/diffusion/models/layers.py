@@ -1,0 +1,325 @@
+"""DDPM U-Net layers for the MI355X path.
+
+Host-side mirror of the live part of the reference's lib/diffusion/models/layers.py:
+`default_init` :88-91, `ddpm_conv3x3` :118-124, `get_timestep_embedding` :542-556, `NIN` :573-582,
+`AttnBlock` :585-608, `Upsample` :611-623, `Downsample` :626-643, `ResnetBlockDDPM` :646-689.
+Class, attribute and parameter names/shapes are identical so reference checkpoints load
+unchanged; everything numerical runs in libmeshdiffusion_hip.so through `hip_ops`.
+
+Each layer has two entry points:
+  forward(x_ncdhw, ...)        -- reference-compatible signature (converts layouts at the edge)
+  forward_blocked(parts, ...)  -- used by the fused U-Net: F32B tensors in, F32B tensor out;
+                                  `parts` is a list of (F32B tensor, channels) standing for
+                                  torch.cat(parts, dim=1) without materialising the concat.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .... import hip_ops as ops
+
+
+# --------------------------------------------------------------------------------------------
+# initialisers (same distributions as the reference; fresh implementation)
+# --------------------------------------------------------------------------------------------
+def variance_scaling(scale, mode, distribution, in_axis=1, out_axis=0, dtype=torch.float32, device="cpu"):
+    def init(shape, dtype=dtype, device=device):
+        receptive = np.prod(shape) / shape[in_axis] / shape[out_axis]
+        fan_in, fan_out = shape[in_axis] * receptive, shape[out_axis] * receptive
+        denom = {"fan_in": fan_in, "fan_out": fan_out, "fan_avg": (fan_in + fan_out) / 2}[mode]
+        var = scale / denom
+        if distribution == "normal":
+            return torch.randn(*shape, dtype=dtype, device=device) * np.sqrt(var)
+        if distribution == "uniform":
+            return (torch.rand(*shape, dtype=dtype, device=device) * 2.0 - 1.0) * np.sqrt(3 * var)
+        raise ValueError("invalid distribution for variance scaling initializer")
+
+    return init
+
+
+def default_init(scale=1.0):
+    return variance_scaling(1e-10 if scale == 0 else scale, "fan_avg", "uniform")
+
+
+def get_act(config):
+    name = config.model.nonlinearity.lower()
+    if name == "swish":
+        return nn.SiLU()
+    raise NotImplementedError("only the 'swish' nonlinearity is implemented on the HIP path "
+                              "(both registered reference models use it)")
+
+
+def _conv(in_planes, out_planes, k, stride=1, padding=1, init_scale=1.0):
+    conv = nn.Conv3d(in_planes, out_planes, kernel_size=k, stride=stride, padding=padding, bias=True)
+    conv.weight.data = default_init(init_scale)(conv.weight.data.shape)
+    nn.init.zeros_(conv.bias)
+    return conv
+
+
+def ddpm_conv3x3(in_planes, out_planes, stride=1, bias=True, dilation=1, init_scale=1.0, padding=1):
+    assert bias and dilation == 1
+    return _conv(in_planes, out_planes, 3, stride, padding, init_scale)
+
+
+def ddpm_conv5x5(in_planes, out_planes, stride=2, bias=True, dilation=1, init_scale=1.0, padding=2):
+    assert bias and dilation == 1
+    return _conv(in_planes, out_planes, 5, stride, padding, init_scale)
+
+
+def get_timestep_embedding(timesteps, embedding_dim, max_positions=10000):
+    """Sinusoidal embedding [B] -> [B, dim] computed by md_timestep_embedding."""
+    assert len(timesteps.shape) == 1 and max_positions == 10000
+    return ops.timestep_embedding(timesteps, embedding_dim)
+
+
+# --------------------------------------------------------------------------------------------
+# packed-weight cache
+# --------------------------------------------------------------------------------------------
+class HipLayer(nn.Module):
+    """Caches device-side packed weights; rebuilt when a parameter is modified in place,
+    re-assigned or moved (key = data_ptr + version counter)."""
+
+    def _cached(self, name, params, builder):
+        cache = self.__dict__.setdefault("_md_cache", {})
+        key = tuple((p.data_ptr(), p._version, str(p.device)) for p in params)
+        hit = cache.get(name)
+        if hit is None or hit[0] != key:
+            hit = (key, builder())
+            cache[name] = hit
+        return hit[1]
+
+
+def _spatial_edge(P):
+    s = round(P ** (1.0 / 3.0))
+    assert s * s * s == P, "cubic grids only"
+    return s
+
+
+def _parts_of(x):
+    """NCDHW tensor -> ([(F32B, C)], B, P, spatial)."""
+    B, Cc = x.shape[0], x.shape[1]
+    spatial = tuple(x.shape[2:])
+    return [(ops.ncdhw_to_f32b(x), Cc)], B, int(np.prod(spatial)), spatial
+
+
+def conv3_packed(layer, name, conv, cfg):
+    return layer._cached(name, [conv.weight], lambda: ops.PackedWeight(conv.weight, "conv", cfg, conv.weight.device))
+
+
+def run_conv3(pw, act_s16, B, S_out, *, bias=None, bias_bstride=0, residual=None, res_bstride=None, ups=0,
+              out=None, out_mode=ops.OUT_F32B, rows_alloc=None):
+    """3x3x3 conv of an S16B activation tensor with packed weights `pw` on an S_out^3 output grid."""
+    P = S_out ** 3
+    rows_alloc = rows_alloc if rows_alloc is not None else ((pw.rows + 7) // 8) * 8
+    if out is None:
+        out = ops.f32b_empty(B, rows_alloc, P, act_s16.device)
+    if residual is not None and res_bstride is None:
+        res_bstride = rows_alloc * P
+    return ops.gemm_conv(cfg=pw.cfg, a=pw.data, b=act_s16, out=out, batch=B, rows=pw.rows,
+                         rows_alloc=rows_alloc, kdim=pw.kdim, dims=(S_out, S_out, S_out), bias=bias,
+                         bias_bstride=bias_bstride, residual=residual, res_bstride=res_bstride or 0, ups=ups,
+                         out_mode=out_mode)
+
+
+def run_gemm(pw, act_s16, B, P, *, bias=None, bias_bstride=0, residual=None, out=None, out_mode=ops.OUT_F32B,
+             alpha=1.0, b_bstride=None):
+    """1x1x1 conv / GEMM with packed weights: out[rows][P]."""
+    rows_alloc = ((pw.rows + 7) // 8) * 8
+    if out is None:
+        out = (ops.f32b_empty if out_mode == ops.OUT_F32B else ops.s16b_empty)(B, rows_alloc, P, act_s16.device)
+    return ops.gemm_conv(cfg=pw.cfg, a=pw.data, b=act_s16, out=out, batch=B, rows=pw.rows,
+                         rows_alloc=rows_alloc, kdim=pw.kdim, dims=(1, 1, P), bias=bias,
+                         bias_bstride=bias_bstride, residual=residual,
+                         res_bstride=rows_alloc * P if residual is not None else 0, alpha=alpha,
+                         out_mode=out_mode, b_bstride=b_bstride)
+
+
+# --------------------------------------------------------------------------------------------
+# layers
+# --------------------------------------------------------------------------------------------
+class NIN(HipLayer):
+    """1x1x1 channel mixing: y[..., o] = sum_i x[..., i] W[i, o] + b[o]  (W is [in, out])."""
+
+    def __init__(self, in_dim, num_units, init_scale=0.1):
+        super().__init__()
+        self.W = nn.Parameter(default_init(scale=init_scale)((in_dim, num_units)), requires_grad=True)
+        self.b = nn.Parameter(torch.zeros(num_units), requires_grad=True)
+
+    def packed(self, P):
+        rows = self.W.shape[1]
+        cfg = ops.gemm_cfg_for(P, rows)
+        return self._cached(f"w{cfg}", [self.W], lambda: ops.PackedWeight(self.W, "nin", cfg, self.W.device))
+
+    def forward_s16(self, act_s16, B, P, residual=None, out_mode=ops.OUT_F32B):
+        return run_gemm(self.packed(P), act_s16, B, P, bias=self.b, residual=residual, out_mode=out_mode)
+
+    def forward(self, x):
+        parts, B, P, spatial = _parts_of(x)
+        act = ops.gn_apply(parts, None, B, P, norm=False, silu=False)
+        return ops.f32b_to_ncdhw(self.forward_s16(act, B, P), spatial)
+
+
+class AttnBlock(HipLayer):
+    """Single-head self-attention over the D*H*W tokens (head dim = C)."""
+
+    def __init__(self, channels):
+        super().__init__()
+        self.GroupNorm_0 = nn.GroupNorm(num_groups=32, num_channels=channels, eps=1e-6)
+        self.NIN_0 = NIN(channels, channels)
+        self.NIN_1 = NIN(channels, channels)
+        self.NIN_2 = NIN(channels, channels)
+        self.NIN_3 = NIN(channels, channels, init_scale=0.0)
+        self.channels = channels
+
+    def _qk_packed(self, P):
+        cfg = ops.gemm_cfg_for(P, 2 * self.channels)
+
+        def build():
+            w = torch.cat([self.NIN_0.W.detach(), self.NIN_1.W.detach()], dim=1)  # [C][2C]
+            return ops.PackedWeight(w, "nin", cfg, w.device)
+
+        return self._cached(f"qk{cfg}", [self.NIN_0.W, self.NIN_1.W], build)
+
+    def _qk_bias(self):
+        return self._cached("qkb", [self.NIN_0.b, self.NIN_1.b],
+                            lambda: torch.cat([self.NIN_0.b.detach(), self.NIN_1.b.detach()]).contiguous())
+
+    def _wv_s16(self):
+        return self._cached("wv", [self.NIN_2.W], lambda: ops.pack_s16b_from_matrix(self.NIN_2.W, self.NIN_2.W.device))
+
+    def forward_blocked(self, x, B, P):
+        Cc = self.channels
+        dev = x.device
+        gn = self.GroupNorm_0
+        params = ops.gn_params([(x, Cc)], gn.weight, gn.bias, B, P, eps=gn.eps, groups=gn.num_groups)
+        h = ops.gn_apply([(x, Cc)], params, B, P, norm=True, silu=False)          # S16B [B][C][P]
+        # q | k  = NIN_0 | NIN_1 in one GEMM: S16B [B][2C][P]
+        qk = run_gemm(self._qk_packed(P), h, B, P, bias=self._qk_bias(), out_mode=ops.OUT_S16B)
+        qk_bstride = (2 * Cc // 8) * 2 * P * 8
+        k_view = qk.view(-1)[(Cc // 8) * 2 * P * 8:]
+        # vT[token][c] = sum_i h[i][token] Wv[i][c]  -> S16B over tokens: [B][P/8][2][C][8]
+        cfg_v = ops.gemm_cfg_for(Cc, P)
+        vT = ops.s16b_empty(B, P, Cc, dev)
+        ops.gemm_conv(cfg=cfg_v, a=h, b=self._wv_s16(), out=vT, batch=B, rows=P, rows_alloc=P, kdim=Cc,
+                      dims=(1, 1, Cc), a_src=ops.A_S16B, a_rows=P, a_bstride=(Cc // 8) * 2 * P * 8,
+                      b_bstride=0, out_mode=ops.OUT_S16B)
+        # S^T[key][query] = C^-1/2 * sum_c k[c][key] q[c][query]   (fp32, keys blocked by 8)
+        cfg_s = ops.gemm_cfg_for(P, P)
+        sT = ops.f32b_empty(B, P, P, dev)
+        ops.gemm_conv(cfg=cfg_s, a=k_view, b=qk, out=sT, batch=B, rows=P, rows_alloc=P, kdim=Cc,
+                      dims=(1, 1, P), a_src=ops.A_S16B, a_rows=P, a_bstride=qk_bstride, b_bstride=qk_bstride,
+                      alpha=ops.attn_scale(Cc))
+        pr = ops.softmax_keys(sT, B, P, P)                                          # S16B [B][P keys][P q]
+        # o[c][q] = sum_key vT[key][c] p[key][q] + b_v[c]   (rows of softmax sum to 1)
+        cfg_o = ops.gemm_cfg_for(P, Cc)
+        o = ops.s16b_empty(B, Cc, P, dev)
+        ops.gemm_conv(cfg=cfg_o, a=vT, b=pr, out=o, batch=B, rows=Cc, rows_alloc=Cc, kdim=P, dims=(1, 1, P),
+                      a_src=ops.A_S16B, a_rows=Cc, a_bstride=(P // 8) * 2 * Cc * 8, bias=self.NIN_2.b,
+                      out_mode=ops.OUT_S16B)
+        return self.NIN_3.forward_s16(o, B, P, residual=x)
+
+    def forward(self, x):
+        parts, B, P, spatial = _parts_of(x)
+        return ops.f32b_to_ncdhw(self.forward_blocked(parts[0][0], B, P), spatial)
+
+
+class Upsample(HipLayer):
+    def __init__(self, channels, with_conv=False):
+        super().__init__()
+        if not with_conv:
+            raise NotImplementedError("Upsample without conv is not used by the registered models")
+        self.Conv_0 = ddpm_conv3x3(channels, channels)
+        self.with_conv = with_conv
+
+    def forward_blocked(self, x, Cc, B, P):
+        s_out = 2 * _spatial_edge(P)
+        act = ops.gn_apply([(x, Cc)], None, B, P, norm=False, silu=False)
+        pw = conv3_packed(self, "w", self.Conv_0, ops.conv_cfg_for(s_out))
+        return run_conv3(pw, act, B, s_out, bias=self.Conv_0.bias, ups=1)
+
+    def forward(self, x):
+        parts, B, P, spatial = _parts_of(x)
+        return ops.f32b_to_ncdhw(self.forward_blocked(parts[0][0], parts[0][1], B, P), tuple(2 * s for s in spatial))
+
+
+class Downsample(HipLayer):
+    def __init__(self, channels, with_conv=False):
+        super().__init__()
+        if not with_conv:
+            raise NotImplementedError("Downsample without conv is not used by the registered models")
+        self.Conv_0 = ddpm_conv3x3(channels, channels, stride=2, padding=0)
+        self.with_conv = with_conv
+
+    def forward_blocked(self, x, Cc, B, P):
+        s_out = _spatial_edge(P) // 2
+        act = ops.gn_apply([(x, Cc)], None, B, P, norm=False, silu=False)
+        pw = conv3_packed(self, "w", self.Conv_0, ops.conv_cfg_for(s_out, stride=2))
+        return run_conv3(pw, act, B, s_out, bias=self.Conv_0.bias)
+
+    def forward(self, x):
+        parts, B, P, spatial = _parts_of(x)
+        return ops.f32b_to_ncdhw(self.forward_blocked(parts[0][0], parts[0][1], B, P), tuple(s // 2 for s in spatial))
+
+
+class ResnetBlockDDPM(HipLayer):
+    """GN-SiLU-conv3 (+temb bias) - GN-SiLU-dropout-conv3 + shortcut (identity or NIN)."""
+
+    def __init__(self, act, in_ch, out_ch=None, temb_dim=None, conv_shortcut=False, dropout=0.1):
+        super().__init__()
+        out_ch = in_ch if out_ch is None else out_ch
+        if conv_shortcut:
+            raise NotImplementedError("conv_shortcut is never enabled by the registered models")
+        self.GroupNorm_0 = nn.GroupNorm(num_groups=32, num_channels=in_ch, eps=1e-6)
+        self.act = act
+        self.Conv_0 = ddpm_conv3x3(in_ch, out_ch)
+        if temb_dim is not None:
+            self.Dense_0 = nn.Linear(temb_dim, out_ch)
+            self.Dense_0.weight.data = default_init()(self.Dense_0.weight.data.shape)
+            nn.init.zeros_(self.Dense_0.bias)
+        self.GroupNorm_1 = nn.GroupNorm(num_groups=32, num_channels=out_ch, eps=1e-6)
+        self.Dropout_0 = nn.Dropout(dropout)
+        self.Conv_1 = ddpm_conv3x3(out_ch, out_ch, init_scale=0.0)
+        if in_ch != out_ch:
+            self.NIN_0 = NIN(in_ch, out_ch)
+        self.out_ch, self.in_ch, self.conv_shortcut = out_ch, in_ch, conv_shortcut
+
+    def _bias0(self):
+        """Conv_0.bias + Dense_0.bias, folded into one per-channel constant."""
+        if hasattr(self, "Dense_0"):
+            return self._cached("b0", [self.Conv_0.bias, self.Dense_0.bias],
+                                lambda: (self.Conv_0.bias.detach() + self.Dense_0.bias.detach()).contiguous())
+        return self.Conv_0.bias
+
+    def forward_blocked(self, parts, B, P, temb=None):
+        if self.training and self.Dropout_0.p > 0:
+            raise NotImplementedError("training-mode dropout/backward is not implemented on the HIP path yet")
+        S = _spatial_edge(P)
+        cin = sum(c for _, c in parts)
+        assert cin == self.in_ch
+        cfg = ops.conv_cfg_for(S)
+        g0, g1 = self.GroupNorm_0, self.GroupNorm_1
+        prm = ops.gn_params(parts, g0.weight, g0.bias, B, P, eps=g0.eps, groups=g0.num_groups)
+        a0 = ops.gn_apply(parts, prm, B, P, norm=True, silu=True)
+        if temb is not None:   # per-(sample, channel) additive bias = Conv_0.b + Dense_0(SiLU(temb))
+            bias0 = ops.linear(temb, self.Dense_0.weight, self._bias0(), silu_in=True)
+            h = run_conv3(conv3_packed(self, "w0", self.Conv_0, cfg), a0, B, S, bias=bias0, bias_bstride=self.out_ch)
+        else:
+            h = run_conv3(conv3_packed(self, "w0", self.Conv_0, cfg), a0, B, S, bias=self.Conv_0.bias)
+        prm1 = ops.gn_params([(h, self.out_ch)], g1.weight, g1.bias, B, P, eps=g1.eps, groups=g1.num_groups)
+        a1 = ops.gn_apply([(h, self.out_ch)], prm1, B, P, norm=True, silu=True)
+        if self.in_ch != self.out_ch:
+            xs = ops.gn_apply(parts, None, B, P, norm=False, silu=False)
+            res = self.NIN_0.forward_s16(xs, B, P)
+        else:
+            assert len(parts) == 1
+            res = parts[0][0]
+        return run_conv3(conv3_packed(self, "w1", self.Conv_1, cfg), a1, B, S, bias=self.Conv_1.bias, residual=res)
+
+    def forward(self, x, temb=None):
+        parts, B, P, spatial = _parts_of(x)
+        return ops.f32b_to_ncdhw(self.forward_blocked(parts, B, P, temb), spatial)
+
+
+_ = math

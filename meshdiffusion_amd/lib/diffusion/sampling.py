@@ -1,0 +1,214 @@
+"""DDPM ancestral (predictor-only) sampler with grid-mask and partial-grid inpainting.
+
+Host-side mirror of the reference's lib/diffusion/sampling.py: `get_sampling_fn` :83-117,
+`AncestralSamplingPredictor.vpsde_update_fn` :222-230, `NoneCorrector` :324-332,
+`get_pc_sampler`/`pc_sampler` :357-487 (unconditional loop :471-481, inpainting :429-467).
+
+Same call surface:
+    fn = get_sampling_fn(config, sde, shape, inverse_scaler, eps, grid_mask=None)
+    samples, nfe = fn(model, partial=None, partial_mask=None, partial_channel=0, freeze_iters=None)
+The per-step arithmetic (score scaling, x_mean, re-noising, masking) is ONE HIP kernel
+(md_ancestral_step); the noise still comes from torch's global generator (CPU generator for the
+prior, device generator per step) so that, on the same device and seed, the stream of random
+numbers is the reference's.  Two optional keyword extensions used by tests/bench:
+    n_iters  -- run only the first n iterations of the N-step schedule
+    noise_fn -- callable(x) -> z replacing torch.randn_like (to replay recorded noise)
+"""
+import torch
+
+from . import sde_lib
+from .models import utils as mutils
+from ... import hip_ops as ops
+
+_PREDICTORS = {}
+_CORRECTORS = {}
+
+
+def _registrar(table):
+    def register(cls=None, *, name=None):
+        def _do(c):
+            key = c.__name__ if name is None else name
+            if key in table:
+                raise ValueError(f"Already registered model with name: {key}")
+            table[key] = c
+            return c
+
+        return _do if cls is None else _do(cls)
+
+    return register
+
+
+register_predictor = _registrar(_PREDICTORS)
+register_corrector = _registrar(_CORRECTORS)
+
+
+def get_predictor(name):
+    return _PREDICTORS[name]
+
+
+def get_corrector(name):
+    return _CORRECTORS[name]
+
+
+class Predictor:
+    def __init__(self, sde, score_fn, probability_flow=False):
+        self.sde, self.score_fn = sde, score_fn
+
+
+class Corrector:
+    def __init__(self, sde, score_fn, snr, n_steps):
+        self.sde, self.score_fn, self.snr, self.n_steps = sde, score_fn, snr, n_steps
+
+
+@register_predictor(name="ancestral_sampling")
+class AncestralSamplingPredictor(Predictor):
+    """x_mean = (x + beta*score)/sqrt(1-beta), x = x_mean + sqrt(beta)*z, score = -eps_hat/sigma."""
+
+    def __init__(self, sde, score_fn, probability_flow=False):
+        super().__init__(sde, score_fn, probability_flow)
+        if not isinstance(sde, sde_lib.VPSDE):
+            raise NotImplementedError(f"SDE class {sde.__class__.__name__} not yet supported.")
+        assert not probability_flow, "Probability flow not supported by ancestral sampling"
+
+    def update_fn(self, x, t, model=None, noise=None, mask=None):
+        """Stand-alone update (same semantics as the reference's vpsde_update_fn)."""
+        sde = self.sde
+        k = (t * (sde.N - 1) / sde.T).long()
+        eps_hat = mutils.get_model_fn(model, train=False)(x, t * (sde.N - 1))
+        beta = sde.discrete_betas.to(t.device)[k]
+        sigma = sde.sqrt_1m_alphas_cumprod.to(t.device)[k]
+        coef = torch.stack([beta, sigma, torch.sqrt(1.0 - beta), torch.sqrt(beta)], dim=1).contiguous()
+        z = torch.randn_like(x) if noise is None else noise
+        return ops.ancestral_step(x, eps_hat, z, mask, coef)
+
+
+@register_predictor(name="none")
+class NonePredictor(Predictor):
+    def update_fn(self, x, t, **_):
+        return x, x
+
+
+@register_corrector(name="none")
+class NoneCorrector(Corrector):
+    def __init__(self, sde=None, score_fn=None, snr=None, n_steps=None):
+        pass
+
+    def update_fn(self, x, t, **_):
+        return x, x
+
+
+def get_sampling_fn(config, sde, shape, inverse_scaler, eps, grid_mask=None, return_traj=False):
+    name = config.sampling.method.lower()
+    if name != "pc":
+        raise ValueError(f"Sampler name {config.sampling.method} unknown / not implemented on the HIP path "
+                         "(the reference's 'ddim' branch is itself broken: sampling.py:569)")
+    return get_pc_sampler(sde=sde, shape=shape,
+                          predictor=get_predictor(config.sampling.predictor.lower()),
+                          corrector=get_corrector(config.sampling.corrector.lower()),
+                          inverse_scaler=inverse_scaler, snr=config.sampling.snr,
+                          n_steps=config.sampling.n_steps_each,
+                          probability_flow=config.sampling.probability_flow,
+                          continuous=config.training.continuous, denoise=config.sampling.noise_removal,
+                          eps=eps, device=config.device, grid_mask=grid_mask, return_traj=return_traj)
+
+
+class AncestralStepper:
+    """Per-iteration state of the N-step ancestral loop: label / coefficient tables built once with the
+    reference's float32 ops (sampling.py:406, :224-226; models/utils.py:193-195), then one U-Net call and
+    one md_ancestral_step launch per iteration.  Used by pc_sampler and by bench.py."""
+
+    def __init__(self, sde, shape, eps=1e-3, device="cuda", grid_mask=None):
+        if not isinstance(sde, sde_lib.VPSDE):
+            raise NotImplementedError(f"SDE class {sde.__class__.__name__} not yet supported.")
+        dev = torch.device(device)
+        self.sde, self.shape, self.dev = sde, tuple(shape), dev
+        self.B = shape[0]
+        self.P = int(shape[2] * shape[3] * shape[4])
+        self.timesteps = torch.linspace(sde.T, eps, sde.N, device=dev)
+        labels_all = self.timesteps * (sde.N - 1)                      # fractional float labels
+        k_all = (self.timesteps * (sde.N - 1) / sde.T).long()
+        betas = sde.discrete_betas.to(dev)[k_all]
+        sigmas = sde.sqrt_1m_alphas_cumprod.to(dev)[k_all]
+        coef_all = torch.stack([betas, sigmas, torch.sqrt(1.0 - betas), torch.sqrt(betas)], dim=1)
+        # per-iteration rows pre-expanded over the batch: no host-side tensor math inside the loop
+        self.labels = labels_all[:, None].expand(sde.N, self.B).contiguous()
+        self.coef = coef_all[:, None, :].expand(sde.N, self.B, 4).contiguous()
+        self.gm, self.gm_flat = None, None
+        if grid_mask is not None:
+            self.gm = grid_mask.to(dev)
+            self.gm_flat = self.gm.reshape(-1).to(torch.float32).contiguous()
+            assert self.gm_flat.numel() == self.P, "grid_mask must broadcast over batch and channels"
+            # a 0/1 mask makes the reference's pre-predictor `x * grid_mask` (sampling.py:476) an exact
+            # no-op on the already masked state, so one masked store per step suffices
+            assert bool(((self.gm_flat == 0) | (self.gm_flat == 1)).all()), "grid_mask must be binary"
+
+    def prior(self):
+        """Initial sample: CPU generator like the reference (sde_lib.py:216-217), then masked."""
+        x = self.sde.prior_sampling(self.shape).to(self.dev)
+        if self.gm is not None:
+            x = x * self.gm
+        return x.contiguous()
+
+    def step(self, model_fn, x, i, draw=torch.randn_like):
+        eps_hat = model_fn(x, self.labels[i])
+        z = draw(x)
+        return ops.ancestral_step(x, eps_hat, z, self.gm_flat, self.coef[i])
+
+
+def get_pc_sampler(sde, shape, predictor, corrector, inverse_scaler, snr, n_steps=1, probability_flow=False,
+                   continuous=False, denoise=True, eps=1e-3, device="cuda", grid_mask=None, return_traj=False):
+    if predictor is not AncestralSamplingPredictor or corrector is not NoneCorrector:
+        raise NotImplementedError("the HIP path implements the configured sampler only: predictor "
+                                  "'ancestral_sampling' + corrector 'none' (configs/res64.py:24-26)")
+    if continuous or probability_flow:
+        raise NotImplementedError("continuous / probability-flow sampling is not part of this path")
+    if return_traj:
+        raise NotImplementedError("return_traj is only used by the reference's unreachable uncond_gen_interp")
+    B = shape[0]
+    P = int(shape[2] * shape[3] * shape[4])
+
+    def pc_sampler(model, partial=None, partial_mask=None, partial_channel=0, freeze_iters=None,
+                   n_iters=None, noise_fn=None):
+        with torch.no_grad():
+            if freeze_iters is None:
+                freeze_iters = sde.N + 10
+            st = AncestralStepper(sde, shape, eps=eps, device=device, grid_mask=grid_mask)
+            dev, timesteps, gm_flat = st.dev, st.timesteps, st.gm_flat
+            model_fn = mutils.get_model_fn(model, train=False)
+            draw = torch.randn_like if noise_fn is None else noise_fn
+            x = st.prior()
+
+            cond = partial is not None
+            if cond:
+                assert st.gm is not None and partial.dim() == 5 and partial_mask is not None
+                ch = partial_channel
+                pm_flat = partial_mask[0, ch].reshape(-1).to(dev, torch.float32).contiguous()
+                src = (partial[:, ch].to(dev, torch.float32)).contiguous()
+                src_bstride = 0 if src.shape[0] == 1 else P
+                # ---- initial conditioning (sampling.py:429-440), including its broadcasting quirk:
+                # `sampled_update` is [B,B,R,R,R] there and `[:, partial_channel]` indexes its SECOND batch
+                # axis, so every sample receives batch element `ch`'s mean and noise, scaled by its own std.
+                vec_t = torch.ones(B, device=dev) * timesteps[0]
+                x[:, ch] = src * gm_flat.view(1, *shape[2:])
+                mean, std = sde.marginal_prob(x, vec_t)
+                z0 = draw(mean[:, ch])
+                upd = (mean[ch, ch][None] + std[:, None, None, None] * z0[ch][None]).contiguous()
+                ops.inpaint_blend_(x, upd, pm_flat, gm_flat, ch, src_bstride=P)
+
+            total = sde.N if cond else sde.N - 1
+            if n_iters is not None:
+                total = min(total, int(n_iters))
+            x_mean = x
+            for i in range(total):
+                x, x_mean = st.step(model_fn, x, i, draw)
+                if cond and i != sde.N - 1 and i < freeze_iters:
+                    ops.inpaint_blend_(x, src, pm_flat, gm_flat, ch, src_bstride=src_bstride)
+                    ops.inpaint_blend_(x_mean, src, pm_flat, gm_flat, ch, src_bstride=src_bstride)
+                    t_i = timesteps[i]
+                    lmc = -0.25 * t_i ** 2 * (sde.beta_1 - sde.beta_0) - 0.5 * t_i * sde.beta_0
+                    rc = torch.stack([torch.exp(lmc), torch.sqrt(1.0 - torch.exp(2.0 * lmc))]).expand(B, 2).contiguous()
+                    z2 = draw(x[:, ch]).contiguous()
+                    ops.inpaint_renoise_(x, x_mean, z2, pm_flat, gm_flat, rc, ch)
+            return inverse_scaler(x_mean if denoise else x), sde.N * (n_steps + 1)
+
+    return pc_sampler

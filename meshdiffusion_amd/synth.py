@@ -1,0 +1,85 @@
+"""Deterministic synthetic weights / inputs for benchmarks and parity tests.
+
+The reference's default initialisation makes the network output ~0 (every Conv_1, NIN_3 and the
+head are scaled by 1e-10: layers.py:90,593,662, ddpm_res64.py:121), so parity on default-init
+weights is blind.  `sensitised_state_dict` therefore draws EVERY tensor from a
+generator seeded by (seed, crc32(key)): independent of module construction order and identical on
+every host with the same torch build, so the 1.46 GB of res64 weights never have to be shipped.
+"""
+import zlib
+
+import numpy as np
+import torch
+
+from .config import get_config_res64
+
+
+def small_config(image_size=16, nf=32, ch_mult=(1, 2, 2), num_res_blocks=1, attn_resolutions=(8,)):
+    """A U-Net small enough for the CPU oracle to run in seconds but covering every kernel config."""
+    c = get_config_res64()
+    c.data.image_size = image_size
+    c.model.update(nf=nf, ch_mult=ch_mult, num_res_blocks=num_res_blocks, attn_resolutions=attn_resolutions,
+                   dropout=0.0)
+    return c
+
+
+def oracle_cfg(config):
+    m = config.model
+    return dict(nf=m.nf, ch_mult=tuple(m.ch_mult), num_res_blocks=m.num_res_blocks,
+                attn_resolutions=tuple(m.attn_resolutions), image_size=config.data.image_size)
+
+
+def _gen(seed, key):
+    g = torch.Generator(device="cpu")
+    g.manual_seed((int(seed) * 1000003 + zlib.crc32(key.encode())) % (2 ** 63 - 1))
+    return g
+
+
+def sensitised_state_dict(template, seed=1234, grid_mask=None):
+    """template: a state dict (shapes/keys).  Returns a new CPU fp32/fp64 state dict."""
+    out = {}
+    for key, ref in template.items():
+        shape, g = tuple(ref.shape), _gen(seed, key)
+        leaf = key.split(".")[-1]
+        if key.endswith("sigmas"):
+            out[key] = ref.detach().clone().cpu()
+        elif key.endswith("coords"):
+            out[key] = torch.rand(shape, generator=g) * 2.0 - 1.0
+        elif key.endswith("mask") and len(shape) == 5:
+            if grid_mask is not None:
+                out[key] = grid_mask.reshape(shape).float().cpu().clone()
+            else:
+                out[key] = (torch.rand(shape, generator=g) < 0.116).float()
+        elif "GroupNorm" in key or (len(shape) == 1 and leaf == "weight"):
+            # GroupNorm affine (the final norm is a bare `all_modules.{i}.weight/.bias` of ndim 1)
+            if leaf == "weight":
+                out[key] = 1.0 + 0.05 * torch.randn(shape, generator=g)
+            else:
+                out[key] = 0.02 * torch.randn(shape, generator=g)
+        elif len(shape) == 1:
+            out[key] = 0.02 * torch.randn(shape, generator=g)
+        else:
+            recept = float(np.prod(shape)) / shape[0] / shape[1]
+            fan_avg = (shape[0] + shape[1]) * recept / 2.0
+            a = float(np.sqrt(3.0 / fan_avg))
+            out[key] = (torch.rand(shape, generator=g) * 2.0 - 1.0) * a
+    return out
+
+
+def synthetic_grid_mask(R, seed=7):
+    """Binary [R,R,R] mask with ~11.6% live cells on a period-4 lattice (the
+    res128 asset is missing upstream, and tests must not depend on the reference tree)."""
+    pat = {(0, 1, 1), (2, 1, 1), (3, 0, 3), (3, 2, 3), (1, 3, 0), (1, 3, 2), (1, 1, 3), (3, 3, 1)}
+    idx = torch.arange(R)
+    X, Y, Z = torch.meshgrid(idx, idx, idx, indexing="ij")
+    m = torch.zeros(R, R, R)
+    for (a, b, c) in pat:
+        m[((X % 4) == a) & ((Y % 4) == b) & ((Z % 4) == c)] = 1.0
+    m[R - 1, :, :] = 0; m[:, R - 1, :] = 0; m[:, :, R - 1] = 0
+    return m
+
+
+def synthetic_inputs(B, C, R, seed=42):
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed)
+    return torch.randn((B, C, R, R, R), generator=g)

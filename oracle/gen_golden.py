@@ -1,0 +1,268 @@
+"""Generate the golden fixtures in tests/golden/ by running the IMPORTED reference
+(/root/reference, read-only) on CPU, and pin the oracle restatements against it.
+
+Run in the build container only (the GPU box has no /root/reference):
+    python oracle/gen_golden.py [--skip-res64]
+
+What is recorded (all inputs are regenerated from seeds by meshdiffusion_amd.synth, so only
+outputs are stored):
+  unet_small.npz     reference DDPMRes64 (small config) eps_hat, full tensor
+  unet_res64.npz     reference DDPMRes64 (res64, B=1) eps_hat: ::4 subsample + statistics
+  sampler_small.npz  unmodified reference pc_sampler, first K iterations, uncond + inpainting
+  sampler_res64.npz  BASELINE config #1: res64, B=1, first 10 of 1000 ancestral steps
+  dmtet.npz          reference DMTet.__call__ on the shipped 64-grid: counts, hashes, samples
+  64_tets_cropped.npz  the tet-grid DATA asset (vertices/indices), copied verbatim
+Every reference result is also compared with the oracle restatement (assert), which is the pin
+that lets the GPU box use the oracle as the checker.
+"""
+import argparse
+import hashlib
+import os
+import shutil
+import sys
+import time
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+GOLD = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, ROOT)
+
+from meshdiffusion_amd import synth  # noqa: E402
+from meshdiffusion_amd.config import ConfigDict  # noqa: E402
+from oracle import dmtet_oracle, unet_oracle  # noqa: E402
+
+
+def rel_l2(a, b):
+    a, b = torch.as_tensor(a).double(), torch.as_tensor(b).double()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def import_reference():
+    """Import lib.diffusion from the reference on a GPU-less host."""
+    if not torch.cuda.is_available():
+        torch.Tensor.cuda = lambda self, *a, **k: self  # sde_lib.py / sampling.py hard-code .cuda()
+    sys.path.insert(0, REF)
+    from lib.diffusion import sampling as rsampling, sde_lib as rsde  # noqa: E402
+    from lib.diffusion.models import ddpm_res64 as rmodel, utils as rmutils  # noqa: F401,E402
+    return rsampling, rsde, rmutils
+
+
+def ref_model(rmutils, config, sd):
+    m = rmutils.create_model(config, use_parallel=False)
+    missing = m.load_state_dict(sd, strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    return m.eval()
+
+
+def make_sd(config, R, seed=1234):
+    # template shapes from OUR module tree (identical keys/shapes are asserted by strict load above)
+    from meshdiffusion_amd.lib.diffusion.models import ddpm_res64, utils as mutils  # noqa: F401
+    c = ConfigDict(config)
+    tmpl = mutils.create_model(c, use_parallel=False).state_dict()
+    return synth.sensitised_state_dict(tmpl, seed=seed, grid_mask=synth.synthetic_grid_mask(R))
+
+
+def run_ref_sampler(rsampling, rsde, config, model, shape, mask, K, seed, cond=None):
+    sde = rsde.VPSDE(beta_min=config.model.beta_min, beta_max=config.model.beta_max, N=config.model.num_scales)
+    fn = rsampling.get_sampling_fn(config, sde, shape, lambda x: x, 1e-3, grid_mask=mask)
+    old = rsampling.tqdm.trange
+    rsampling.tqdm.trange = lambda n, *a, **k: range(min(n, K))  # first K iterations of the real loop
+    try:
+        torch.manual_seed(seed)
+        if cond is None:
+            out, _ = fn(model)
+        else:
+            out, _ = fn(model, partial=cond[0], partial_mask=cond[1], freeze_iters=cond[2])
+    finally:
+        rsampling.tqdm.trange = old
+    return out
+
+
+def oracle_sampler(sd, ocfg, shape, mask, K, seed, N=1000):
+    torch.manual_seed(seed)
+    x0 = torch.randn(*shape) * mask
+    noises = []
+
+    def eps_fn(x, labels):
+        return unet_oracle.unet_res64_forward(sd, ocfg, x, labels)
+
+    timesteps = torch.linspace(1.0, 1e-3, N)
+    x, x_mean = x0, x0
+    for i in range(K):
+        labels = torch.ones(shape[0]) * timesteps[i] * (N - 1)
+        e = eps_fn(x, labels)
+        z = torch.randn_like(x)
+        x, x_mean = unet_oracle.ancestral_step(x, e, z, timesteps[i], mask, N)
+    return x_mean
+
+
+def gen_unet_and_sampler(skip_res64):
+    rsampling, rsde, rmutils = import_reference()
+    with torch.no_grad():
+        # ---------------- small config ----------------
+        cfg = synth.small_config(); cfg.device = torch.device("cpu")
+        R = cfg.data.image_size
+        sd = make_sd(cfg, R)
+        model = ref_model(rmutils, cfg, sd)
+        x = synth.synthetic_inputs(2, 4, R, seed=42)
+        labels = torch.tensor([500.3, 12.7])
+        y_ref = model(x, labels)
+        y_or = unet_oracle.unet_res64_forward(sd, synth.oracle_cfg(cfg), x, labels)
+        e = rel_l2(y_or, y_ref)
+        print(f"[small] oracle vs reference U-Net rel-L2 = {e:.3e}; out std {float(y_ref.std()):.3f}")
+        assert e < 1e-5
+        np.savez_compressed(os.path.join(GOLD, "unet_small.npz"), y=y_ref.numpy(), labels=labels.numpy(),
+                            x_seed=42, sd_seed=1234)
+
+        mask = synth.synthetic_grid_mask(R).view(1, R, R, R)
+        K = 6
+        xm_ref = run_ref_sampler(rsampling, rsde, cfg, model, (2, 4, R, R, R), mask, K, seed=77)
+        xm_or = oracle_sampler(sd, synth.oracle_cfg(cfg), (2, 4, R, R, R), mask, K, seed=77)
+        e = rel_l2(xm_or, xm_ref)
+        print(f"[small] oracle vs reference {K}-step sampler rel-L2 = {e:.3e}")
+        assert e < 1e-5
+        # inpainting branch of the unmodified reference sampler
+        g = torch.Generator().manual_seed(5)
+        partial = torch.sign(torch.randn((1, 1, R, R, R), generator=g))
+        pmask = (torch.rand((1, 1, R, R, R), generator=g) < 0.5).float() * mask.view(1, 1, R, R, R)
+        mask5 = mask.view(1, 1, R, R, R)
+        xc_ref = run_ref_sampler(rsampling, rsde, cfg, model, (2, 4, R, R, R), mask5, K, seed=78,
+                                 cond=(partial, pmask, 4))
+        np.savez_compressed(os.path.join(GOLD, "sampler_small.npz"), uncond=xm_ref.numpy(), cond=xc_ref.numpy(),
+                            K=K, uncond_seed=77, cond_seed=78, cond_data_seed=5, freeze_iters=4)
+
+        if skip_res64:
+            return
+        # ---------------- res64 ----------------
+        from meshdiffusion_amd.config import get_config_res64
+        cfg = get_config_res64(); cfg.device = torch.device("cpu")
+        R = 64
+        t0 = time.time()
+        sd = make_sd(cfg, R)
+        model = ref_model(rmutils, cfg, sd)
+        print(f"[res64] weights ready in {time.time() - t0:.1f}s")
+        x = synth.synthetic_inputs(1, 4, R, seed=42)
+        labels = torch.tensor([500.3])
+        t0 = time.time(); y_ref = model(x, labels); t_ref = time.time() - t0
+        t0 = time.time(); y_or = unet_oracle.unet_res64_forward(sd, synth.oracle_cfg(cfg), x, labels); t_or = time.time() - t0
+        e = rel_l2(y_or, y_ref)
+        print(f"[res64] oracle vs reference rel-L2 = {e:.3e}; ref {t_ref:.1f}s oracle {t_or:.1f}s; std {float(y_ref.std()):.3f}")
+        assert e < 1e-5
+        np.savez_compressed(os.path.join(GOLD, "unet_res64.npz"), y_sub=y_ref[:, :, ::4, ::4, ::4].numpy(),
+                            y_norm=float(y_ref.double().norm()), y_sum=y_ref.double().sum(dim=(0, 2, 3, 4)).numpy(),
+                            y_row=y_ref[0, :, 31, 17, :].numpy(), labels=labels.numpy(), x_seed=42, sd_seed=1234)
+        mask = synth.synthetic_grid_mask(R).view(1, R, R, R)
+        t0 = time.time()
+        xm = run_ref_sampler(rsampling, rsde, cfg, model, (1, 4, R, R, R), mask, 10, seed=42)
+        print(f"[res64] reference 10-step sampler {time.time() - t0:.1f}s")
+        np.savez_compressed(os.path.join(GOLD, "sampler_res64.npz"), xm_sub=xm[:, :, ::4, ::4, ::4].numpy(),
+                            xm_norm=float(xm.double().norm()), xm_row=xm[0, :, 33, 17, :].numpy(), K=10, seed=42)
+
+
+# -------------------------------------------------------------------------------------------------
+def import_ref_dmtet():
+    for name in ("kaolin", "pytorch3d", "pytorch3d.ops", "nvdiffrast", "nvdiffrast.torch", "imageio",
+                 "tinycudann", "xatlas"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.path.insert(0, os.path.join(REF, "nvdiffrec"))
+    # render/ pulls in the CUDA plugin; DMTet.__call__ needs none of it: stub the whole sub-package
+    render = types.ModuleType("lib.render")
+    for sub in ("mesh", "render", "regularizer", "util", "renderutils"):
+        m = types.ModuleType(f"lib.render.{sub}")
+        setattr(render, sub, m)
+        sys.modules[f"lib.render.{sub}"] = m
+    sys.modules["lib.render"] = render
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_dmtet", os.path.join(REF, "nvdiffrec/lib/geometry/dmtet.py"),
+                                                  submodule_search_locations=None)
+    mod = importlib.util.module_from_spec(spec)
+    mod.__package__ = "lib.geometry"
+    sys.modules.setdefault("lib", types.ModuleType("lib"))
+    sys.modules.setdefault("lib.geometry", types.ModuleType("lib.geometry"))
+    spec.loader.exec_module(mod)
+    return mod
+
+
+class _CudaToCpu(torch.overrides.TorchFunctionMode):
+    def __torch_function__(self, func, types_, args=(), kwargs=None):
+        kwargs = dict(kwargs or {})
+        if kwargs.get("device", None) in ("cuda", torch.device("cuda")):
+            kwargs["device"] = "cpu"
+        return func(*args, **kwargs)
+
+
+def dmtet_cases(verts, seed=0):
+    """Deterministic (pos, sdf) inputs on the 64 tet grid; shared with tests/."""
+    g = torch.Generator().manual_seed(seed)
+    v = torch.as_tensor(verts, dtype=torch.float32) * 2.1
+    deform = (torch.rand(v.shape, generator=g) * 2 - 1) * (2 / 128) * 2.0
+    pos = v + deform
+    r = v.norm(dim=1)
+    cases = {
+        "sphere": torch.sign(0.6 - r),
+        "noise": torch.sign(torch.randn(v.shape[0], generator=g)),
+        "sinus": torch.sign(torch.sin(7 * v[:, 0]) * torch.cos(5 * v[:, 1]) + 0.3 * torch.sin(9 * v[:, 2])),
+        "box_zeros": torch.where((v.abs().max(dim=1).values < 0.5), torch.ones(v.shape[0]),
+                                 torch.where(v.abs().max(dim=1).values < 0.6, torch.zeros(v.shape[0]),
+                                             -torch.ones(v.shape[0]))),
+        "smooth": 0.55 - r + 0.1 * torch.sin(11 * v[:, 0]),   # non-unit sdf: exercises the interpolation weights
+    }
+    return pos, cases
+
+
+def gen_dmtet():
+    src = os.path.join(REF, "nvdiffrec/data/tets/64_tets_cropped.npz")
+    shutil.copyfile(src, os.path.join(GOLD, "64_tets_cropped.npz"))
+    tet = np.load(src)
+    verts, idx = tet["vertices"], tet["indices"]
+    # the grid mask asset equals the tet-vertex occupancy (data/get_tet_mask.py)
+    from meshdiffusion_amd.dmtet import grid_mask_from_tets
+    ref_mask = torch.load(os.path.join(REF, "data/grid_mask_64.pt"), map_location="cpu").float()
+    assert torch.equal(grid_mask_from_tets(verts, 64), ref_mask.view(64, 64, 64)), "grid mask mismatch"
+    print("[dmtet] grid_mask_from_tets == data/grid_mask_64.pt ; live cells", int(ref_mask.sum()))
+    mod = import_ref_dmtet()
+    pos, cases = dmtet_cases(verts)
+    tets_t = torch.as_tensor(idx, dtype=torch.long)
+    out = {}
+    with _CudaToCpu():
+        dm = mod.DMTet()
+        for name, sdf in cases.items():
+            t0 = time.time()
+            v, f, uvs, uv_idx, ftet, vvi = dm(pos, sdf.clone(), tets_t)
+            dt = time.time() - t0
+            vo, fo, fto = dmtet_oracle.marching_tets(pos.numpy(), sdf.numpy(), idx)
+            assert np.array_equal(fo, f.numpy()), name
+            assert np.array_equal(fto, ftet.numpy()), name
+            assert np.array_equal(vo, v.numpy()), (name, np.abs(vo - v.numpy()).max())
+            print(f"[dmtet] {name}: V={v.shape[0]} F={f.shape[0]} ref {dt:.2f}s  oracle == reference (faces, verts bit-equal)")
+            out[f"{name}_counts"] = np.array([v.shape[0], f.shape[0]])
+            out[f"{name}_faces_sha"] = sha(f.numpy().astype(np.int64))
+            out[f"{name}_verts_sha"] = sha(v.numpy().astype(np.float32))
+            out[f"{name}_uv_idx_sha"] = sha(uv_idx.numpy().astype(np.int64))
+            out[f"{name}_vvi_sha"] = sha(vvi.numpy().astype(np.int64))
+            out[f"{name}_faces_head"] = f.numpy()[:64]
+            out[f"{name}_faces_tail"] = f.numpy()[-64:]
+            out[f"{name}_verts_head"] = v.numpy()[:64]
+    np.savez_compressed(os.path.join(GOLD, "dmtet.npz"), **out)
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--skip-res64", action="store_true")
+    ap.add_argument("--only", choices=["unet", "dmtet"], default=None)
+    a = ap.parse_args()
+    os.makedirs(GOLD, exist_ok=True)
+    torch.set_num_threads(os.cpu_count())
+    if a.only in (None, "dmtet"):
+        gen_dmtet()
+    if a.only in (None, "unet"):
+        gen_unet_and_sampler(a.skip_res64)
+    print("golden fixtures written to", GOLD)

@@ -1,0 +1,222 @@
+"""Per-kernel parity on the GPU: each HIP entry point (through the C ABI) against plain PyTorch
+fp32 on the CPU (the oracle's building blocks).  Tolerances: bf16x3 GEMM/conv 3e-5 rel-L2
+(operand split keeps ~16 mantissa bits; SURVEY 7.1 measured 1.8e-5 for a whole U-Net), fp32
+streaming kernels 2e-6, bit-exact where stated."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+TOL_MFMA = 3e-5
+TOL_F32 = 2e-6
+
+
+@pytest.fixture(scope="module")
+def ops(hip_lib):
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from meshdiffusion_amd import hip_ops
+    return hip_ops
+
+
+def _rand(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(shape, generator=g) * scale
+
+
+def _to_s16(ops, x):
+    parts = [(ops.ncdhw_to_f32b(x.cuda()), x.shape[1])]
+    B, P = x.shape[0], int(np.prod(x.shape[2:]))
+    return ops.gn_apply(parts, None, B, P, norm=False, silu=False), B, P
+
+
+def test_layout_roundtrip_and_split(ops):
+    x = _rand((2, 16, 4, 4, 8), 0)
+    f = ops.ncdhw_to_f32b(x.cuda())
+    assert torch.equal(ops.f32b_to_ncdhw(f, x.shape[2:]).cpu(), x)
+    s, B, P = _to_s16(ops, x)
+    back = ops.s16b_to_ncdhw(s, x.shape[2:]).cpu()
+    assert rel_l2(back, x) < 2e-5          # hi+lo keeps >= 16 mantissa bits
+    hi = s[:, :, 0].float().cpu()           # plane 0 must be exactly bf16(x)
+    x_blk = x.reshape(2, 2, 8, -1).permute(0, 1, 3, 2)
+    assert torch.equal(hi, x_blk.to(torch.bfloat16).float())
+    s2 = ops.ncdhw_to_s16b(x.cuda(), 16)
+    assert torch.equal(s2.view(torch.int16).cpu(), s.view(torch.int16).cpu())
+
+
+def test_gemm_asymmetric_identity(ops):
+    """Transpose-detecting check of the MFMA fragment/accumulator mapping: W = shifted identity."""
+    Cc, P = 128, 256
+    x = torch.arange(Cc * P, dtype=torch.float32).reshape(1, Cc, 1, 1, P) / 7.0
+    W = torch.zeros(Cc, Cc)
+    for i in range(Cc):
+        W[i, (3 * i + 5) % Cc] = 1.0 + i / 64.0      # y[o] = sum_i x[i] W[i,o]: asymmetric permutation
+    s, B, Pn = _to_s16(ops, x)
+    pw = ops.PackedWeight(W.cuda(), "nin", ops.CFG_G1_128, "cuda")
+    out = ops.f32b_empty(1, Cc, P, "cuda")
+    ops.gemm_conv(cfg=ops.CFG_G1_128, a=pw.data, b=s, out=out, batch=1, rows=Cc, rows_alloc=Cc, kdim=Cc,
+                  dims=(1, 1, P))
+    y = ops.f32b_to_ncdhw(out, (1, 1, P)).cpu()
+    ref = torch.einsum("bcdhw,co->bodhw", x, W)
+    assert rel_l2(y, ref) < TOL_MFMA
+
+
+@pytest.mark.parametrize("cin,cout,S,B", [(32, 128, 8, 2), (64, 256, 16, 1), (160, 128, 8, 1)])
+def test_conv3_main(ops, cin, cout, S, B):
+    x = _rand((B, cin, S, S, S), 1)
+    w = _rand((cout, cin, 3, 3, 3), 2, 0.05)
+    bias = _rand((B, cout), 3)
+    res = _rand((B, cout, S, S, S), 4)
+    s, _, P = _to_s16(ops, x)
+    pw = ops.PackedWeight(w.cuda(), "conv", ops.CFG_C3_128, "cuda")
+    out = ops.f32b_empty(B, cout, P, "cuda")
+    ops.gemm_conv(cfg=ops.CFG_C3_128, a=pw.data, b=s, out=out, batch=B, rows=cout, rows_alloc=cout, kdim=cin,
+                  dims=(S, S, S), bias=bias.cuda(), bias_bstride=cout, residual=ops.ncdhw_to_f32b(res.cuda()),
+                  res_bstride=cout * P)
+    y = ops.f32b_to_ncdhw(out, (S, S, S)).cpu()
+    ref = F.conv3d(x, w, padding=1) + bias[:, :, None, None, None] + res
+    assert rel_l2(y, ref) < TOL_MFMA
+
+
+def test_conv3_low_tile(ops):
+    x = _rand((2, 64, 4, 4, 4), 5); w = _rand((128, 64, 3, 3, 3), 6, 0.05)
+    s, B, P = _to_s16(ops, x)
+    pw = ops.PackedWeight(w.cuda(), "conv", ops.CFG_C3_LOW, "cuda")
+    out = ops.f32b_empty(2, 128, P, "cuda")
+    ops.gemm_conv(cfg=ops.CFG_C3_LOW, a=pw.data, b=s, out=out, batch=2, rows=128, rows_alloc=128, kdim=64, dims=(4, 4, 4))
+    assert rel_l2(ops.f32b_to_ncdhw(out, (4, 4, 4)).cpu(), F.conv3d(x, w, padding=1)) < TOL_MFMA
+
+
+@pytest.mark.parametrize("S_in", [8, 16])
+def test_conv3_stride2(ops, S_in):
+    x = _rand((2, 32, S_in, S_in, S_in), 7); w = _rand((64, 32, 3, 3, 3), 8, 0.05); b = _rand((64,), 9)
+    s, B, _ = _to_s16(ops, x)
+    So = S_in // 2
+    pw = ops.PackedWeight(w.cuda(), "conv", ops.CFG_C3_S2, "cuda")
+    out = ops.f32b_empty(2, 64, So ** 3, "cuda")
+    ops.gemm_conv(cfg=ops.CFG_C3_S2, a=pw.data, b=s, out=out, batch=2, rows=64, rows_alloc=64, kdim=32,
+                  dims=(So, So, So), bias=b.cuda())
+    ref = F.conv3d(F.pad(x, (0, 1, 0, 1, 0, 1)), w, b, stride=2)
+    assert rel_l2(ops.f32b_to_ncdhw(out, (So, So, So)).cpu(), ref) < TOL_MFMA
+
+
+@pytest.mark.parametrize("S_in,cfg_name", [(4, "CFG_C3_128"), (8, "CFG_C3_128")])
+def test_conv3_upsample_fold(ops, S_in, cfg_name):
+    cfg = getattr(ops, cfg_name)
+    x = _rand((1, 64, S_in, S_in, S_in), 10); w = _rand((64, 64, 3, 3, 3), 11, 0.05)
+    s, B, _ = _to_s16(ops, x)
+    So = 2 * S_in
+    pw = ops.PackedWeight(w.cuda(), "conv", cfg, "cuda")
+    out = ops.f32b_empty(1, 64, So ** 3, "cuda")
+    ops.gemm_conv(cfg=cfg, a=pw.data, b=s, out=out, batch=1, rows=64, rows_alloc=64, kdim=64, dims=(So, So, So), ups=1)
+    ref = F.conv3d(F.interpolate(x, scale_factor=2, mode="nearest"), w, padding=1)
+    assert rel_l2(ops.f32b_to_ncdhw(out, (So, So, So)).cpu(), ref) < TOL_MFMA
+
+
+def test_conv3_stem_and_head(ops):
+    S = 8
+    x = _rand((2, 4, S, S, S), 12); w = _rand((128, 4, 3, 3, 3), 13, 0.1)
+    x16 = ops.ncdhw_to_s16b(x.cuda(), 16)
+    pw = ops.PackedWeight(w.cuda(), "conv", ops.CFG_C3_128_K16, "cuda")
+    out = ops.f32b_empty(2, 128, S ** 3, "cuda")
+    ops.gemm_conv(cfg=ops.CFG_C3_128_K16, a=pw.data, b=x16, out=out, batch=2, rows=128, rows_alloc=128,
+                  kdim=16, dims=(S, S, S))
+    assert rel_l2(ops.f32b_to_ncdhw(out, (S, S, S)).cpu(), F.conv3d(x, w, padding=1)) < TOL_MFMA
+    # head: Cout=4 written straight to NCDHW
+    xh = _rand((2, 64, S, S, S), 14); wh = _rand((4, 64, 3, 3, 3), 15, 0.05); bh = _rand((4,), 16)
+    s, _, _ = _to_s16(ops, xh)
+    pwh = ops.PackedWeight(wh.cuda(), "conv", ops.CFG_C3_32, "cuda")
+    o = torch.empty((2, 4, S, S, S), device="cuda")
+    ops.gemm_conv(cfg=ops.CFG_C3_32, a=pwh.data, b=s, out=o, batch=2, rows=4, rows_alloc=8, kdim=64, dims=(S, S, S),
+                  bias=bh.cuda(), out_mode=ops.OUT_NCDHW)
+    assert rel_l2(o.cpu(), F.conv3d(xh, wh, bh, padding=1)) < TOL_MFMA
+
+
+@pytest.mark.parametrize("P,cin,cout,cfg_name", [(512, 64, 128, "CFG_G1_128"), (64, 96, 128, "CFG_G1_128_LOW"),
+                                                 (64, 64, 64, "CFG_G1_64_LOW")])
+def test_nin_gemm_and_s16b_out(ops, P, cin, cout, cfg_name):
+    cfg = getattr(ops, cfg_name)
+    x = _rand((2, cin, 1, 1, P), 17); W = _rand((cin, cout), 18, 0.1); b = _rand((cout,), 19)
+    s, _, _ = _to_s16(ops, x)
+    pw = ops.PackedWeight(W.cuda(), "nin", cfg, "cuda")
+    ref = torch.einsum("bcdhw,co->bodhw", x, W) + b[None, :, None, None, None]
+    out = ops.f32b_empty(2, cout, P, "cuda")
+    ops.gemm_conv(cfg=cfg, a=pw.data, b=s, out=out, batch=2, rows=cout, rows_alloc=cout, kdim=pw.kdim, dims=(1, 1, P), bias=b.cuda())
+    assert rel_l2(ops.f32b_to_ncdhw(out, (1, 1, P)).cpu(), ref) < TOL_MFMA
+    o16 = ops.s16b_empty(2, cout, P, "cuda")
+    ops.gemm_conv(cfg=cfg, a=pw.data, b=s, out=o16, batch=2, rows=cout, rows_alloc=cout, kdim=pw.kdim, dims=(1, 1, P),
+                  bias=b.cuda(), out_mode=ops.OUT_S16B)
+    assert rel_l2(ops.s16b_to_ncdhw(o16, (1, 1, P)).cpu(), ref) < TOL_MFMA
+
+
+@pytest.mark.parametrize("Cc,groups_ch", [(32, 1), (128, 4), (96, 3)])
+def test_groupnorm_silu_split(ops, Cc, groups_ch):
+    B, S = 2, 8
+    xa = _rand((B, Cc // 2 if Cc % 16 == 0 else Cc, S, S, S), 20) * 3 + 1.5
+    parts_t = [xa] if xa.shape[1] == Cc else [xa, _rand((B, Cc - xa.shape[1], S, S, S), 21) - 0.7]
+    gamma = 1 + 0.1 * _rand((Cc,), 22); beta = 0.1 * _rand((Cc,), 23)
+    P = S ** 3
+    parts = [(ops.ncdhw_to_f32b(t.cuda()), t.shape[1]) for t in parts_t]
+    prm = ops.gn_params(parts, gamma.cuda(), beta.cuda(), B, P)
+    xcat = torch.cat(parts_t, dim=1)
+    for silu in (True, False):
+        y = ops.s16b_to_ncdhw(ops.gn_apply(parts, prm, B, P, norm=True, silu=silu), (S, S, S)).cpu()
+        ref = F.group_norm(xcat, 32, gamma, beta, eps=1e-6)
+        ref = F.silu(ref) if silu else ref
+        assert rel_l2(y, ref) < 1e-5, (Cc, silu)
+
+
+def test_softmax_keys(ops):
+    B, N = 2, 256
+    s = _rand((B, N, N), 24) * 4     # s[b][key][query]
+    s_blk = s.reshape(B, N // 8, 8, N).permute(0, 1, 3, 2).contiguous().cuda()
+    p = ops.softmax_keys(s_blk, B, N, N)          # [B][N/8][2][N][8]
+    pf = (p[:, :, 0].float() + p[:, :, 1].float()).cpu()  # [B][N/8][Nq][8]
+    got = pf.permute(0, 1, 3, 2).reshape(B, N, N)
+    ref = F.softmax(s, dim=1)
+    assert rel_l2(got, ref) < 2e-5
+
+
+def test_temb_and_linear(ops):
+    from oracle import unet_oracle as uo
+    t = torch.tensor([999.0, 998.001, 500.3, 0.999])
+    emb = ops.timestep_embedding(t.cuda(), 128).cpu()
+    ref = uo.timestep_embedding(t, 128)
+    assert float((emb - ref).abs().max()) < 2e-4   # sin/cos of arguments up to ~1e3: 1 ulp of the argument
+    x = _rand((4, 128), 25); w = _rand((512, 128), 26, 0.1); b = _rand((512,), 27)
+    y = ops.linear(x.cuda(), w.cuda(), b.cuda(), silu_in=True).cpu()
+    assert rel_l2(y, F.linear(F.silu(x), w, b)) < TOL_F32
+
+
+def test_ancestral_step_bit_exact(ops):
+    from oracle import unet_oracle as uo
+    B, Cc, S = 2, 4, 8
+    x, e, z = _rand((B, Cc, S, S, S), 28), _rand((B, Cc, S, S, S), 29), _rand((B, Cc, S, S, S), 30)
+    mask = (torch.rand(S, S, S, generator=torch.Generator().manual_seed(31)) < 0.3).float()
+    t = torch.tensor(0.731)
+    betas, _, sq1m = uo.vpsde_tables()
+    k = (t * 999).long()
+    coef = torch.stack([betas[k], sq1m[k], torch.sqrt(1.0 - betas[k]), torch.sqrt(betas[k])]).expand(B, 4).contiguous()
+    xn, xm = ops.ancestral_step(x.cuda(), e.cuda(), z.cuda(), mask.reshape(-1).cuda(), coef.cuda())
+    rn, rm = uo.ancestral_step(x, e, z, t, mask)
+    assert torch.equal(xm.cpu(), rm) and torch.equal(xn.cpu(), rn)
+
+
+def test_inpaint_blend_and_renoise(ops):
+    B, Cc, S = 2, 4, 8
+    x = _rand((B, Cc, S, S, S), 32); src = _rand((1, S, S, S), 33); z = _rand((B, S, S, S), 34)
+    pm = (torch.rand(S, S, S, generator=torch.Generator().manual_seed(35)) < 0.5).float()
+    gm = (torch.rand(S, S, S, generator=torch.Generator().manual_seed(36)) < 0.5).float()
+    xg = x.cuda().clone()
+    ops.inpaint_blend_(xg, src.cuda(), pm.reshape(-1).cuda(), gm.reshape(-1).cuda(), 0)
+    ref = x.clone(); ref[:, 0] = (x[:, 0] * (1 - pm) + src * pm) * gm
+    assert torch.equal(xg.cpu(), ref)
+    coef = torch.tensor([[0.9, 0.4], [0.8, 0.6]])
+    xm = torch.zeros_like(xg)
+    ops.inpaint_renoise_(xg, xm, z.cuda(), pm.reshape(-1).cuda(), gm.reshape(-1).cuda(), coef.cuda(), 0)
+    upd = coef[:, 0, None, None, None] * ref[:, 0] + coef[:, 1, None, None, None] * z
+    ref2 = ref.clone(); ref2[:, 0] = (ref[:, 0] * (1 - pm) + upd * pm) * gm
+    assert rel_l2(xg.cpu(), ref2) < 1e-6 and torch.equal(xm[:, 0].cpu(), xg[:, 0].cpu())
