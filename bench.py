@@ -1,0 +1,186 @@
+"""bench.py -- denoise steps/sec on 64^3 x 4 DMTet grids (BASELINE.json metric), 1..8 MI355X.
+
+A "step" is one DDPM ancestral denoise step of a batch: one res64 U-Net evaluation (HIP kernels)
+plus the fused ancestral update.  Workload = BASELINE.json configs[1]: res64 4-channel grid,
+batch 8 per GPU, iterations of the 1000-step sampler; random-init ("sensitised") weights, synthetic
+data.  Sampling shards over GPUs as independent sample batches: no data-path collective
+("scaling": "weak", batch per GPU fixed).
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line (rank 0).  `value` = N * B * K / wall  (sample-steps per second, whole job).
+Extra objects: `roofline` (dominant kernel = the 3x3x3 implicit-GEMM conv, HIP-event timed inside
+the timed region) and `cpu_baseline` (the CPU oracle restatement of the reference on the host cores,
+rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# algorithmic work of one res64 U-Net forward per sample
+FLOPS_PER_SAMPLE_STEP = 5.763e12
+ACT_BYTES_PER_SAMPLE_STEP = 8.21e9
+WEIGHT_BYTES_PER_STEP = 1.456e9
+PEAK_BF16_TFLOPS = 2500.0     # dense bf16 MFMA peak, MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=8, help="samples per GPU (configs[1]: 8)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true")
+    return ap.parse_args()
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from meshdiffusion_amd import hip_ops, synth
+    from meshdiffusion_amd.config import get_config_res64
+    from meshdiffusion_amd.lib.diffusion import sampling, sde_lib
+    from meshdiffusion_amd.lib.diffusion.models import ddpm_res64, utils as mutils  # noqa: F401
+
+    cfg = get_config_res64()
+    cfg.device = dev
+    cfg.eval.batch_size = a.batch
+    R, B = cfg.data.image_size, a.batch
+    t_setup = time.time()
+    model = mutils.create_model(cfg).eval()
+    sd_cpu = synth.sensitised_state_dict(model.module.state_dict(), seed=1234, grid_mask=synth.synthetic_grid_mask(R))
+    model.module.load_state_dict(sd_cpu, strict=True)
+    if not (rank == 0 and world == 1 and not a.no_cpu_baseline):
+        sd_cpu = None
+    sde = sde_lib.VPSDE(cfg.model.beta_min, cfg.model.beta_max, cfg.model.num_scales, device=dev)
+    mask = synth.synthetic_grid_mask(R).view(1, R, R, R).to(dev)
+    shape = (B, cfg.data.num_channels, R, R, R)
+    stepper = sampling.AncestralStepper(sde, shape, eps=1e-3, device=dev, grid_mask=mask)
+    model_fn = mutils.get_model_fn(model, train=False)
+    torch.manual_seed(42 + rank)
+    t_setup = time.time() - t_setup
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        x = stepper.prior()
+        it = 0
+        for _ in range(a.warmup):          # untimed: packs weights, warms allocator and caches
+            x, _ = stepper.step(model_fn, x, it); it += 1
+        if not a.no_kernel_events:
+            hip_ops.PROFILE = []
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            x, xm = stepper.step(model_fn, x, it); it += 1
+        barrier()
+        wall = time.perf_counter() - t0
+    events, hip_ops.PROFILE = hip_ops.PROFILE, None
+    assert bool(torch.isfinite(xm).all()), "non-finite samples"
+
+    wall_t = torch.tensor([wall], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(wall_t, op=dist.ReduceOp.MAX)
+    wall = float(wall_t.item())
+
+    if rank == 0:
+        sample_steps = world * B * a.steps
+        value = sample_steps / wall
+        ms_per_step = wall / a.steps * 1e3
+        # ---- roofline of the dominant kernel from in-region HIP events ----
+        roof = None
+        if events:
+            main = [(f, s.elapsed_time(e) * 1e-3) for (c, f, s, e) in events if c == hip_ops.CFG_C3_128]
+            tot_f, tot_t = sum(f for f, _ in main), sum(t for _, t in main)
+            allt = sum(s.elapsed_time(e) * 1e-3 for (_, _, s, e) in events)
+            ach = tot_f / tot_t / 1e12
+            roof = {"bound": "mfma", "kernel": "md_gemm_conv_kernel<Cfg_C3_128> (3x3x3 conv, bf16x3 MFMA)",
+                    "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                    "launches": len(main), "avg_launch_ms": round(tot_t / max(len(main), 1) * 1e3, 4),
+                    "kernel_time_share_of_step": round(tot_t / wall, 4),
+                    "all_gemm_conv_time_share_of_step": round(allt / wall, 4),
+                    "note": "achieved = algorithmic 2*M*N*K flops (1x, not the 3 bf16 MFMAs issued per product) "
+                            "/ HIP-event time of every launch of this kernel inside the timed region; "
+                            "ceiling of the bf16x3 scheme is 1/3 of peak"}
+        step_flops = B * FLOPS_PER_SAMPLE_STEP
+        step_bytes = B * ACT_BYTES_PER_SAMPLE_STEP + WEIGHT_BYTES_PER_STEP
+        whole = {"mfma_frac_step": round(step_flops / (wall / a.steps) / (PEAK_BF16_TFLOPS * 1e12), 4),
+                 "hbm_frac_step": round(step_bytes / (wall / a.steps) / (PEAK_HBM_GBS * 1e9), 4),
+                 "ms_per_unet_eval_per_sample": round(ms_per_step / B, 3)}
+        cpu = None
+        if world == 1 and not a.no_cpu_baseline:
+            cpu = cpu_baseline(sd_cpu, cfg, synth)
+        line = {
+            "metric": "denoise steps/sec on 64^3x4 DMTet grids (sample-steps/s = n_gpus*batch*steps/wall)",
+            "value": round(value, 3), "unit": "sample-steps/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16x3 (split-bf16 MFMA operands, fp32 accumulate/IO)",
+            "data": "synthetic (seeded prior noise, sensitised random-init res64 weights, synthetic grid mask)",
+            "config": {"workload": "BASELINE configs[1]: res64 4-ch grid DDPM ancestral sampling steps, batch=8 per GPU",
+                       "batch_per_gpu": B, "grid": [cfg.data.num_channels, R, R, R],
+                       "sharding": "independent sample shards per GPU, no data-path collective"},
+            "roofline": roof, "whole_step": whole, "cpu_baseline": cpu, "setup_s": round(t_setup, 1),
+        }
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(sd_cpu, cfg, synth):
+    """The oracle (CPU restatement of the reference, pinned to it by oracle/gen_golden.py) timed on
+    the host cores: one denoise step at B=1 = 1/(8*K) of the GPU workload's unit count."""
+    from oracle import unet_oracle as uo
+    torch.set_num_threads(os.cpu_count())
+    ocfg = synth.oracle_cfg(cfg)
+    R = cfg.data.image_size
+    x = synth.synthetic_inputs(1, 4, R, seed=42)
+    z = synth.synthetic_inputs(1, 4, R, seed=43)
+    mask = synth.synthetic_grid_mask(R).view(1, R, R, R)
+    times = []
+    with torch.no_grad():
+        for i in range(2):
+            t0 = time.perf_counter()
+            t = torch.tensor(1.0 - i * 1e-3)
+            e = uo.unet_res64_forward(sd_cpu, ocfg, x, torch.ones(1) * t * 999)
+            x, _ = uo.ancestral_step(x, e, z, t, mask)
+            times.append(time.perf_counter() - t0)
+    best = min(times)
+    return {"value": round(1.0 / best, 4), "unit": "sample-steps/s", "cores": torch.get_num_threads(),
+            "kind": "port", "s_per_sample_step": round(best, 2),
+            "sample": "2 denoise steps (res64 U-Net eval + ancestral update) at batch=1 on the host CPU, best of 2; "
+                      "PyTorch fp32 oracle restatement (oracle/unet_oracle.py)"}
+
+
+if __name__ == "__main__":
+    main()

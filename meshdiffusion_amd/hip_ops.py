@@ -14,6 +14,9 @@ from ._lib import (A_PACKED, A_S16B, CFG_C3_128, CFG_C3_128_K16, CFG_C3_32, CFG_
                    MdGemmConvArgs, check)
 
 
+PROFILE = None   # set to a list by bench.py to collect (cfg, flops, start_event, end_event) per GEMM/conv launch
+
+
 def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -102,7 +105,16 @@ def gemm_conv(*, cfg, a, b, out, batch, rows, rows_alloc, kdim, dims, bias=None,
             pin *= 8
         b_bstride = (kdim // 8) * 2 * pin * 8
     args.b_bstride = b_bstride
-    check(lib.md_gemm_conv(C.byref(args), _stream()), f"md_gemm_conv(cfg={cfg})")
+    if PROFILE is None:
+        check(lib.md_gemm_conv(C.byref(args), _stream()), f"md_gemm_conv(cfg={cfg})")
+    else:  # bench.py: HIP events on the launch stream around this launch (algorithmic flops, 1x)
+        taps = _lib.cfg_info(cfg)["taps"]
+        flops = 2.0 * batch * rows * kdim * taps * D * H * W
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(lib.md_gemm_conv(C.byref(args), _stream()), f"md_gemm_conv(cfg={cfg})")
+        e1.record()
+        PROFILE.append((cfg, flops, e0, e1))
     return out
 
 
