@@ -161,7 +161,8 @@ def cpu_baseline(sd_cpu, cfg, synth):
     """The oracle (CPU restatement of the reference, pinned to it by oracle/gen_golden.py) timed on
     the host cores: one denoise step at B=1 = 1/(8*K) of the GPU workload's unit count."""
     from oracle import unet_oracle as uo
-    torch.set_num_threads(os.cpu_count())
+    # oneDNN convs of this size get slower beyond a few dozen threads (256 threads: 98 s/step measured)
+    torch.set_num_threads(min(os.cpu_count(), 32))
     ocfg = synth.oracle_cfg(cfg)
     R = cfg.data.image_size
     x = synth.synthetic_inputs(1, 4, R, seed=42)
@@ -170,6 +171,8 @@ def cpu_baseline(sd_cpu, cfg, synth):
     times = []
     with torch.no_grad():
         for i in range(2):
+            if times and times[0] > 12.0:
+                break            # keep the default bench run within minutes
             t0 = time.perf_counter()
             t = torch.tensor(1.0 - i * 1e-3)
             e = uo.unet_res64_forward(sd_cpu, ocfg, x, torch.ones(1) * t * 999)
@@ -178,7 +181,7 @@ def cpu_baseline(sd_cpu, cfg, synth):
     best = min(times)
     return {"value": round(1.0 / best, 4), "unit": "sample-steps/s", "cores": torch.get_num_threads(),
             "kind": "port", "s_per_sample_step": round(best, 2),
-            "sample": "2 denoise steps (res64 U-Net eval + ancestral update) at batch=1 on the host CPU, best of 2; "
+            "sample": f"{len(times)} denoise step(s) (res64 U-Net eval + ancestral update) at batch=1 on the host CPU, best; "
                       "PyTorch fp32 oracle restatement (oracle/unet_oracle.py)"}
 
 

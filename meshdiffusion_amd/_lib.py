@@ -77,6 +77,12 @@ def load():
         raise MeshDiffusionHipError(
             f"{LIB_PATH} not found: run `python -m meshdiffusion_amd.build` (needs hipcc). "
             "There is no CPU fallback for the HIP path.")
+    # ORDER MATTERS: PyTorch bundles its own libamdhip64.so (SONAME libamdhip64.so.7).  Importing torch
+    # first makes the dynamic linker satisfy our DT_NEEDED libamdhip64.so.7 with that already-loaded
+    # copy, so torch and this library share ONE HIP runtime (streams, events and the null stream mean
+    # the same thing on both sides).  Loading us first would pull in /opt/rocm's runtime next to
+    # torch's and every launch would fail with hipErrorNoDevice.
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
@@ -89,6 +95,9 @@ def load():
         lib.md_gemm_conv_cfg_info(cfg, *[C.byref(x) for x in v])
         if (v[0].value, v[1].value) != (nt, kc):
             raise MeshDiffusionHipError(f"cfg {cfg} NT/KC mismatch between _lib.py and the library")
+    if torch.cuda.is_available() and lib.md_device_count() != torch.cuda.device_count():
+        raise MeshDiffusionHipError("libmeshdiffusion_hip.so is not sharing PyTorch's HIP runtime "
+                                    f"({lib.md_device_count()} vs {torch.cuda.device_count()} devices)")
     _lib = lib
     return lib
 

@@ -170,6 +170,7 @@ extern "C" int md_marching_tets(const float* pos, const float* sdf, const int32_
       n_meshes <= 0 || n_verts <= 0 || n_edges <= 0 || n_tets <= 0)
     return MD_ERR_BAD_ARG;
   if (workspace_bytes < md_marching_tets_workspace_bytes(n_meshes, n_edges)) return MD_ERR_BAD_ARG;
+  MD_HIP_CLEAR_ERROR();
   hipLaunchKernelGGL(md_marching_tets_kernel, dim3((unsigned)n_meshes), dim3(MT_THREADS), 0,
                      (hipStream_t)stream, pos, sdf, tets, edges, tet_edges, n_verts, n_edges, n_tets,
                      verts, faces, face_tet, counts, (int32_t*)workspace);

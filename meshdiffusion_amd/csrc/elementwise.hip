@@ -39,6 +39,7 @@ __global__ __launch_bounds__(256) void md_linear_kernel(const float* __restrict_
 extern "C" int md_linear(const float* x, const float* w, const float* bias, float* y, int32_t batch,
                          int32_t in_dim, int32_t out_dim, int32_t silu_in, void* stream) {
   if (!x || !w || !y || batch <= 0 || in_dim <= 0 || out_dim <= 0) return MD_ERR_BAD_ARG;
+  MD_HIP_CLEAR_ERROR();
   hipLaunchKernelGGL(md_linear_kernel<8>, dim3((unsigned)((out_dim + 3) / 4)), dim3(256), 0,
                      (hipStream_t)stream, x, w, bias, y, batch, in_dim, out_dim, silu_in);
   MD_HIP_CHECK_LAUNCH();
@@ -70,6 +71,7 @@ extern "C" int md_ncdhw_to_s16b(const float* x, void* out, int32_t batch, int32_
                                 int64_t P, void* stream) {
   if (!x || !out || batch <= 0 || C <= 0 || c_pad < C || (c_pad % 8) || P <= 0) return MD_ERR_BAD_ARG;
   dim3 grid((unsigned)((P + 255) / 256), (unsigned)batch);
+  MD_HIP_CLEAR_ERROR();
   hipLaunchKernelGGL(md_ncdhw_to_s16b_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, (uint4*)out,
                      C, c_pad, P);
   MD_HIP_CHECK_LAUNCH();
@@ -98,6 +100,7 @@ __global__ void md_relayout_kernel(const void* __restrict__ xin, float* __restri
 static int relayout(const void* x, float* out, int32_t batch, int32_t C, int64_t P, int mode, void* stream) {
   if (!x || !out || batch <= 0 || C <= 0 || (C % 8) || P <= 0) return MD_ERR_BAD_ARG;
   dim3 grid((unsigned)((P + 255) / 256), (unsigned)C, (unsigned)batch);
+  MD_HIP_CLEAR_ERROR();
   hipLaunchKernelGGL(md_relayout_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, out, C, P, mode);
   MD_HIP_CHECK_LAUNCH();
   return MD_OK;
@@ -152,6 +155,7 @@ extern "C" int md_ancestral_step(const float* x, const float* eps, const float* 
   const int64_t CP = (int64_t)C * P;
   int blocks = (int)((CP / 4 + 255) / 256);
   if (blocks > 2048) blocks = 2048;
+  MD_HIP_CLEAR_ERROR();
   hipLaunchKernelGGL(md_ancestral_step_kernel, dim3((unsigned)blocks, (unsigned)batch), dim3(256), 0,
                      (hipStream_t)stream, x, eps, z, mask, coef, x_out, x_mean_out, CP, P);
   MD_HIP_CHECK_LAUNCH();
@@ -203,6 +207,7 @@ extern "C" int md_inpaint_blend(float* x, const float* src, const float* pmask, 
   if (!x || !src || !pmask || batch <= 0 || C <= 0 || ch < 0 || ch >= C || P <= 0) return MD_ERR_BAD_ARG;
   int blocks = (int)((P + 255) / 256);
   if (blocks > 1024) blocks = 1024;
+  MD_HIP_CLEAR_ERROR();
   hipLaunchKernelGGL(md_inpaint_blend_kernel, dim3((unsigned)blocks, (unsigned)batch), dim3(256), 0,
                      (hipStream_t)stream, x, src, pmask, gmask, C, ch, P, src_bstride);
   MD_HIP_CHECK_LAUNCH();
@@ -215,6 +220,7 @@ extern "C" int md_inpaint_renoise(float* x, float* x_mean, const float* z, const
   if (!x || !z || !pmask || !coef || batch <= 0 || C <= 0 || ch < 0 || ch >= C || P <= 0) return MD_ERR_BAD_ARG;
   int blocks = (int)((P + 255) / 256);
   if (blocks > 1024) blocks = 1024;
+  MD_HIP_CLEAR_ERROR();
   hipLaunchKernelGGL(md_inpaint_renoise_kernel, dim3((unsigned)blocks, (unsigned)batch), dim3(256), 0,
                      (hipStream_t)stream, x, x_mean, z, pmask, gmask, coef, C, ch, P);
   MD_HIP_CHECK_LAUNCH();
@@ -271,6 +277,7 @@ __global__ __launch_bounds__(256) void md_softmax_keys_kernel(const float* __res
 extern "C" int md_softmax_keys(const float* s, void* p, int32_t batch, int32_t n_keys, int32_t n_q,
                                void* stream) {
   if (!s || !p || batch <= 0 || n_keys <= 0 || (n_keys % 8) || n_q <= 0 || (n_q % 32)) return MD_ERR_BAD_ARG;
+  MD_HIP_CLEAR_ERROR();
   hipLaunchKernelGGL(md_softmax_keys_kernel, dim3((unsigned)(n_q / 32), (unsigned)batch), dim3(256), 0,
                      (hipStream_t)stream, s, (uint16_t*)p, n_keys, n_q);
   MD_HIP_CHECK_LAUNCH();
@@ -298,6 +305,7 @@ extern "C" int md_timestep_embedding(const float* t, float* emb, int32_t batch, 
   const int half = dim / 2;
   const float neg_scale = (float)(-(log(10000.0) / (double)(half - 1)));
   const int n = batch * half;
+  MD_HIP_CLEAR_ERROR();
   hipLaunchKernelGGL(md_temb_freq_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
                      (hipStream_t)stream, t, emb, batch, dim, neg_scale);
   MD_HIP_CHECK_LAUNCH();

@@ -306,6 +306,7 @@ static int launch_cfg(const MdGemmConvArgs& a, hipStream_t stream) {
   if (a.a_src == MD_A_S16B && a.a_rows <= 0) return MD_ERR_BAD_ARG;
   const int row_tiles = (a.rows + C::NT - 1) / C::NT;
   dim3 grid((unsigned)(tiles * a.batch), (unsigned)row_tiles, 1);
+  MD_HIP_CLEAR_ERROR();
   hipLaunchKernelGGL(md_gemm_conv_kernel<C>, grid, dim3(C::NTHREADS), 0, stream, a);
   MD_HIP_CHECK_LAUNCH();
   return MD_OK;
@@ -395,6 +396,7 @@ extern "C" int md_pack_weights(const float* w, void* wpk, int32_t rows, int32_t 
   const int64_t n_items = bytes / 16;
   int blocks = (int)((n_items + 255) / 256);
   if (blocks > 4096) blocks = 4096;
+  MD_HIP_CLEAR_ERROR();
   hipLaunchKernelGGL(md_pack_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w,
                      (uint4*)wpk, rows, kdim, taps, s_row, s_k, s_tap, nt, kc, n_items);
   MD_HIP_CHECK_LAUNCH();

@@ -8,6 +8,9 @@ typedef __attribute__((ext_vector_type(8))) short bf16x8;  // 8 bf16 = 4 VGPRs (
 typedef __attribute__((ext_vector_type(16))) float f32x16; // 32x32 MFMA accumulator
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
+// hipGetLastError() is sticky per host thread: an error left behind by an unrelated earlier runtime
+// call (e.g. a device probe before the context existed) must not be attributed to our launch.
+#define MD_HIP_CLEAR_ERROR() (void)hipGetLastError()
 #define MD_HIP_CHECK_LAUNCH()                      \
   do {                                             \
     hipError_t e__ = hipGetLastError();            \

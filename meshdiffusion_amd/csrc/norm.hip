@@ -122,6 +122,7 @@ extern "C" int md_gn_stats(const float* x, double* sums, int32_t batch, int32_t 
   if (!x || !sums || batch <= 0 || C <= 0 || (C % 8) || P <= 0 || c_off < 0 || c_off + C > c_total)
     return MD_ERR_BAD_ARG;
   dim3 grid((unsigned)((P + GN_CHUNK - 1) / GN_CHUNK), (unsigned)(C / 8), (unsigned)batch);
+  MD_HIP_CLEAR_ERROR();
   hipLaunchKernelGGL(md_gn_stats_kernel, grid, dim3(GN_BLOCK), 0, (hipStream_t)stream, x, sums, C, P,
                      c_total, c_off);
   MD_HIP_CHECK_LAUNCH();
@@ -133,6 +134,7 @@ extern "C" int md_gn_finalize(const double* sums, const float* gamma, const floa
                               int64_t P, float eps, void* stream) {
   if (!sums || !gamma || !beta || !params || batch <= 0 || groups <= 0 || (c_total % groups))
     return MD_ERR_BAD_ARG;
+  MD_HIP_CLEAR_ERROR();
   hipLaunchKernelGGL(md_gn_finalize_kernel, dim3((unsigned)(batch * groups)), dim3(64), 0,
                      (hipStream_t)stream, sums, gamma, beta, params, c_total, groups, P, eps);
   MD_HIP_CHECK_LAUNCH();
@@ -146,6 +148,7 @@ extern "C" int md_gn_apply(const float* x, const float* params, void* out, int32
       (c_total % 8) || c_off + C > c_total || P <= 0)
     return MD_ERR_BAD_ARG;
   dim3 grid((unsigned)((P + GN_CHUNK - 1) / GN_CHUNK), (unsigned)(C / 8), (unsigned)batch);
+  MD_HIP_CLEAR_ERROR();
   hipLaunchKernelGGL(md_gn_apply_kernel, grid, dim3(GN_BLOCK), 0, (hipStream_t)stream, x, params,
                      (uint16_t*)out, C, P, c_total, c_off, norm, silu);
   MD_HIP_CHECK_LAUNCH();

@@ -1,0 +1,232 @@
+"""CPU suite (-m "not gpu"): oracle vs golden fixtures, host logic, C-ABI exports.  No kernel runs."""
+import ctypes
+import hashlib
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLD, ROOT, rel_l2
+
+
+# ---- oracle pinned to the reference's golden outputs ---------------------------------------------
+def _small_sd():
+    from meshdiffusion_amd import synth
+    from meshdiffusion_amd.lib.diffusion.models import ddpm_res64, utils as mutils  # noqa: F401
+    cfg = synth.small_config(); cfg.device = torch.device("cpu")
+    tmpl = mutils.create_model(cfg, use_parallel=False).state_dict()
+    R = cfg.data.image_size
+    return cfg, synth.sensitised_state_dict(tmpl, seed=1234, grid_mask=synth.synthetic_grid_mask(R))
+
+
+def test_oracle_unet_matches_reference_golden():
+    from meshdiffusion_amd import synth
+    from oracle import unet_oracle as uo
+    cfg, sd = _small_sd()
+    gold = np.load(os.path.join(GOLD, "unet_small.npz"))
+    x = synth.synthetic_inputs(2, 4, cfg.data.image_size, seed=int(gold["x_seed"]))
+    with torch.no_grad():
+        y = uo.unet_res64_forward(sd, synth.oracle_cfg(cfg), x, torch.tensor(gold["labels"]))
+    assert rel_l2(y, gold["y"]) < 1e-5
+
+
+def test_oracle_sampler_matches_reference_golden():
+    from meshdiffusion_amd import synth
+    from oracle import unet_oracle as uo
+    cfg, sd = _small_sd()
+    gold = np.load(os.path.join(GOLD, "sampler_small.npz"))
+    R, K = cfg.data.image_size, int(gold["K"])
+    mask = synth.synthetic_grid_mask(R).view(1, R, R, R)
+    torch.manual_seed(int(gold["uncond_seed"]))
+    x = torch.randn(2, 4, R, R, R) * mask
+    ts = torch.linspace(1.0, 1e-3, 1000)
+    with torch.no_grad():
+        xm = x
+        for i in range(K):
+            e = uo.unet_res64_forward(sd, synth.oracle_cfg(cfg), x, torch.ones(2) * ts[i] * 999)
+            x, xm = uo.ancestral_step(x, e, torch.randn_like(x), ts[i], mask)
+    assert rel_l2(xm, gold["uncond"]) < 1e-5
+
+
+def test_oracle_dmtet_matches_reference_golden():
+    from oracle import dmtet_oracle
+    from oracle.gen_golden import dmtet_cases
+    tet = np.load(os.path.join(GOLD, "64_tets_cropped.npz"))
+    gold = np.load(os.path.join(GOLD, "dmtet.npz"))
+    pos, cases = dmtet_cases(tet["vertices"])
+    for name in ("sphere", "smooth", "box_zeros"):
+        v, f, _ = dmtet_oracle.marching_tets(pos.numpy(), cases[name].numpy(), tet["indices"])
+        assert hashlib.sha256(np.ascontiguousarray(f).tobytes()).hexdigest() == str(gold[f"{name}_faces_sha"])
+        assert hashlib.sha256(np.ascontiguousarray(v).tobytes()).hexdigest() == str(gold[f"{name}_verts_sha"])
+
+
+def test_static_edge_table_formulation_equals_oracle_on_cpu():
+    """The product's formulation (static sorted edge table + prefix sums), emulated with numpy on the
+    tables built by TetTables, gives the reference's faces: checks the host tables without a GPU."""
+    from meshdiffusion_amd.dmtet import TetTables
+    from oracle import dmtet_oracle
+    from oracle.gen_golden import dmtet_cases
+    tet = np.load(os.path.join(GOLD, "64_tets_cropped.npz"))
+    tb = TetTables(torch.as_tensor(tet["indices"]), "cpu")
+    assert tb.n_edges == 195331 and tb.n_tets == 159330
+    pos, cases = dmtet_cases(tet["vertices"])
+    sdf = cases["sinus"].numpy()
+    occ = sdf > 0
+    e = tb.edges.numpy()
+    cross = occ[e[:, 0]] != occ[e[:, 1]]
+    vid = np.where(cross, np.cumsum(cross) - 1, -1)
+    t = tb.tets.numpy()
+    idx = (occ[t] * (2 ** np.arange(4))[None]).sum(-1)
+    ntri = dmtet_oracle.NUM_TRIANGLES[idx]
+    ev = vid[tb.tet_edges.numpy()]
+    f1 = np.take_along_axis(ev[ntri == 1], dmtet_oracle.TRIANGLE_TABLE[idx[ntri == 1]][:, :3], 1).reshape(-1, 3)
+    f2 = np.take_along_axis(ev[ntri == 2], dmtet_oracle.TRIANGLE_TABLE[idx[ntri == 2]][:, :6], 1).reshape(-1, 3)
+    _, fo, _ = dmtet_oracle.marching_tets(pos.numpy(), sdf, tet["indices"])
+    assert np.array_equal(np.concatenate([f1, f2]), fo)
+
+
+def test_grid_mask_from_tets():
+    from meshdiffusion_amd.dmtet import grid_mask_from_tets
+    tet = np.load(os.path.join(GOLD, "64_tets_cropped.npz"))
+    m = grid_mask_from_tets(tet["vertices"], 64)
+    assert int(m.sum()) == 30512 and float(m[63].sum()) == 0.0
+
+
+# ---- C ABI ------------------------------------------------------------------------------------------
+def test_c_abi_exports_every_declared_symbol(hip_lib):
+    from meshdiffusion_amd import _lib
+    header = open(os.path.join(ROOT, "include", "meshdiffusion_hip.h")).read()
+    declared = set(re.findall(r"\b(md_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(raw, name), name
+    assert hip_lib.md_abi_version() == 1
+    info = _lib.cfg_info(_lib.CFG_C3_128)
+    assert info["taps"] == 27 and info["lds_bytes"] <= 160 * 1024 and info["threads"] == 512
+    nm = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    assert " T md_gemm_conv" in nm
+
+
+def test_struct_layout_matches_header():
+    from meshdiffusion_amd._lib import MdGemmConvArgs
+    # 5 pointers, 1 float + 12 int32, 4 int64 -> natural alignment, no surprises
+    assert ctypes.sizeof(MdGemmConvArgs) == 5 * 8 + 13 * 4 + 4 + 4 * 8
+    assert MdGemmConvArgs.a_bstride.offset % 8 == 0
+
+
+def test_bad_arguments_are_rejected_without_a_gpu(hip_lib):
+    from meshdiffusion_amd._lib import MdGemmConvArgs
+    assert hip_lib.md_gemm_conv(None, None) == -1
+    a = MdGemmConvArgs()
+    assert hip_lib.md_gemm_conv(ctypes.byref(a), None) == -1
+    assert hip_lib.md_packed_weight_bytes(128, 128, 27, 128, 32) == 128 * 128 * 27 * 4
+    assert hip_lib.md_marching_tets_workspace_bytes(0, 5) < 0
+
+
+def test_hip_path_refuses_cpu_tensors():
+    from meshdiffusion_amd import _lib, hip_ops
+    with pytest.raises(_lib.MeshDiffusionHipError):
+        hip_ops.ncdhw_to_f32b(torch.zeros(1, 8, 2, 2, 2))
+    from meshdiffusion_amd import synth
+    from meshdiffusion_amd.lib.diffusion.models import ddpm_res64, utils as mutils  # noqa: F401
+    cfg = synth.small_config(); cfg.device = torch.device("cpu")
+    model = mutils.create_model(cfg, use_parallel=False).eval()
+    with pytest.raises(RuntimeError):
+        with torch.no_grad():
+            model(torch.zeros(1, 4, 16, 16, 16), torch.zeros(1))
+
+
+# ---- host-side mirror of the reference API ---------------------------------------------------------------
+def test_registry_state_dict_and_param_count():
+    from meshdiffusion_amd.config import get_config_res64
+    from meshdiffusion_amd.lib.diffusion.models import ddpm_res64, utils as mutils  # noqa: F401
+    cfg = get_config_res64(); cfg.device = torch.device("cpu")
+    m = mutils.get_model("ddpm_res64")(cfg)
+    sd = m.state_dict()
+    assert len(sd) == 497
+    assert sum(p.numel() for p in m.parameters()) == 365076484   # 365.08 M
+    assert sum(p.numel() for p in m.parameters() if p.requires_grad) == 365076484 - 4 * 64 ** 3
+    for k in ("all_modules.0.weight", "all_modules.3.GroupNorm_0.weight", "all_modules.3.Conv_0.weight",
+              "all_modules.3.Dense_0.weight", "all_modules.5.NIN_0.W", "pos_layer.weight", "mask_layer.bias",
+              "coords", "mask", "sigmas"):
+        assert k in sd, k
+    assert tuple(sd["all_modules.3.Conv_0.weight"].shape) == (128, 128, 3, 3, 3)
+    with pytest.raises(ValueError):
+        mutils.register_model(name="ddpm_res64")(type("X", (), {}))
+    from meshdiffusion_amd import synth
+    small = synth.small_config(); small.device = torch.device("cpu")
+    wrapped = mutils.create_model(small)
+    assert all(k.startswith("module.") for k in wrapped.state_dict())
+
+
+def test_config_shim_and_cli_overrides(tmp_path):
+    from meshdiffusion_amd import config as mdc
+    c = mdc.get_config_res64()
+    rest = mdc.apply_overrides(c, ["--config.eval.batch_size=8", "--config.eval.ckpt_path", "a/b.pth", "--x"])
+    assert c.eval.batch_size == 8 and c.eval.ckpt_path == "a/b.pth" and rest == ["--x"]
+    assert c.model.ch_mult == (1, 1, 2, 4, 4) and c.model.num_scales == 1000 and c.optim.lr == 2e-5
+    # a reference-style config file that imports ml_collections loads through the shim
+    d = tmp_path / "configs"; d.mkdir()
+    (d / "default_configs.py").write_text(
+        "import ml_collections\n\ndef get_default_configs():\n    c = ml_collections.ConfigDict()\n"
+        "    c.model = ml_collections.ConfigDict()\n    c.model.nf = 64\n    return c\n")
+    (d / "mine.py").write_text("from configs.default_configs import get_default_configs\n\n"
+                               "def get_config():\n    c = get_default_configs()\n    c.model.name = 'ddpm_res64'\n    return c\n")
+    cfg = mdc.load_config_file(str(d / "mine.py"))
+    assert cfg.model.nf == 64 and cfg.model.name == "ddpm_res64"
+    sys.path.insert(0, ROOT)
+    import main_diffusion
+    cfg2, mode = main_diffusion.parse(["--config=res64", "--mode", "uncond_gen", "--config.eval.batch_size=2"])
+    assert mode == "uncond_gen" and cfg2.eval.batch_size == 2
+    with pytest.raises(SystemExit):
+        main_diffusion.parse(["--config=res64", "--mode=bogus"])
+
+
+def test_vpsde_tables_and_stepper_tables_match_oracle():
+    from meshdiffusion_amd.lib.diffusion import sampling, sde_lib
+    from oracle import unet_oracle as uo
+    sde = sde_lib.VPSDE(0.1, 20.0, 1000, device="cpu")
+    betas, sqac, sq1m = uo.vpsde_tables()
+    assert torch.equal(sde.discrete_betas, betas) and torch.equal(sde.sqrt_1m_alphas_cumprod, sq1m)
+    st = sampling.AncestralStepper(sde, (2, 4, 8, 8, 8), device="cpu", grid_mask=torch.ones(1, 8, 8, 8))
+    # fractional labels 999.0, 998.001, ... ; .long() truncation visits each integer 999..0 once
+    assert float(st.labels[0, 0]) == 999.0 and abs(float(st.labels[1, 0]) - 998.001) < 1e-3
+    ks = (st.timesteps * 999).long()
+    assert sorted(ks.tolist()) == list(range(1000))
+    assert torch.equal(st.coef[5, 0, 0], betas[ks[5]]) and torch.equal(st.coef[5, 1, 1], sq1m[ks[5]])
+    with pytest.raises(AssertionError):
+        sampling.AncestralStepper(sde, (1, 4, 8, 8, 8), device="cpu", grid_mask=torch.full((1, 8, 8, 8), 0.5))
+
+
+def test_ema_and_checkpoint_roundtrip(tmp_path):
+    from meshdiffusion_amd import synth
+    from meshdiffusion_amd.lib.diffusion import losses
+    from meshdiffusion_amd.lib.diffusion.models import ddpm_res64, utils as mutils  # noqa: F401
+    from meshdiffusion_amd.lib.diffusion.models.ema import ExponentialMovingAverage
+    from meshdiffusion_amd.lib.diffusion.utils import restore_checkpoint, save_checkpoint
+    cfg = synth.small_config(); cfg.device = torch.device("cpu")
+    m = mutils.create_model(cfg)
+    ema = ExponentialMovingAverage(m.parameters(), decay=0.9999)
+    before = [s.clone() for s in ema.shadow_params[:3]]
+    with torch.no_grad():
+        for p in m.parameters():
+            if p.requires_grad:
+                p.add_(1.0)
+    ema.update(m.parameters())      # decay = min(0.9999, 2/11)
+    d = 2.0 / 11.0
+    assert torch.allclose(ema.shadow_params[0], before[0] + (1 - d) * 1.0, atol=1e-6)
+    opt = losses.get_optimizer(cfg, m.parameters())
+    state = dict(optimizer=opt, model=m, ema=ema, step=7)
+    path = str(tmp_path / "ck" / "checkpoint.pth"); os.makedirs(os.path.dirname(path))
+    save_checkpoint(path, state)
+    m2 = mutils.create_model(cfg)
+    st2 = dict(optimizer=losses.get_optimizer(cfg, m2.parameters()), model=m2,
+               ema=ExponentialMovingAverage(m2.parameters(), decay=0.5), step=0)
+    st2 = restore_checkpoint(path, st2, device="cpu")
+    assert st2["step"] == 7 and st2["ema"].decay == 0.9999
+    assert torch.equal(m2.state_dict()["module.all_modules.2.weight"], m.state_dict()["module.all_modules.2.weight"])
