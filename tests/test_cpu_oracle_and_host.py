@@ -152,7 +152,7 @@ def test_registry_state_dict_and_param_count():
     assert sum(p.numel() for p in m.parameters()) == 365076484   # 365.08 M
     assert sum(p.numel() for p in m.parameters() if p.requires_grad) == 365076484 - 4 * 64 ** 3
     for k in ("all_modules.0.weight", "all_modules.3.GroupNorm_0.weight", "all_modules.3.Conv_0.weight",
-              "all_modules.3.Dense_0.weight", "all_modules.5.NIN_0.W", "pos_layer.weight", "mask_layer.bias",
+              "all_modules.3.Dense_0.weight", "all_modules.11.NIN_0.W", "all_modules.12.NIN_3.W", "pos_layer.weight", "mask_layer.bias",
               "coords", "mask", "sigmas"):
         assert k in sd, k
     assert tuple(sd["all_modules.3.Conv_0.weight"].shape) == (128, 128, 3, 3, 3)
