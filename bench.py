@@ -119,11 +119,11 @@ def main():
         # ---- roofline of the dominant kernel from in-region HIP events ----
         roof = None
         if events:
-            main = [(f, s.elapsed_time(e) * 1e-3) for (c, f, s, e) in events if c == hip_ops.CFG_C3_128]
+            main = [(f, s.elapsed_time(e) * 1e-3) for (c, f, s, e) in events if c == hip_ops.CFG_C3_128_FAST]
             tot_f, tot_t = sum(f for f, _ in main), sum(t for _, t in main)
             allt = sum(s.elapsed_time(e) * 1e-3 for (_, _, s, e) in events)
             ach = tot_f / tot_t / 1e12
-            roof = {"bound": "mfma", "kernel": "md_gemm_conv_kernel<Cfg_C3_128> (3x3x3 conv, bf16x3 MFMA)",
+            roof = {"bound": "mfma", "kernel": "md_conv3_main_kernel<0> (3x3x3 conv, implicit GEMM, bf16x3 MFMA)",
                     "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
                     "launches": len(main), "avg_launch_ms": round(tot_t / max(len(main), 1) * 1e3, 4),

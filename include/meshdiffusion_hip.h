@@ -50,7 +50,14 @@ enum {
   MD_CFG_G1_128 = 5,     /* 1x1x1 / GEMM, 256 cols, NT=128, KC=32                    */
   MD_CFG_G1_128_LOW = 6, /* 1x1x1 / GEMM, 64 cols,  NT=128, KC=32                    */
   MD_CFG_G1_64_LOW = 7,  /* 1x1x1 / GEMM, 64 cols,  NT=64,  KC=32                    */
-  MD_CFG_COUNT = 8
+  MD_CFG_C3_128_V2 = 8,  /* C3_128 + conflict-free halo layout + software-pipelined loads     */
+  MD_CFG_C3_128_SW = 9,  /* (A/B) conflict-free halo layout only                              */
+  MD_CFG_C3_128_PIPE = 10, /* (A/B) pipelined loads only                                       */
+  MD_CFG_C3_128_V3 = 11, /* weights L2->registers (no LDS weight tiles, no per-tap barrier), 4x2 waves */
+  MD_CFG_C3_128_V3B = 12, /* same, 2x4 wave grid                                              */
+  MD_CFG_C3_128_V4 = 13, /* C3_128_V2 with the barrier between the two K=16 half-steps (LDS latency hidden) */
+  MD_CFG_C3_128_FAST = 14, /* dedicated kernel for the hot conv: C3_128_V2 layout, taps unrolled, F32B out */
+  MD_CFG_COUNT = 15
 };
 
 enum { MD_OUT_F32B = 0, MD_OUT_S16B = 1, MD_OUT_NCDHW = 2 };

@@ -1,0 +1,328 @@
+// md_conv3_main_kernel: the hot 3x3x3 stride-1 convolution (75% of a res64 U-Net evaluation),
+// specialised from md_gemm_conv_kernel<128,32,4,8,8,27,1,2,4,SW=1> with the index arithmetic
+// removed from the steady state.
+//
+// Ablations on MI355X (tools/bench_conv.py, DESIGN.md "Kernel notes") showed that the generic
+// kernel was bound neither by LDS bank conflicts, nor by exposed LDS latency, nor by the halo
+// bubble, but by instruction issue: ~250 integer/branch instructions per tap per wavefront next to
+// 24 MFMAs, executed in lock step by both wavefronts of a SIMD.  Here:
+//   * the 27-tap loop is fully unrolled, so every LDS address is `one VGPR + immediate`
+//     (tap, K-half, hi/lo plane, row tile, column tile are all compile-time offsets);
+//   * weight tiles advance by a scalar pointer bump per tap (WPK tiles are contiguous in step order);
+//   * halo prefetch addresses / validity are computed once per workgroup, not per chunk;
+//   * the epilogue batches its bias / residual loads instead of waiting on each.
+// Same data layouts, same MFMA order per output element => bit-identical to the generic kernel.
+//
+// Reference op: nn.Conv3d 3x3x3 pad 1 (lib/diffusion/models/layers.py:118-124), optionally on the
+// nearest-x2 upsampled input (layers.py:618-623, `ups`).
+#include "md_common.h"
+
+namespace {
+constexpr int NT = 128, KC = 32, TZ = 4, TY = 8, TX = 8, TAPS = 27;
+constexpr int ZH = 6, YH = 10, XH = 10;
+constexpr int HS = 3 * YH * 24;          // 720 halo slots (odd z-planes interleaved at +12, y stride 24)
+constexpr int HPOS = ZH * YH * XH;       // 600 valid halo positions
+constexpr int KG = KC / 8;               // 4
+constexpr int W_ITEMS = KG * 2 * NT;     // 1024 uint4 per weight tile (16 KiB)
+constexpr int A_ITEMS = KG * 2 * HPOS;   // 4800 uint4 per halo tile
+constexpr int NTHREADS = 512;
+constexpr int A_PER_THREAD = (A_ITEMS + NTHREADS - 1) / NTHREADS;  // 10
+constexpr int W_LDS_BYTES = 2 * W_ITEMS * 16;                     // 32 KiB (double buffer)
+constexpr int LDS_ITEMS = 2 * W_ITEMS + KG * 2 * HS;              // 124928 B
+constexpr int PF_TAP = 20;               // tap at which the next chunk's halo loads are issued
+
+__device__ __forceinline__ int slot_of(int hz, int hy, int hx) {
+  return (hz >> 1) * (YH * 24) + hy * 24 + (hz & 1) * 12 + hx;
+}
+}  // namespace
+
+// ABL: timing-only ablations (results invalid): 1 = no LDS fragment reads, 3 = no barriers / weight commits,
+// 4 = no weight global loads, 6 = no barriers only; 7 = (valid results) no MFMA/DS interleave hint
+template <int ABL>
+__global__ __launch_bounds__(NTHREADS) void md_conv3_main_kernel(const MdGemmConvArgs A) {
+  __shared__ __attribute__((aligned(16))) uint4 smem[LDS_ITEMS];
+  unsigned char* lds = (unsigned char*)smem;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform => SALU
+  const int wr = wid >> 2, wc = wid & 3;
+  const int j = lane & 31, h = lane >> 5;
+
+  // ---- tile coordinates (scalar) ----------------------------------------------------------------
+  const int D = A.D, H = A.H, W = A.W;
+  const int64_t P = (int64_t)D * H * W;
+  const int ntx = W / TX, nty = H / TY, ntz = D / TZ;
+  const int tiles = ntx * nty * ntz;
+  int Di = D, Hi = H, Wi = W;
+  if (A.ups) { Di = D >> 1; Hi = H >> 1; Wi = W >> 1; }
+  int bid = blockIdx.x;  // XCD-aware order: one contiguous run of tiles per XCD (block b runs on XCD b%8)
+  if ((gridDim.x & 7) == 0) bid = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  const int b = bid / tiles;
+  const int t = bid % tiles;
+  const int x0 = (t % ntx) * TX, y0 = ((t / ntx) % nty) * TY, z0 = (t / (ntx * nty)) * TZ;
+  const int64_t Pin = (int64_t)Di * Hi * Wi;
+  const int rt = blockIdx.y;
+  const int ncc = A.kdim / KC;
+  const int nsteps = ncc * TAPS;
+
+  const uint4* bptr = (const uint4*)A.b + (int64_t)b * (A.b_bstride / 8);
+  const uint4* wbase = (const uint4*)A.a + (int64_t)rt * nsteps * W_ITEMS;  // tiles contiguous in step order
+
+  // ---- halo prefetch descriptors: computed ONCE (source offset in uint4 units relative to the chunk
+  //      base, -1 = outside the grid => zero fill; LDS destination byte offset) ---------------------
+  int hsrc[A_PER_THREAD], hdst[A_PER_THREAD];
+#pragma unroll
+  for (int i = 0; i < A_PER_THREAD; ++i) {
+    const int item = tid + i * NTHREADS;
+    hsrc[i] = -1; hdst[i] = -1;
+    if (item < A_ITEMS) {
+      const int gp = item / HPOS, r = item % HPOS;
+      const int hx = r % XH, hy = (r / XH) % YH, hz = r / (XH * YH);
+      int uz = z0 + hz - 1, uy = y0 + hy - 1, ux = x0 + hx - 1;
+      bool inb;
+      if (A.ups) {
+        inb = (uz >= 0) & (uz < D) & (uy >= 0) & (uy < H) & (ux >= 0) & (ux < W);
+        uz >>= 1; uy >>= 1; ux >>= 1;
+      } else {
+        inb = (uz >= 0) & (uz < Di) & (uy >= 0) & (uy < Hi) & (ux >= 0) & (ux < Wi);
+      }
+      hdst[i] = W_LDS_BYTES + (gp * HS + slot_of(hz, hy, hx)) * 16;
+      if (inb) hsrc[i] = (int)(gp * Pin + ((int64_t)uz * Hi + uy) * Wi + ux);
+    }
+  }
+  uint4 hreg[A_PER_THREAD];
+  auto act_issue = [&](int cc) {
+    const uint4* cb = bptr + (int64_t)cc * (KG * 2) * Pin;  // scalar chunk base
+#pragma unroll
+    for (int i = 0; i < A_PER_THREAD; ++i) {
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (hsrc[i] >= 0) v = cb[hsrc[i]];
+      hreg[i] = v;
+    }
+  };
+  auto act_commit = [&]() {
+#pragma unroll
+    for (int i = 0; i < A_PER_THREAD; ++i)
+      if (hdst[i] >= 0) *(uint4*)(lds + hdst[i]) = hreg[i];
+  };
+
+  // ---- fragment addresses: one VGPR each, everything else is an immediate ------------------------
+  // weights  [KG][2][NT][8]: byte = ((ks*2+h)*2+part)*NT*16 + (wr*64 + rm*32 + j)*16 (+ buffer)
+  const int vA = (h * 2 * NT + wr * 64 + j) * 16;
+  // halo     [KG][2][HS][8]: byte = W_LDS_BYTES + ((ks*2+h)*2+part)*HS*16 + slot*16,
+  //          slot = zterm(z+dz) + (y+dy)*24 + (x+dx),  y = cm*4 + (j>>3), x = j&7, z = wc
+  const int laneB = W_LDS_BYTES + (h * 2 * HS + (j >> 3) * 24 + (j & 7)) * 16;
+  int vB[3];
+#pragma unroll
+  for (int dz = 0; dz < 3; ++dz) {
+    const int zz = wc + dz;
+    vB[dz] = laneB + ((zz >> 1) * (YH * 24) + (zz & 1) * 12) * 16;
+  }
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int rm = 0; rm < 2; ++rm)
+#pragma unroll
+    for (int cm = 0; cm < 2; ++cm)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[rm][cm][r] = 0.f;
+  // Pin the accumulators to the AccVGPR half of the register file: MFMA C/D traffic (4 KiB read + 4 KiB
+  // written per instruction) then stays off the architectural-VGPR ports that the LDS returns use.
+  if constexpr (ABL != 8) {
+#pragma unroll
+    for (int rm = 0; rm < 2; ++rm)
+#pragma unroll
+      for (int cm = 0; cm < 2; ++cm) asm volatile("" : "+a"(acc[rm][cm]));
+  }
+
+  // ---- prologue -------------------------------------------------------------------------------------
+  uint4 wreg0, wreg1;
+  {
+    wreg0 = wbase[tid]; wreg1 = wbase[tid + NTHREADS];
+    act_issue(0);
+    act_commit();
+    *(uint4*)(lds + tid * 16) = wreg0;
+    *(uint4*)(lds + (tid + NTHREADS) * 16) = wreg1;
+    if (nsteps > 1) { wreg0 = wbase[W_ITEMS + tid]; wreg1 = wbase[W_ITEMS + tid + NTHREADS]; }
+  }
+  __syncthreads();
+
+  // ---- main loop -----------------------------------------------------------------------------------------
+  // Each tap is two K=16 half-steps.  Fragment set F0 feeds the first half, F1 the second, and the one
+  // barrier of a tap sits BETWEEN the two MFMA groups:
+  //   read F1(s) | MFMA F0(s) | commit W(s+1), request W(s+2) | barrier | read F0(s+1) | MFMA F1(s)
+  // Every LDS read is issued a full MFMA group (12 MFMAs) before its first use, and right after the
+  // barrier the matrix pipe already has 12 register-resident MFMAs to run.
+  struct Frags { bf16x8 ahi[2], alo[2], bhi[2], blo[2]; };
+  Frags F0, F1;
+  if constexpr (ABL == 1) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        F0.ahi[i][e] = F0.alo[i][e] = F1.ahi[i][e] = F1.alo[i][e] = (short)(0x3f80 + lane + e);
+        F0.bhi[i][e] = F0.blo[i][e] = F1.bhi[i][e] = F1.blo[i][e] = (short)(0x3c00 + lane * 3 + e);
+      }
+  }
+#define MD_LOAD_FRAGS(F, PA, PB, KS)                                                         \
+  if constexpr (ABL != 1)                                                                    \
+  _Pragma("unroll") for (int rm = 0; rm < 2; ++rm) {                                         \
+    F.ahi[rm] = *(const bf16x8*)((PA) + (((KS) * 4 + 0) * NT + rm * 32) * 16);               \
+    F.alo[rm] = *(const bf16x8*)((PA) + (((KS) * 4 + 1) * NT + rm * 32) * 16);               \
+  }                                                                                          \
+  if constexpr (ABL != 1)                                                                    \
+  _Pragma("unroll") for (int cm = 0; cm < 2; ++cm) {                                         \
+    F.bhi[cm] = *(const bf16x8*)((PB) + (((KS) * 4 + 0) * HS + cm * 4 * 24) * 16);           \
+    F.blo[cm] = *(const bf16x8*)((PB) + (((KS) * 4 + 1) * HS + cm * 4 * 24) * 16);           \
+  }
+#define MD_MMA(F)                                                                                            \
+  _Pragma("unroll") for (int rm = 0; rm < 2; ++rm) _Pragma("unroll") for (int cm = 0; cm < 2; ++cm)          \
+    acc[rm][cm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.alo[rm], F.bhi[cm], acc[rm][cm], 0, 0, 0);       \
+  _Pragma("unroll") for (int rm = 0; rm < 2; ++rm) _Pragma("unroll") for (int cm = 0; cm < 2; ++cm)          \
+    acc[rm][cm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.ahi[rm], F.blo[cm], acc[rm][cm], 0, 0, 0);       \
+  _Pragma("unroll") for (int rm = 0; rm < 2; ++rm) _Pragma("unroll") for (int cm = 0; cm < 2; ++cm)          \
+    acc[rm][cm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.ahi[rm], F.bhi[cm], acc[rm][cm], 0, 0, 0);
+
+  // All wavefronts run the same code in step, so a block of 8 back-to-back ds_read_b128 per wave arrives at
+  // the LDS as a 64-instruction burst and every wave's (in-order) MFMA issue stalls behind its own queued
+  // reads: measured LDS time was purely additive to MFMA time.  Ask the scheduler for 3 MFMA : 2 DS-read
+  // groups so each read is issued in the shadow of the previous MFMA.
+#define MD_INTERLEAVE()                                                  \
+  if constexpr (ABL != 7) {                                              \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                   \
+      __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);                 \
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                 \
+    }                                                                    \
+  }
+  int cur = 0;                                       // byte offset of the weight buffer holding W(s)
+  int s = 0;
+  {
+    const unsigned char* pa = lds + vA;
+    const unsigned char* pb = lds + vB[0];
+    MD_LOAD_FRAGS(F0, pa, pb, 0)
+  }
+  // The loop body is branch-free (one scheduling region per half-step): past the end, weight tile
+  // indices and the prefetched chunk are clamped, so the redundant loads / LDS writes hit valid
+  // addresses and are simply never consumed.
+  const int last_tile = nsteps - 1;
+  for (int cc = 0; cc < ncc; ++cc) {
+    const int cpre = (cc + 1 < ncc) ? cc + 1 : cc;   // chunk whose halo is prefetched during this chunk
+#pragma unroll
+    for (int tap = 0; tap < TAPS; ++tap) {
+      const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
+      const int tn = (tap + 1) % TAPS;                 // next step's tap (same offsets in the next chunk)
+      const int ndz = tn / 9, ndy = (tn / 3) % 3, ndx = tn % 3;
+      const int nxt = cur ^ (W_ITEMS * 16);
+      {
+        const unsigned char* pa = lds + cur + vA;
+        const unsigned char* pb = lds + vB[dz] + (dy * 24 + dx) * 16;
+        MD_LOAD_FRAGS(F1, pa, pb, 1)
+      }
+      MD_MMA(F0)
+      MD_INTERLEAVE()
+      if constexpr (ABL != 3) {  // W(s+1): registers -> LDS (the other buffer; its last readers passed a barrier)
+        *(uint4*)(lds + nxt + tid * 16) = wreg0;
+        *(uint4*)(lds + nxt + (tid + NTHREADS) * 16) = wreg1;
+      }
+      if constexpr (ABL != 4) {
+        const int ts = (s + 2 < last_tile) ? s + 2 : last_tile;
+        const uint4* wt = wbase + (int64_t)ts * W_ITEMS;
+        wreg0 = wt[tid]; wreg1 = wt[tid + NTHREADS];
+      }
+      if (tap == PF_TAP) act_issue(cpre);
+      if (tap == TAPS - 1) {
+        __syncthreads();  // every wave has issued and completed its reads of this chunk's halo tile
+        act_commit();
+      }
+      if constexpr (ABL != 3 && ABL != 6) __syncthreads();
+      {
+        const unsigned char* pa = lds + nxt + vA;
+        const unsigned char* pb = lds + vB[ndz] + (ndy * 24 + ndx) * 16;
+        MD_LOAD_FRAGS(F0, pa, pb, 0)
+      }
+      MD_MMA(F1)
+      MD_INTERLEAVE()
+      cur = nxt;
+      ++s;
+    }
+  }
+#undef MD_LOAD_FRAGS
+#undef MD_MMA
+#undef MD_INTERLEAVE
+
+  // ---- epilogue: bias + residual loads batched, 16-byte stores into the F32B layout -------------------
+  const float alpha = A.alpha;
+  const int rows = A.rows, rows_alloc = A.rows_alloc;
+  const int rg_alloc = rows_alloc / 8;
+  float* outp = (float*)A.out + (int64_t)b * rg_alloc * P * 8;
+  const float* resp = A.residual ? A.residual + (int64_t)b * A.res_bstride : nullptr;
+  const float* biasp = A.bias ? A.bias + (int64_t)b * A.bias_bstride : nullptr;
+  f32x4 bv[2][4];
+#pragma unroll
+  for (int rm = 0; rm < 2; ++rm)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int row = rt * NT + wr * 64 + rm * 32 + 8 * q + 4 * h;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (biasp != nullptr) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (row + e < rows) v[e] = biasp[row + e];
+      }
+      bv[rm][q] = v;
+    }
+#pragma unroll
+  for (int cm = 0; cm < 2; ++cm) {
+    const int y = cm * 4 + (j >> 3), x = j & 7;
+    const int64_t gp = ((int64_t)(z0 + wc) * H + (y0 + y)) * W + (x0 + x);
+    f32x4 rv[2][4];
+#pragma unroll
+    for (int rm = 0; rm < 2; ++rm)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int row = rt * NT + wr * 64 + rm * 32 + 8 * q + 4 * h;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (resp != nullptr && row < rows_alloc) v = *(const f32x4*)(resp + ((int64_t)(row >> 3) * P + gp) * 8 + (row & 7));
+        rv[rm][q] = v;
+      }
+#pragma unroll
+    for (int rm = 0; rm < 2; ++rm)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int row = rt * NT + wr * 64 + rm * 32 + 8 * q + 4 * h;
+        if (row >= rows_alloc) continue;
+        f32x4 o4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          // same association as the generic kernel: (alpha*acc + bias) + residual
+          float v = alpha * acc[rm][cm][q * 4 + e];
+          v += bv[rm][q][e];
+          v += rv[rm][q][e];
+          o4[e] = v;
+        }
+        *(f32x4*)(outp + ((int64_t)(row >> 3) * P + gp) * 8 + (row & 7)) = o4;
+      }
+  }
+}
+
+// launched from gemm_conv.hip (MD_CFG_C3_128_FAST)
+int md_launch_conv3_main(const MdGemmConvArgs& a, hipStream_t stream) {
+  if (a.kdim % KC != 0 || a.kdim <= 0 || a.rows <= 0 || a.rows_alloc % 8 != 0 || a.batch <= 0) return MD_ERR_BAD_ARG;
+  if (a.D % TZ || a.H % TY || a.W % TX) return MD_ERR_BAD_ARG;
+  if (a.ups && ((a.D | a.H | a.W) & 1)) return MD_ERR_BAD_ARG;
+  if (a.a_src != MD_A_PACKED || a.out_mode != MD_OUT_F32B) return MD_ERR_UNSUPPORTED;
+  const int tiles = (a.D / TZ) * (a.H / TY) * (a.W / TX);
+  dim3 grid((unsigned)(tiles * a.batch), (unsigned)((a.rows + NT - 1) / NT), 1);
+  MD_HIP_CLEAR_ERROR();
+  switch (a.cfg) {
+    case 111: hipLaunchKernelGGL(md_conv3_main_kernel<1>, grid, dim3(NTHREADS), 0, stream, a); break;
+    case 113: hipLaunchKernelGGL(md_conv3_main_kernel<3>, grid, dim3(NTHREADS), 0, stream, a); break;
+    case 114: hipLaunchKernelGGL(md_conv3_main_kernel<4>, grid, dim3(NTHREADS), 0, stream, a); break;
+    case 116: hipLaunchKernelGGL(md_conv3_main_kernel<6>, grid, dim3(NTHREADS), 0, stream, a); break;
+    case 117: hipLaunchKernelGGL(md_conv3_main_kernel<7>, grid, dim3(NTHREADS), 0, stream, a); break;
+    case 118: hipLaunchKernelGGL(md_conv3_main_kernel<8>, grid, dim3(NTHREADS), 0, stream, a); break;
+    default: hipLaunchKernelGGL(md_conv3_main_kernel<0>, grid, dim3(NTHREADS), 0, stream, a); break;
+  }
+  MD_HIP_CHECK_LAUNCH();
+  return MD_OK;
+}

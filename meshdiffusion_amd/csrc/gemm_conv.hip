@@ -19,10 +19,13 @@
 //   i.e. one 16-byte store into the 8-channel blocked F32B layout.
 #include "md_common.h"
 
-template <int NT_, int KC_, int TZ_, int TY_, int TX_, int TAPS_, int STRIDE_, int WR_, int WC_>
+template <int NT_, int KC_, int TZ_, int TY_, int TX_, int TAPS_, int STRIDE_, int WR_, int WC_,
+          int SW_ = 0, int PIPE_ = 0, int ABL_ = 0>
 struct GCfg {
+  static constexpr int ABL = ABL_;  // timing-only ablations (results invalid): 1 no LDS frag reads, 2 no MFMA,
+                                    // 3 no barriers/weight commits, 4 no weight global loads
   static constexpr int NT = NT_, KC = KC_, TZ = TZ_, TY = TY_, TX = TX_, TAPS = TAPS_,
-                       STRIDE = STRIDE_, WR = WR_, WC = WC_;
+                       STRIDE = STRIDE_, WR = WR_, WC = WC_, SW = SW_, PIPE = PIPE_;
   static constexpr int MT = TZ * TY * TX;
   static constexpr int NW = WR * WC;
   static constexpr int NTHREADS = NW * 64;
@@ -32,25 +35,35 @@ struct GCfg {
   static constexpr int YH = (TAPS == 27) ? (TY - 1) * STRIDE + 3 : 1;
   static constexpr int XH = (TAPS == 27) ? (TX - 1) * STRIDE + 3 : MT;
   static constexpr int XHP = XH;
-  static constexpr int HS = ZH * YH * XHP;  // halo slots
+  // SW=1 (tile x-extent 8, stride 1): y-rows are 24 slots apart with odd z-planes interleaved at +12,
+  // so a 32-position fragment (8 x by 4 y) touches every 16-byte LDS slot class exactly twice, once
+  // per ds_read_b128 lane group => conflict free for every tap (24 = 8 mod 16).
+  static constexpr int HS = (SW == 1) ? ((ZH + 1) / 2) * YH * 24 : ZH * YH * XHP;  // halo slots
+  static constexpr int HPOS = ZH * YH * XH;                                          // valid halo positions
+  static __device__ __forceinline__ int slot_of(int hz, int hy, int hx) {
+    if constexpr (SW == 1) return (hz >> 1) * (YH * 24) + hy * 24 + (hz & 1) * 12 + hx;
+    else return (hz * YH + hy) * XHP + hx;
+  }
   static constexpr int KG = KC / 8;         // 8-channel groups per K chunk
   static constexpr int W_ITEMS = KG * 2 * NT;  // uint4 items of one weight tile
-  static constexpr int A_ITEMS = KG * 2 * HS;  // uint4 items of the activation halo tile
+  static constexpr int A_ITEMS = KG * 2 * HPOS;  // uint4 items loaded per activation halo tile
   static constexpr int W_PER_THREAD = (W_ITEMS + NTHREADS - 1) / NTHREADS;
   static constexpr int A_PER_THREAD = (A_ITEMS + NTHREADS - 1) / NTHREADS;
-  static constexpr int LDS_ITEMS = 2 * W_ITEMS + A_ITEMS;
+  static constexpr int W_LDS_ITEMS = (PIPE_ == 2) ? 0 : 2 * W_ITEMS;  // PIPE=2 keeps weights out of LDS
+  static constexpr int LDS_ITEMS = W_LDS_ITEMS + KG * 2 * HS;
   static constexpr int LDS_BYTES = LDS_ITEMS * 16;
   static constexpr int PADLO = (STRIDE == 2) ? 0 : 1;
   static_assert(RM >= 1 && CM >= 1, "tile too small for the wave grid");
   static_assert(NT % (32 * WR) == 0 && MT % (32 * WC) == 0, "tile / wave grid mismatch");
   static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+  static_assert(SW == 0 || (TAPS == 27 && STRIDE == 1 && TX == 8), "SW=1 layout is for x-extent 8, stride 1");
 };
 
 template <class C>
 __global__ __launch_bounds__(C::NTHREADS) void md_gemm_conv_kernel(const MdGemmConvArgs A) {
   __shared__ __attribute__((aligned(16))) uint4 smem[C::LDS_ITEMS];
   uint4* wl = smem;                   // [2][KG*2][NT]
-  uint4* al = smem + 2 * C::W_ITEMS;  // [KG*2][HS]
+  uint4* al = smem + C::W_LDS_ITEMS;  // [KG*2][HS]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -71,8 +84,12 @@ __global__ __launch_bounds__(C::NTHREADS) void md_gemm_conv_kernel(const MdGemmC
   } else {
     tiles = W / C::MT;
   }
-  const int b = blockIdx.x / tiles;
-  const int t = blockIdx.x % tiles;
+  // XCD-aware block order: workgroup b runs on XCD b % 8, so give each XCD one contiguous run of
+  // tiles (neighbouring tiles share halos, every tile shares the weights) to keep re-reads in its L2.
+  int bid = blockIdx.x;
+  if ((gridDim.x & 7) == 0) bid = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  const int b = bid / tiles;
+  const int t = bid % tiles;
   if constexpr (C::TAPS == 27) {
     const int ntx = W / C::TX, nty = H / C::TY;
     x0 = (t % ntx) * C::TX;
@@ -92,15 +109,14 @@ __global__ __launch_bounds__(C::NTHREADS) void md_gemm_conv_kernel(const MdGemmC
   int a_row[C::RM];
 #pragma unroll
   for (int rm = 0; rm < C::RM; ++rm) a_row[rm] = (wr * C::RM + rm) * 32 + j;
-  int b_slot[C::CM];
+  int bz[C::CM], by[C::CM], bx[C::CM];  // halo coordinates (tap 0) of this lane's column in each col tile
 #pragma unroll
   for (int cm = 0; cm < C::CM; ++cm) {
     const int p = (wc * C::CM + cm) * 32 + j;
     if constexpr (C::TAPS == 27) {
-      const int x = p % C::TX, y = (p / C::TX) % C::TY, z = p / (C::TX * C::TY);
-      b_slot[cm] = ((z * C::STRIDE) * C::YH + y * C::STRIDE) * C::XHP + x * C::STRIDE;
+      bx[cm] = (p % C::TX) * C::STRIDE; by[cm] = ((p / C::TX) % C::TY) * C::STRIDE; bz[cm] = (p / (C::TX * C::TY)) * C::STRIDE;
     } else {
-      b_slot[cm] = p;
+      bx[cm] = p; by[cm] = 0; bz[cm] = 0;
     }
   }
 
@@ -140,17 +156,19 @@ __global__ __launch_bounds__(C::NTHREADS) void md_gemm_conv_kernel(const MdGemmC
     }
   };
 
-  // ---- activation halo tile: global -> LDS (zero fill outside the grid) ----
-  auto act_load = [&](int cc) {
+  // ---- activation halo tile: global -> registers -> LDS (zero fill outside the grid) ----
+  uint4 hreg[C::A_PER_THREAD];
+  auto act_issue = [&](int cc) {
 #pragma unroll
     for (int i = 0; i < C::A_PER_THREAD; ++i) {
       const int item = tid + i * C::NTHREADS;
+      uint4 v = make_uint4(0, 0, 0, 0);
       if (item < C::A_ITEMS) {
-        const int gp = item / C::HS, slot = item % C::HS;
+        const int gp = item / C::HPOS, r = item % C::HPOS;
         int64_t src;
         bool inb = true;
         if constexpr (C::TAPS == 27) {
-          const int hx = slot % C::XHP, hy = (slot / C::XHP) % C::YH, hz = slot / (C::XHP * C::YH);
+          const int hx = r % C::XH, hy = (r / C::XH) % C::YH, hz = r / (C::XH * C::YH);
           int uz = z0 * C::STRIDE + hz - C::PADLO;
           int uy = y0 * C::STRIDE + hy - C::PADLO;
           int ux = x0 * C::STRIDE + hx - C::PADLO;
@@ -160,14 +178,24 @@ __global__ __launch_bounds__(C::NTHREADS) void md_gemm_conv_kernel(const MdGemmC
           } else {
             inb = (uz >= 0) & (uz < Di) & (uy >= 0) & (uy < Hi) & (ux >= 0) & (ux < Wi);
           }
-          if (C::XHP != C::XH) inb = inb & (hx < C::XH);
           src = ((int64_t)uz * Hi + uy) * Wi + ux;
         } else {
-          src = (int64_t)t * C::MT + slot;
+          src = (int64_t)t * C::MT + r;
         }
-        uint4 v = make_uint4(0, 0, 0, 0);
         if (inb) v = bptr[((int64_t)(cc * C::KG + (gp >> 1)) * 2 + (gp & 1)) * Pin + src];
-        al[item] = v;
+      }
+      hreg[i] = v;
+    }
+  };
+  auto act_commit = [&]() {
+#pragma unroll
+    for (int i = 0; i < C::A_PER_THREAD; ++i) {
+      const int item = tid + i * C::NTHREADS;
+      if (item < C::A_ITEMS) {
+        const int gp = item / C::HPOS, r = item % C::HPOS;
+        int slot = r;
+        if constexpr (C::TAPS == 27) slot = C::slot_of(r / (C::XH * C::YH), (r / C::XH) % C::YH, r % C::XH);
+        al[gp * C::HS + slot] = hreg[i];
       }
     }
   };
@@ -175,52 +203,249 @@ __global__ __launch_bounds__(C::NTHREADS) void md_gemm_conv_kernel(const MdGemmC
   const bf16x8* wlf = (const bf16x8*)wl;
   const bf16x8* alf = (const bf16x8*)al;
 
-  // ---- main loop over (K chunk, tap) ---------------------------------------
-  int cc = 0, tap = 0, dz = 0, dy = 0, dx = 0;
-  w_issue(0, 0);
-  for (int s = 0; s < nsteps; ++s) {
-    if (tap == 0) {
-      __syncthreads();  // everyone finished reading the previous halo tile
-      act_load(cc);
-    }
-    const int buf = s & 1;
-    w_commit(buf);
-    __syncthreads();
-    // next step's coordinates + its weight loads go in flight behind the MFMAs
-    int ncc_ = cc, ntap = tap + 1, ndz = dz, ndy = dy, ndx = dx + 1;
-    if constexpr (C::TAPS == 27) {
-      if (ndx == 3) { ndx = 0; ++ndy; }
-      if (ndy == 3) { ndy = 0; ++ndz; }
-    }
-    if (ntap == C::TAPS) { ntap = 0; ndz = ndy = ndx = 0; ++ncc_; }
-    if (s + 1 < nsteps) w_issue(ncc_, ntap);
-
-    const int toff = (C::TAPS == 27) ? (dz * C::YH + dy) * C::XHP + dx : 0;
+  // ---- one (K chunk, tap) step of MFMAs ----------------------------------------
+  bf16x8 abl_a[C::RM], abl_b[C::CM];  // ABL==1 only
+  if constexpr (C::ABL == 1 || C::ABL == 5) {
+#pragma unroll
+    for (int rm = 0; rm < C::RM; ++rm)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) abl_a[rm][e] = (short)(0x3f80 + lane + e);
+#pragma unroll
+    for (int cm = 0; cm < C::CM; ++cm)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) abl_b[cm][e] = (short)(0x3c00 + lane * 3 + e);
+  }
+  auto compute = [&](int buf, int dz, int dy, int dx) {
     const bf16x8* wb = wlf + buf * C::W_ITEMS;
+    int bs[C::CM];
+#pragma unroll
+    for (int cm = 0; cm < C::CM; ++cm) bs[cm] = C::slot_of(bz[cm] + dz, by[cm] + dy, bx[cm] + dx);
 #pragma unroll
     for (int ks = 0; ks < C::KC / 16; ++ks) {
       const int g = ks * 2 + h;
       bf16x8 ahi[C::RM], alo[C::RM], bhi[C::CM], blo[C::CM];
 #pragma unroll
       for (int rm = 0; rm < C::RM; ++rm) {
-        ahi[rm] = wb[(g * 2 + 0) * C::NT + a_row[rm]];
-        alo[rm] = wb[(g * 2 + 1) * C::NT + a_row[rm]];
+        if constexpr (C::ABL == 1 || C::ABL == 5) { ahi[rm] = abl_a[rm]; alo[rm] = abl_a[rm]; }
+        else {
+          ahi[rm] = wb[(g * 2 + 0) * C::NT + a_row[rm]];
+          alo[rm] = wb[(g * 2 + 1) * C::NT + a_row[rm]];
+        }
       }
 #pragma unroll
       for (int cm = 0; cm < C::CM; ++cm) {
-        bhi[cm] = alf[(g * 2 + 0) * C::HS + b_slot[cm] + toff];
-        blo[cm] = alf[(g * 2 + 1) * C::HS + b_slot[cm] + toff];
+        if constexpr (C::ABL == 1 || C::ABL == 5) { bhi[cm] = abl_b[cm]; blo[cm] = abl_b[cm]; }
+        else {
+          bhi[cm] = alf[(g * 2 + 0) * C::HS + bs[cm]];
+          blo[cm] = alf[(g * 2 + 1) * C::HS + bs[cm]];
+        }
       }
+      if constexpr (C::ABL == 2) {
+#pragma unroll
+        for (int rm = 0; rm < C::RM; ++rm) { asm volatile("" ::"v"(ahi[rm]), "v"(alo[rm])); }
+#pragma unroll
+        for (int cm = 0; cm < C::CM; ++cm) { asm volatile("" ::"v"(bhi[cm]), "v"(blo[cm])); }
+      } else {
+#pragma unroll
+        for (int rm = 0; rm < C::RM; ++rm)
+#pragma unroll
+          for (int cm = 0; cm < C::CM; ++cm) {
+            acc[rm][cm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo[rm], bhi[cm], acc[rm][cm], 0, 0, 0);
+            acc[rm][cm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[rm], blo[cm], acc[rm][cm], 0, 0, 0);
+            acc[rm][cm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[rm], bhi[cm], acc[rm][cm], 0, 0, 0);
+          }
+      }
+    }
+  };
+  auto advance = [&](int& cc, int& tap, int& dz, int& dy, int& dx) {
+    ++tap; ++dx;
+    if constexpr (C::TAPS == 27) {
+      if (dx == 3) { dx = 0; ++dy; }
+      if (dy == 3) { dy = 0; ++dz; }
+    }
+    if (tap == C::TAPS) { tap = 0; dz = dy = dx = 0; ++cc; }
+  };
+
+  // ---- main loop over (K chunk, tap) ---------------------------------------
+  int cc = 0, tap = 0, dz = 0, dy = 0, dx = 0;
+  if constexpr (C::PIPE == 0) {
+    w_issue(0, 0);
+    for (int s = 0; s < nsteps; ++s) {
+      if (tap == 0) {
+        __syncthreads();  // everyone finished reading the previous halo tile
+        act_issue(cc);
+        act_commit();
+      }
+      const int buf = s & 1;
+      w_commit(buf);
+      __syncthreads();
+      int ncc_ = cc, ntap = tap, ndz = dz, ndy = dy, ndx = dx;
+      advance(ncc_, ntap, ndz, ndy, ndx);
+      if (s + 1 < nsteps) w_issue(ncc_, ntap);  // next step's weights fly behind the MFMAs
+      compute(buf, dz, dy, dx);
+      cc = ncc_; tap = ntap; dz = ndz; dy = ndy; dx = ndx;
+    }
+  } else if constexpr (C::PIPE == 3) {
+    // Mid-step barrier pipeline (KC = 32 = two K=16 half-steps per tap).  Fragment set F0 serves the
+    // first half-step, F1 the second.  The single barrier of a step sits BETWEEN the two MFMA groups:
+    //   read F1(s)  | MFMA F0(s) | commit W(s+1), request W(s+2) | barrier | read F0(s+1) | MFMA F1(s)
+    // so every LDS read is issued one MFMA group (12 MFMAs ~ 400-800 cycles) before its first use and
+    // no LDS latency is exposed behind the barrier.
+    static_assert(C::KC == 32, "PIPE=3 needs two K=16 half-steps per step");
+    struct Frags { bf16x8 ahi[C::RM], alo[C::RM], bhi[C::CM], blo[C::CM]; };
+    Frags F0, F1;
+    auto load_frags = [&](Frags& F, int buf, int ks, int dz_, int dy_, int dx_) {
+      const bf16x8* wb = wlf + buf * C::W_ITEMS;
+      const int g = ks * 2 + h;
+#pragma unroll
+      for (int rm = 0; rm < C::RM; ++rm) {
+        F.ahi[rm] = wb[(g * 2 + 0) * C::NT + a_row[rm]];
+        F.alo[rm] = wb[(g * 2 + 1) * C::NT + a_row[rm]];
+      }
+#pragma unroll
+      for (int cm = 0; cm < C::CM; ++cm) {
+        const int bs = C::slot_of(bz[cm] + dz_, by[cm] + dy_, bx[cm] + dx_);
+        F.bhi[cm] = alf[(g * 2 + 0) * C::HS + bs];
+        F.blo[cm] = alf[(g * 2 + 1) * C::HS + bs];
+      }
+    };
+    auto mma = [&](const Frags& F) {
 #pragma unroll
       for (int rm = 0; rm < C::RM; ++rm)
 #pragma unroll
         for (int cm = 0; cm < C::CM; ++cm) {
-          acc[rm][cm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo[rm], bhi[cm], acc[rm][cm], 0, 0, 0);
-          acc[rm][cm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[rm], blo[cm], acc[rm][cm], 0, 0, 0);
-          acc[rm][cm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[rm], bhi[cm], acc[rm][cm], 0, 0, 0);
+          acc[rm][cm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.alo[rm], F.bhi[cm], acc[rm][cm], 0, 0, 0);
+          acc[rm][cm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.ahi[rm], F.blo[cm], acc[rm][cm], 0, 0, 0);
+          acc[rm][cm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.ahi[rm], F.bhi[cm], acc[rm][cm], 0, 0, 0);
         }
+    };
+    constexpr int PF = (C::TAPS >= 3) ? C::TAPS - 3 : 0;
+    int c1 = 0, t1 = 0, z1 = 0, y1 = 0, x1 = 0;  // coordinates of step s+2 (for w_issue)
+    w_issue(0, 0);
+    act_issue(0);
+    act_commit();
+    w_commit(0);
+    advance(c1, t1, z1, y1, x1);
+    if (nsteps > 1) w_issue(c1, t1);
+    advance(c1, t1, z1, y1, x1);
+    __syncthreads();
+    load_frags(F0, 0, 0, 0, 0, 0);
+    for (int s = 0; s < nsteps; ++s) {
+      load_frags(F1, s & 1, 1, dz, dy, dx);
+      mma(F0);
+      if (s + 1 < nsteps) w_commit((s + 1) & 1);
+      if (s + 2 < nsteps) w_issue(c1, t1);
+      advance(c1, t1, z1, y1, x1);
+      const bool more = cc + 1 < ncc;
+      if (tap == PF && more) act_issue(cc + 1);
+      if (tap == C::TAPS - 1 && more) {
+        __syncthreads();  // every wave has finished reading this chunk's halo tile
+        act_commit();
+      }
+      __syncthreads();
+      advance(cc, tap, dz, dy, dx);
+      if (s + 1 < nsteps) load_frags(F0, (s + 1) & 1, 0, dz, dy, dx);
+      mma(F1);
     }
-    cc = ncc_; tap = ntap; dz = ndz; dy = ndy; dx = ndx;
+  } else if constexpr (C::PIPE == 2) {
+    // Weight fragments go L2 -> registers directly (the WPK tile is already in fragment order: lanes
+    // 0-31 / 32-63 each read 512 contiguous bytes), one step ahead of their use; only the activation
+    // halo tile lives in LDS.  No per-tap barrier: wavefronts free-run through the 27 taps of a K chunk
+    // and meet only when the halo tile is swapped, so the two wavefronts of a SIMD drift out of phase
+    // and keep the matrix pipe fed while the partner waits on LDS.
+    constexpr int KS = C::KC / 16;
+    constexpr int PF = (C::TAPS >= 3) ? C::TAPS - 3 : 0;
+    bf16x8 fa0[C::RM][KS][2], fa1[C::RM][KS][2];
+    auto a_issue = [&](bf16x8 (&af)[C::RM][KS][2], int cc_, int tap_) {
+      const bf16x8* tile = (const bf16x8*)(aptr + ((int64_t)(rt * ncc + cc_) * C::TAPS + tap_) * C::W_ITEMS);
+#pragma unroll
+      for (int rm = 0; rm < C::RM; ++rm)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+          for (int part = 0; part < 2; ++part)
+            af[rm][ks][part] = tile[((ks * 2 + h) * 2 + part) * C::NT + a_row[rm]];
+    };
+    auto mma = [&](bf16x8 (&af)[C::RM][KS][2], int dz_, int dy_, int dx_) {
+      int bs[C::CM];
+#pragma unroll
+      for (int cm = 0; cm < C::CM; ++cm) bs[cm] = C::slot_of(bz[cm] + dz_, by[cm] + dy_, bx[cm] + dx_);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const int g = ks * 2 + h;
+        bf16x8 bhi[C::CM], blo[C::CM];
+#pragma unroll
+        for (int cm = 0; cm < C::CM; ++cm) {
+          bhi[cm] = alf[(g * 2 + 0) * C::HS + bs[cm]];
+          blo[cm] = alf[(g * 2 + 1) * C::HS + bs[cm]];
+        }
+#pragma unroll
+        for (int rm = 0; rm < C::RM; ++rm) {
+#pragma unroll
+          for (int cm = 0; cm < C::CM; ++cm)
+            acc[rm][cm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[rm][ks][1], bhi[cm], acc[rm][cm], 0, 0, 0);
+#pragma unroll
+          for (int cm = 0; cm < C::CM; ++cm)
+            acc[rm][cm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[rm][ks][0], blo[cm], acc[rm][cm], 0, 0, 0);
+#pragma unroll
+          for (int cm = 0; cm < C::CM; ++cm)
+            acc[rm][cm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[rm][ks][0], bhi[cm], acc[rm][cm], 0, 0, 0);
+        }
+      }
+    };
+    int s = 0;
+    auto step = [&](bf16x8 (&use)[C::RM][KS][2], bf16x8 (&nxt)[C::RM][KS][2]) {
+      int ncc_ = cc, ntap = tap, ndz = dz, ndy = dy, ndx = dx;
+      advance(ncc_, ntap, ndz, ndy, ndx);
+      if (s + 1 < nsteps) a_issue(nxt, ncc_, ntap);
+      const bool more = cc + 1 < ncc;
+      if (tap == PF && more) act_issue(cc + 1);
+      mma(use, dz, dy, dx);
+      if (tap == C::TAPS - 1 && more) {
+        __syncthreads();  // everyone finished reading this chunk's halo tile
+        act_commit();
+        __syncthreads();
+      }
+      cc = ncc_; tap = ntap; dz = ndz; dy = ndy; dx = ndx;
+      ++s;
+    };
+    a_issue(fa0, 0, 0);
+    act_issue(0);
+    act_commit();
+    __syncthreads();
+    while (s < nsteps) {
+      step(fa0, fa1);
+      if (s >= nsteps) break;
+      step(fa1, fa0);
+    }
+  } else {
+    // Software pipeline: W(s+1) is written to LDS and W(s+2) is requested from L2 *inside* step s,
+    // the next K-chunk's halo tile is requested 3 taps early into registers, and there is exactly
+    // one barrier per step (two at a chunk switch).
+    constexpr int PF = (C::TAPS >= 3) ? C::TAPS - 3 : 0;
+    int c1 = 0, t1 = 0, z1 = 0, y1 = 0, x1 = 0;  // coordinates of step s+2 (for w_issue)
+    w_issue(0, 0);
+    act_issue(0);
+    act_commit();
+    w_commit(0);
+    advance(c1, t1, z1, y1, x1);
+    if (nsteps > 1) w_issue(c1, t1);
+    advance(c1, t1, z1, y1, x1);
+    __syncthreads();
+    for (int s = 0; s < nsteps; ++s) {
+      if (C::ABL != 3 && C::ABL != 5 && s + 1 < nsteps) w_commit((s + 1) & 1);
+      if (C::ABL != 4 && C::ABL != 5 && s + 2 < nsteps) w_issue(c1, t1);
+      advance(c1, t1, z1, y1, x1);
+      const bool more = cc + 1 < ncc;
+      if (C::ABL != 5 && tap == PF && more) act_issue(cc + 1);
+      compute(s & 1, dz, dy, dx);
+      if (C::ABL != 5 && tap == C::TAPS - 1 && more) {
+        __syncthreads();  // everyone finished reading this chunk's halo tile
+        act_commit();
+      }
+      if constexpr (C::ABL != 3 && C::ABL != 5) __syncthreads();
+      advance(cc, tap, dz, dy, dx);
+    }
   }
 
   // ---- epilogue --------------------------------------------------------------
@@ -281,6 +506,17 @@ __global__ __launch_bounds__(C::NTHREADS) void md_gemm_conv_kernel(const MdGemmC
 
 // ------------------------------------------------------------------------------
 using Cfg_C3_128 = GCfg<128, 32, 4, 8, 8, 27, 1, 2, 4>;
+using Cfg_C3_128_V2 = GCfg<128, 32, 4, 8, 8, 27, 1, 2, 4, 1, 1>;
+using Cfg_C3_128_SW = GCfg<128, 32, 4, 8, 8, 27, 1, 2, 4, 1, 0>;
+using Cfg_C3_128_PIPE = GCfg<128, 32, 4, 8, 8, 27, 1, 2, 4, 0, 1>;
+using Cfg_C3_128_V3 = GCfg<128, 32, 4, 8, 8, 27, 1, 4, 2, 1, 2>;   // weights L2->registers, no per-tap barrier
+using Cfg_C3_128_V3B = GCfg<128, 32, 4, 8, 8, 27, 1, 2, 4, 1, 2>;  // same with the 2x4 wave grid
+using Cfg_C3_128_V4 = GCfg<128, 32, 4, 8, 8, 27, 1, 2, 4, 1, 3>;   // mid-step barrier pipeline
+using Cfg_ABL1 = GCfg<128, 32, 4, 8, 8, 27, 1, 2, 4, 1, 1, 1>;
+using Cfg_ABL2 = GCfg<128, 32, 4, 8, 8, 27, 1, 2, 4, 1, 1, 2>;
+using Cfg_ABL3 = GCfg<128, 32, 4, 8, 8, 27, 1, 2, 4, 1, 1, 3>;
+using Cfg_ABL4 = GCfg<128, 32, 4, 8, 8, 27, 1, 2, 4, 1, 1, 4>;
+using Cfg_ABL5 = GCfg<128, 32, 4, 8, 8, 27, 1, 2, 4, 1, 1, 5>;
 using Cfg_C3_128_K16 = GCfg<128, 16, 4, 8, 8, 27, 1, 2, 4>;
 using Cfg_C3_32 = GCfg<32, 32, 4, 8, 8, 27, 1, 1, 8>;
 using Cfg_C3_LOW = GCfg<128, 32, 4, 4, 4, 27, 1, 4, 2>;
@@ -304,6 +540,7 @@ static int launch_cfg(const MdGemmConvArgs& a, hipStream_t stream) {
     tiles = a.W / C::MT;
   }
   if (a.a_src == MD_A_S16B && a.a_rows <= 0) return MD_ERR_BAD_ARG;
+  if (C::PIPE == 2 && a.a_src != MD_A_PACKED) return MD_ERR_UNSUPPORTED;
   const int row_tiles = (a.rows + C::NT - 1) / C::NT;
   dim3 grid((unsigned)(tiles * a.batch), (unsigned)row_tiles, 1);
   MD_HIP_CLEAR_ERROR();
@@ -332,20 +569,35 @@ static void cfg_info(int32_t* nt, int32_t* kc, int32_t* cols, int32_t* taps, int
     case MD_CFG_G1_128: F<Cfg_G1_128>(__VA_ARGS__); break;          \
     case MD_CFG_G1_128_LOW: F<Cfg_G1_128_LOW>(__VA_ARGS__); break;  \
     case MD_CFG_G1_64_LOW: F<Cfg_G1_64_LOW>(__VA_ARGS__); break;    \
+    case MD_CFG_C3_128_V2: F<Cfg_C3_128_V2>(__VA_ARGS__); break;    \
+    case MD_CFG_C3_128_SW: F<Cfg_C3_128_SW>(__VA_ARGS__); break;    \
+    case MD_CFG_C3_128_PIPE: F<Cfg_C3_128_PIPE>(__VA_ARGS__); break; \
+    case MD_CFG_C3_128_V3: F<Cfg_C3_128_V3>(__VA_ARGS__); break; \
+    case MD_CFG_C3_128_V3B: F<Cfg_C3_128_V3B>(__VA_ARGS__); break; \
+    case MD_CFG_C3_128_V4: F<Cfg_C3_128_V4>(__VA_ARGS__); break; \
+    case 101: F<Cfg_ABL1>(__VA_ARGS__); break; \
+    case 102: F<Cfg_ABL2>(__VA_ARGS__); break; \
+    case 103: F<Cfg_ABL3>(__VA_ARGS__); break; \
+    case 104: F<Cfg_ABL4>(__VA_ARGS__); break; \
+    case 105: F<Cfg_ABL5>(__VA_ARGS__); break; \
     default: return MD_ERR_UNSUPPORTED;                             \
   }
+
+int md_launch_conv3_main(const MdGemmConvArgs& a, hipStream_t stream);  // conv3_main.hip
 
 extern "C" int md_gemm_conv(const MdGemmConvArgs* args, void* stream) {
   if (args == nullptr || args->a == nullptr || args->b == nullptr || args->out == nullptr)
     return MD_ERR_BAD_ARG;
   int rc = MD_OK;
   hipStream_t st = (hipStream_t)stream;
+  if (args->cfg == MD_CFG_C3_128_FAST || (args->cfg >= 111 && args->cfg <= 118)) return md_launch_conv3_main(*args, st);
   MD_CFG_SWITCH(args->cfg, rc = launch_cfg, *args, st);
   return rc;
 }
 
 extern "C" int md_gemm_conv_cfg_info(int32_t cfg, int32_t* nt, int32_t* kc, int32_t* cols,
                                      int32_t* taps, int32_t* lds_bytes, int32_t* threads) {
+  if (cfg == MD_CFG_C3_128_FAST || (cfg >= 111 && cfg <= 118)) cfg = MD_CFG_C3_128_V2;  // same tile geometry and LDS image
   MD_CFG_SWITCH(cfg, cfg_info, nt, kc, cols, taps, lds_bytes, threads);
   return MD_OK;
 }

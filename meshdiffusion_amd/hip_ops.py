@@ -9,11 +9,13 @@ import math
 import torch
 
 from . import _lib
-from ._lib import (A_PACKED, A_S16B, CFG_C3_128, CFG_C3_128_K16, CFG_C3_32, CFG_C3_LOW, CFG_C3_S2,
+from ._lib import (A_PACKED, A_S16B, CFG_C3_128, CFG_C3_128_V2, CFG_C3_128_SW, CFG_C3_128_PIPE, CFG_C3_128_V3, CFG_C3_128_V3B, CFG_C3_128_V4, CFG_C3_128_FAST, CFG_C3_128_K16, CFG_C3_32, CFG_C3_LOW, CFG_C3_S2,
                    CFG_G1_128, CFG_G1_128_LOW, CFG_G1_64_LOW, CFG_NT_KC, OUT_F32B, OUT_NCDHW, OUT_S16B,
                    MdGemmConvArgs, check)
 
 
+CFG_ABL1, CFG_ABL2, CFG_ABL3, CFG_ABL4, CFG_ABL5 = 101, 102, 103, 104, 105
+CFG_F1, CFG_F3, CFG_F4, CFG_F6, CFG_F7, CFG_F8 = 111, 113, 114, 116, 117, 118   # ablations of the dedicated kernel  # timing-only ablation kernels (tools/bench_conv.py)
 PROFILE = None   # set to a list by bench.py to collect (cfg, flops, start_event, end_event) per GEMM/conv launch
 
 
@@ -257,7 +259,8 @@ def conv_cfg_for(spatial, stride=1):
     """Pick the 3x3x3 tile configuration for an OUTPUT grid of edge `spatial`."""
     if stride == 2:
         return CFG_C3_S2
-    return CFG_C3_128 if spatial % 8 == 0 else CFG_C3_LOW
+    # CFG_C3_128_FAST: dedicated kernel (F32B output only); same WPK weight tiles as CFG_C3_128
+    return CFG_C3_128_FAST if spatial % 8 == 0 else CFG_C3_LOW
 
 
 def gemm_cfg_for(ncols, nrows):

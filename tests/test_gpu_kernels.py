@@ -64,16 +64,18 @@ def test_gemm_asymmetric_identity(ops):
     assert rel_l2(y, ref) < TOL_MFMA
 
 
+@pytest.mark.parametrize("cfg_name", ["CFG_C3_128", "CFG_C3_128_FAST", "CFG_C3_128_V2"])
 @pytest.mark.parametrize("cin,cout,S,B", [(32, 128, 8, 2), (64, 256, 16, 1), (160, 128, 8, 1)])
-def test_conv3_main(ops, cin, cout, S, B):
+def test_conv3_main(ops, cin, cout, S, B, cfg_name):
+    cfg = getattr(ops, cfg_name)
     x = _rand((B, cin, S, S, S), 1)
     w = _rand((cout, cin, 3, 3, 3), 2, 0.05)
     bias = _rand((B, cout), 3)
     res = _rand((B, cout, S, S, S), 4)
     s, _, P = _to_s16(ops, x)
-    pw = ops.PackedWeight(w.cuda(), "conv", ops.CFG_C3_128, "cuda")
+    pw = ops.PackedWeight(w.cuda(), "conv", cfg, "cuda")
     out = ops.f32b_empty(B, cout, P, "cuda")
-    ops.gemm_conv(cfg=ops.CFG_C3_128, a=pw.data, b=s, out=out, batch=B, rows=cout, rows_alloc=cout, kdim=cin,
+    ops.gemm_conv(cfg=cfg, a=pw.data, b=s, out=out, batch=B, rows=cout, rows_alloc=cout, kdim=cin,
                   dims=(S, S, S), bias=bias.cuda(), bias_bstride=cout, residual=ops.ncdhw_to_f32b(res.cuda()),
                   res_bstride=cout * P)
     y = ops.f32b_to_ncdhw(out, (S, S, S)).cpu()
@@ -103,7 +105,7 @@ def test_conv3_stride2(ops, S_in):
     assert rel_l2(ops.f32b_to_ncdhw(out, (So, So, So)).cpu(), ref) < TOL_MFMA
 
 
-@pytest.mark.parametrize("S_in,cfg_name", [(4, "CFG_C3_128"), (8, "CFG_C3_128")])
+@pytest.mark.parametrize("S_in,cfg_name", [(4, "CFG_C3_128"), (8, "CFG_C3_128"), (4, "CFG_C3_128_FAST"), (8, "CFG_C3_128_FAST")])
 def test_conv3_upsample_fold(ops, S_in, cfg_name):
     cfg = getattr(ops, cfg_name)
     x = _rand((1, 64, S_in, S_in, S_in), 10); w = _rand((64, 64, 3, 3, 3), 11, 0.05)
