@@ -1,0 +1,68 @@
+"""Multi-GPU sampling: one process per GPU, independent sample shards, no data-path collective.
+
+Replaces the reference's single-process `torch.nn.DataParallel` (lib/diffusion/models/utils.py:88-96),
+which re-broadcasts all 1.46 GB of parameters on every denoise step.  Each rank keeps a
+static weight replica and draws its own shard with `seed + rank`; the only collective is the optional
+final gather of the finished `[B,4,R,R,R]` grids (4.2 MB/sample) to rank 0 over RCCL (backend "nccl" on
+ROCm) or gloo (CPU tests).
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def shard_sizes(total, world):
+    """Split `total` samples over `world` ranks as evenly as possible (first ranks get the remainder)."""
+    base, rem = divmod(int(total), int(world))
+    return [base + (1 if r < rem else 0) for r in range(world)]
+
+
+def init_distributed(backend=None):
+    """Initialise from the torchrun environment; returns (rank, world, local_rank).  No-op for world 1."""
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, world, local_rank
+
+
+def sharded_sample(sample_fn, total_batch, seed, gather=True):
+    """Run `sample_fn(local_batch, seed + rank) -> tensor[local_batch, ...]` on every rank.
+
+    Returns the concatenated `[total_batch, ...]` tensor on rank 0 (None elsewhere) when `gather`,
+    else the local shard.  Rank r owns samples [sum(sizes[:r]), sum(sizes[:r+1])).
+    """
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    sizes = shard_sizes(total_batch, world)
+    local = sample_fn(sizes[rank], int(seed) + rank) if sizes[rank] > 0 else None
+    if not gather or world == 1:
+        return local
+    # all ranks must contribute equal-shaped buffers: pad the shard to the largest size
+    ref = local if local is not None else None
+    shape_t = torch.zeros(8, dtype=torch.int64)
+    if ref is not None:
+        shape_t[0] = ref.dim()
+        shape_t[1:1 + ref.dim()] = torch.tensor(ref.shape)
+    dev = ref.device if ref is not None else torch.device("cpu")
+    if dist.get_backend() == "nccl":
+        dev = torch.device("cuda", torch.cuda.current_device())
+    shape_t = shape_t.to(dev)
+    dist.all_reduce(shape_t, op=dist.ReduceOp.MAX)
+    nd = int(shape_t[0])
+    full = [int(v) for v in shape_t[1:1 + nd]]
+    buf = torch.zeros([max(sizes)] + full[1:], dtype=torch.float32, device=dev)
+    if local is not None:
+        buf[:sizes[rank]] = local.to(dev, torch.float32)
+    out = [torch.empty_like(buf) for _ in range(world)] if rank == 0 else None
+    dist.gather(buf, out, dst=0)
+    if rank != 0:
+        return None
+    return torch.cat([o[:n] for o, n in zip(out, sizes)], dim=0)

@@ -1,0 +1,61 @@
+"""world_size-2 gloo tests of the multi-GPU sampling host logic (no kernels: a stub sampler stands in
+for the HIP U-Net, which the -m gpu tests cover)."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _stub_sampler(local_batch, seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn((local_batch, 4, 4, 4, 4), generator=g)
+
+
+def _worker(rank, world, port, total, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from meshdiffusion_amd.lib.diffusion import parallel
+    r, w, _ = parallel.init_distributed(backend="gloo")
+    assert (r, w) == (rank, world)
+    out = parallel.sharded_sample(_stub_sampler, total, seed=100)
+    local = parallel.sharded_sample(_stub_sampler, total, seed=100, gather=False)
+    q.put((rank, None if out is None else out.clone(), local.clone()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("total", [8, 5])
+def test_sharded_sampling_two_ranks_gloo(total):
+    from meshdiffusion_amd.lib.diffusion import parallel
+    assert parallel.shard_sizes(5, 2) == [3, 2] and parallel.shard_sizes(8, 8) == [1] * 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, total, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(2):
+        rank, out, local = q.get(timeout=120)
+        res[rank] = (out, local)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    sizes = parallel.shard_sizes(total, 2)
+    expect = torch.cat([_stub_sampler(sizes[r], 100 + r) for r in range(2)], 0)
+    assert res[1][0] is None
+    assert torch.equal(res[0][0], expect)                       # rank-0 gather == per-shard reference runs
+    assert torch.equal(res[1][1], _stub_sampler(sizes[1], 101))  # each rank == a run with its own seed
