@@ -22,7 +22,7 @@ def timestep_embedding(t, dim):
     """lib/diffusion/models/layers.py:542-556."""
     half = dim // 2
     scale = math.log(10000) / (half - 1)
-    freqs = torch.exp(torch.arange(half, dtype=torch.float32) * -scale)
+    freqs = torch.exp(torch.arange(half, dtype=torch.float32, device=t.device) * -scale)
     arg = t.float()[:, None] * freqs[None, :]
     return torch.cat([torch.sin(arg), torch.cos(arg)], dim=1)
 
