@@ -68,6 +68,9 @@ enum { MD_A_PACKED = 0, MD_A_S16B = 1 };
  *                              + bias[b*bias_bstride + i] + residual[b][i][j]
  * computed on the matrix cores with a bf16x3 split (hi*hi + hi*lo + lo*hi,
  * fp32 accumulate).  i = output row (output channel), j = spatial position.
+ * With ksplit > 1 (F32B output only) the K-chunk range is divided over grid.z workgroups that write
+ * raw partial sums to `partial`; a second, deterministic kernel adds the slices in order and applies
+ * alpha / bias / residual.  Used for the 4^3 and 8^3 levels where tiles alone cannot fill 256 CUs.
  *
  * Replaces: nn.Conv3d 3x3x3 (lib/diffusion/models/layers.py:118-124 used at
  * :654,:662, ddpm_res64.py:85-87,:121), Downsample pad+stride-2 conv
@@ -96,6 +99,9 @@ typedef struct MdGemmConvArgs {
   int64_t bias_bstride;  /* floats between batches of bias; 0 = shared                         */
   int64_t res_bstride;   /* floats between batches of residual; 0 = shared                     */
   int64_t b_bstride;     /* elements (bf16) between batches of B; 0 = shared                   */
+  float* partial;        /* ksplit>1: fp32 workspace [ksplit][B][rows_alloc/8][P][8]            */
+  int32_t ksplit;        /* split the K-chunk loop over this many workgroups (grid.z); 0/1 = off */
+  int32_t reserved0;
 } MdGemmConvArgs;
 
 int md_abi_version(void);
@@ -103,6 +109,8 @@ int md_abi_version(void);
 int md_device_count(void);
 
 int md_gemm_conv(const MdGemmConvArgs* args, void* stream);
+/* bytes of `partial` workspace md_gemm_conv needs for these args (0 when ksplit <= 1) */
+int64_t md_gemm_conv_partial_bytes(const MdGemmConvArgs* args);
 /* bytes of LDS and threads per workgroup of a cfg (for DESIGN/bench reporting) */
 int md_gemm_conv_cfg_info(int32_t cfg, int32_t* nt, int32_t* kc, int32_t* cols,
                           int32_t* taps, int32_t* lds_bytes, int32_t* threads);

@@ -33,7 +33,7 @@ class MdGemmConvArgs(C.Structure):
         ("rows", C.c_int32), ("rows_alloc", C.c_int32), ("kdim", C.c_int32), ("D", C.c_int32),
         ("H", C.c_int32), ("W", C.c_int32), ("ups", C.c_int32), ("a_src", C.c_int32),
         ("out_mode", C.c_int32), ("a_rows", C.c_int32), ("a_bstride", C.c_int64),
-        ("bias_bstride", C.c_int64), ("res_bstride", C.c_int64), ("b_bstride", C.c_int64),
+        ("bias_bstride", C.c_int64), ("res_bstride", C.c_int64), ("b_bstride", C.c_int64), ("partial", C.c_void_p), ("ksplit", C.c_int32), ("reserved0", C.c_int32),
     ]
 
 
@@ -44,6 +44,7 @@ SIGNATURES = {
     "md_abi_version": (C.c_int, []),
     "md_device_count": (C.c_int, []),
     "md_gemm_conv": (C.c_int, [C.POINTER(MdGemmConvArgs), _P]),
+    "md_gemm_conv_partial_bytes": (_I64, [C.POINTER(MdGemmConvArgs)]),
     "md_gemm_conv_cfg_info": (C.c_int, [_I32] + [C.POINTER(C.c_int32)] * 6),
     "md_pack_weights": (C.c_int, [_P, _P, _I32, _I32, _I32, _I64, _I64, _I64, _I32, _I32, _P]),
     "md_packed_weight_bytes": (_I64, [_I32, _I32, _I32, _I32, _I32]),

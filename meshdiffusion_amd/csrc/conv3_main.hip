@@ -63,11 +63,15 @@ __global__ __launch_bounds__(NTHREADS) void md_conv3_main_kernel(const MdGemmCon
   const int x0 = (t % ntx) * TX, y0 = ((t / ntx) % nty) * TY, z0 = (t / (ntx * nty)) * TZ;
   const int64_t Pin = (int64_t)Di * Hi * Wi;
   const int rt = blockIdx.y;
-  const int ncc = A.kdim / KC;
+  const int ncc_total = A.kdim / KC;
+  const int ksplit = A.ksplit > 1 ? A.ksplit : 1;  // split-K: this workgroup owns chunks [cc_lo, cc_lo+ncc)
+  const int cc_lo = (int)(((int64_t)blockIdx.z * ncc_total) / ksplit);
+  const int ncc = (int)(((int64_t)(blockIdx.z + 1) * ncc_total) / ksplit) - cc_lo;
   const int nsteps = ncc * TAPS;
 
-  const uint4* bptr = (const uint4*)A.b + (int64_t)b * (A.b_bstride / 8);
-  const uint4* wbase = (const uint4*)A.a + (int64_t)rt * nsteps * W_ITEMS;  // tiles contiguous in step order
+  const uint4* bptr = (const uint4*)A.b + (int64_t)b * (A.b_bstride / 8) + (int64_t)cc_lo * (KG * 2) * Pin;
+  // tiles are contiguous in step order
+  const uint4* wbase = (const uint4*)A.a + ((int64_t)rt * ncc_total + cc_lo) * TAPS * W_ITEMS;
 
   // ---- halo prefetch descriptors: computed ONCE (source offset in uint4 units relative to the chunk
   //      base, -1 = outside the grid => zero fill; LDS destination byte offset) ---------------------
@@ -252,12 +256,14 @@ __global__ __launch_bounds__(NTHREADS) void md_conv3_main_kernel(const MdGemmCon
 #undef MD_INTERLEAVE
 
   // ---- epilogue: bias + residual loads batched, 16-byte stores into the F32B layout -------------------
-  const float alpha = A.alpha;
+  const bool partial = ksplit > 1;  // raw partial sums go to the workspace slice; md_splitk_reduce finishes
+  const float alpha = partial ? 1.f : A.alpha;
   const int rows = A.rows, rows_alloc = A.rows_alloc;
   const int rg_alloc = rows_alloc / 8;
-  float* outp = (float*)A.out + (int64_t)b * rg_alloc * P * 8;
-  const float* resp = A.residual ? A.residual + (int64_t)b * A.res_bstride : nullptr;
-  const float* biasp = A.bias ? A.bias + (int64_t)b * A.bias_bstride : nullptr;
+  float* outp = partial ? A.partial + ((int64_t)blockIdx.z * A.batch + b) * rg_alloc * P * 8
+                        : (float*)A.out + (int64_t)b * rg_alloc * P * 8;
+  const float* resp = (A.residual && !partial) ? A.residual + (int64_t)b * A.res_bstride : nullptr;
+  const float* biasp = (A.bias && !partial) ? A.bias + (int64_t)b * A.bias_bstride : nullptr;
   f32x4 bv[2][4];
 #pragma unroll
   for (int rm = 0; rm < 2; ++rm)
@@ -305,6 +311,8 @@ __global__ __launch_bounds__(NTHREADS) void md_conv3_main_kernel(const MdGemmCon
   }
 }
 
+int md_launch_splitk_reduce(const MdGemmConvArgs& a, hipStream_t stream);  // gemm_conv.hip
+
 // launched from gemm_conv.hip (MD_CFG_C3_128_FAST)
 int md_launch_conv3_main(const MdGemmConvArgs& a, hipStream_t stream) {
   if (a.kdim % KC != 0 || a.kdim <= 0 || a.rows <= 0 || a.rows_alloc % 8 != 0 || a.batch <= 0) return MD_ERR_BAD_ARG;
@@ -312,7 +320,9 @@ int md_launch_conv3_main(const MdGemmConvArgs& a, hipStream_t stream) {
   if (a.ups && ((a.D | a.H | a.W) & 1)) return MD_ERR_BAD_ARG;
   if (a.a_src != MD_A_PACKED || a.out_mode != MD_OUT_F32B) return MD_ERR_UNSUPPORTED;
   const int tiles = (a.D / TZ) * (a.H / TY) * (a.W / TX);
-  dim3 grid((unsigned)(tiles * a.batch), (unsigned)((a.rows + NT - 1) / NT), 1);
+  const int ks = a.ksplit > 1 ? a.ksplit : 1;
+  if (ks > 1 && (a.partial == nullptr || ks > a.kdim / KC)) return MD_ERR_BAD_ARG;
+  dim3 grid((unsigned)(tiles * a.batch), (unsigned)((a.rows + NT - 1) / NT), (unsigned)ks);
   MD_HIP_CLEAR_ERROR();
   switch (a.cfg) {
     case 111: hipLaunchKernelGGL(md_conv3_main_kernel<1>, grid, dim3(NTHREADS), 0, stream, a); break;
@@ -324,5 +334,6 @@ int md_launch_conv3_main(const MdGemmConvArgs& a, hipStream_t stream) {
     default: hipLaunchKernelGGL(md_conv3_main_kernel<0>, grid, dim3(NTHREADS), 0, stream, a); break;
   }
   MD_HIP_CHECK_LAUNCH();
+  if (ks > 1) return md_launch_splitk_reduce(a, stream);
   return MD_OK;
 }

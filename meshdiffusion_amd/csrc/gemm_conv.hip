@@ -98,7 +98,11 @@ __global__ __launch_bounds__(C::NTHREADS) void md_gemm_conv_kernel(const MdGemmC
   }
   const int64_t Pin = (int64_t)Di * Hi * Wi;
   const int rt = blockIdx.y;
-  const int ncc = A.kdim / C::KC;
+  const int ncc_total = A.kdim / C::KC;
+  // split-K: this workgroup owns K chunks [cc_lo, cc_lo + ncc)
+  const int ksplit = A.ksplit > 1 ? A.ksplit : 1;
+  const int cc_lo = (int)(((int64_t)blockIdx.z * ncc_total) / ksplit);
+  const int ncc = (int)(((int64_t)(blockIdx.z + 1) * ncc_total) / ksplit) - cc_lo;
   const int nsteps = ncc * C::TAPS;
 
   const uint4* bptr = (const uint4*)A.b + (int64_t)b * (A.b_bstride / 8);
@@ -137,12 +141,12 @@ __global__ __launch_bounds__(C::NTHREADS) void md_gemm_conv_kernel(const MdGemmC
       uint4 v = make_uint4(0, 0, 0, 0);
       if (item < C::W_ITEMS) {
         if (A.a_src == MD_A_PACKED) {
-          v = aptr[((int64_t)(rt * ncc + cc) * C::TAPS + tap) * C::W_ITEMS + item];
+          v = aptr[((int64_t)(rt * ncc_total + cc_lo + cc) * C::TAPS + tap) * C::W_ITEMS + item];
         } else {
           const int gp = item / C::NT, r = item % C::NT;
           const int row = rt * C::NT + r;
           if (row < A.a_rows)
-            v = aptr[((int64_t)(cc * C::KG + (gp >> 1)) * 2 + (gp & 1)) * A.a_rows + row];
+            v = aptr[((int64_t)((cc_lo + cc) * C::KG + (gp >> 1)) * 2 + (gp & 1)) * A.a_rows + row];
         }
       }
       wreg[i] = v;
@@ -182,7 +186,7 @@ __global__ __launch_bounds__(C::NTHREADS) void md_gemm_conv_kernel(const MdGemmC
         } else {
           src = (int64_t)t * C::MT + r;
         }
-        if (inb) v = bptr[((int64_t)(cc * C::KG + (gp >> 1)) * 2 + (gp & 1)) * Pin + src];
+        if (inb) v = bptr[((int64_t)((cc_lo + cc) * C::KG + (gp >> 1)) * 2 + (gp & 1)) * Pin + src];
       }
       hreg[i] = v;
     }
@@ -357,7 +361,7 @@ __global__ __launch_bounds__(C::NTHREADS) void md_gemm_conv_kernel(const MdGemmC
     constexpr int PF = (C::TAPS >= 3) ? C::TAPS - 3 : 0;
     bf16x8 fa0[C::RM][KS][2], fa1[C::RM][KS][2];
     auto a_issue = [&](bf16x8 (&af)[C::RM][KS][2], int cc_, int tap_) {
-      const bf16x8* tile = (const bf16x8*)(aptr + ((int64_t)(rt * ncc + cc_) * C::TAPS + tap_) * C::W_ITEMS);
+      const bf16x8* tile = (const bf16x8*)(aptr + ((int64_t)(rt * ncc_total + cc_lo + cc_) * C::TAPS + tap_) * C::W_ITEMS);
 #pragma unroll
       for (int rm = 0; rm < C::RM; ++rm)
 #pragma unroll
@@ -449,6 +453,31 @@ __global__ __launch_bounds__(C::NTHREADS) void md_gemm_conv_kernel(const MdGemmC
   }
 
   // ---- epilogue --------------------------------------------------------------
+  if (ksplit > 1) {  // raw partial sums -> workspace slice (F32B layout); md_splitk_reduce finishes the job
+    const int rga = A.rows_alloc / 8;
+    float* part = A.partial + ((int64_t)blockIdx.z * A.batch + b) * rga * P * 8;
+#pragma unroll
+    for (int cm = 0; cm < C::CM; ++cm) {
+      const int p = (wc * C::CM + cm) * 32 + j;
+      int64_t gp;
+      if constexpr (C::TAPS == 27) {
+        const int x = p % C::TX, y = (p / C::TX) % C::TY, z = p / (C::TX * C::TY);
+        gp = ((int64_t)(z0 + z) * H + (y0 + y)) * W + (x0 + x);
+      } else {
+        gp = (int64_t)t * C::MT + p;
+      }
+#pragma unroll
+      for (int rm = 0; rm < C::RM; ++rm)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int row = rt * C::NT + (wr * C::RM + rm) * 32 + 8 * q + 4 * h;
+          if (row >= A.rows_alloc) continue;
+          f32x4 o4 = {acc[rm][cm][q * 4 + 0], acc[rm][cm][q * 4 + 1], acc[rm][cm][q * 4 + 2], acc[rm][cm][q * 4 + 3]};
+          *(f32x4*)(part + ((int64_t)(row >> 3) * P + gp) * 8 + (row & 7)) = o4;
+        }
+    }
+    return;
+  }
   const float alpha = A.alpha;
   const int rows = A.rows, rows_alloc = A.rows_alloc;
   const int rg_alloc = rows_alloc / 8;
@@ -525,6 +554,54 @@ using Cfg_G1_128 = GCfg<128, 32, 1, 1, 256, 1, 1, 2, 4>;
 using Cfg_G1_128_LOW = GCfg<128, 32, 1, 1, 64, 1, 1, 4, 2>;
 using Cfg_G1_64_LOW = GCfg<64, 32, 1, 1, 64, 1, 1, 2, 2>;
 
+// ---- split-K finish: out = alpha * sum_z partial[z] + bias + residual (slices added in order) ----
+__global__ void md_splitk_reduce_kernel(const MdGemmConvArgs A, int64_t P) {
+  const int rga = A.rows_alloc / 8;
+  const int64_t n4 = (int64_t)A.batch * rga * P * 2;  // float4 items
+  const int64_t slice = (int64_t)A.batch * rga * P * 8;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t e0 = i * 4;
+    f32x4 s = *(const f32x4*)(A.partial + e0);
+    for (int z = 1; z < A.ksplit; ++z) {
+      const f32x4 v = *(const f32x4*)(A.partial + (int64_t)z * slice + e0);
+      s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
+    }
+    const int64_t per_b = (int64_t)rga * P * 8;
+    const int b = (int)(e0 / per_b);
+    const int64_t r = e0 % per_b;
+    const int row = (int)(r / (P * 8)) * 8 + (int)(r & 7);
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float x = A.alpha * s[e];
+      if (A.bias != nullptr && row + e < A.rows) x += A.bias[(int64_t)b * A.bias_bstride + row + e];
+      o[e] = x;
+    }
+    if (A.residual != nullptr) {
+      const f32x4 rv = *(const f32x4*)(A.residual + (int64_t)b * A.res_bstride + r);
+      o[0] += rv[0]; o[1] += rv[1]; o[2] += rv[2]; o[3] += rv[3];
+    }
+    *(f32x4*)((float*)A.out + e0) = o;
+  }
+}
+
+int md_launch_splitk_reduce(const MdGemmConvArgs& a, hipStream_t stream) {
+  const int64_t P = (int64_t)a.D * a.H * a.W;
+  const int64_t n4 = (int64_t)a.batch * (a.rows_alloc / 8) * P * 2;
+  int blocks = (int)((n4 + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  MD_HIP_CLEAR_ERROR();
+  hipLaunchKernelGGL(md_splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a, P);
+  MD_HIP_CHECK_LAUNCH();
+  return MD_OK;
+}
+
+extern "C" int64_t md_gemm_conv_partial_bytes(const MdGemmConvArgs* a) {
+  if (a == nullptr) return MD_ERR_BAD_ARG;
+  if (a->ksplit <= 1) return 0;
+  return (int64_t)a->ksplit * a->batch * (a->rows_alloc / 8) * ((int64_t)a->D * a->H * a->W) * 8 * 4;
+}
+
 template <class C>
 static int launch_cfg(const MdGemmConvArgs& a, hipStream_t stream) {
   if (a.kdim % C::KC != 0 || a.kdim <= 0) return MD_ERR_BAD_ARG;
@@ -542,10 +619,13 @@ static int launch_cfg(const MdGemmConvArgs& a, hipStream_t stream) {
   if (a.a_src == MD_A_S16B && a.a_rows <= 0) return MD_ERR_BAD_ARG;
   if (C::PIPE == 2 && a.a_src != MD_A_PACKED) return MD_ERR_UNSUPPORTED;
   const int row_tiles = (a.rows + C::NT - 1) / C::NT;
-  dim3 grid((unsigned)(tiles * a.batch), (unsigned)row_tiles, 1);
+  const int ks = a.ksplit > 1 ? a.ksplit : 1;
+  if (ks > 1 && (a.partial == nullptr || a.out_mode != MD_OUT_F32B || ks > a.kdim / C::KC || C::PIPE == 2)) return MD_ERR_BAD_ARG;
+  dim3 grid((unsigned)(tiles * a.batch), (unsigned)row_tiles, (unsigned)ks);
   MD_HIP_CLEAR_ERROR();
   hipLaunchKernelGGL(md_gemm_conv_kernel<C>, grid, dim3(C::NTHREADS), 0, stream, a);
   MD_HIP_CHECK_LAUNCH();
+  if (ks > 1) return md_launch_splitk_reduce(a, stream);
   return MD_OK;
 }
 

@@ -87,7 +87,7 @@ def pack_s16b_from_matrix(w_kp, device):
 # ---------------------------------------------------------------------------------------------
 def gemm_conv(*, cfg, a, b, out, batch, rows, rows_alloc, kdim, dims, bias=None, bias_bstride=0,
               residual=None, res_bstride=0, alpha=1.0, ups=0, a_src=A_PACKED, a_rows=0, a_bstride=0,
-              b_bstride=None, out_mode=OUT_F32B):
+              b_bstride=None, out_mode=OUT_F32B, ksplit=1):
     lib = _lib.load()
     D, H, W = dims
     args = MdGemmConvArgs()
@@ -107,6 +107,13 @@ def gemm_conv(*, cfg, a, b, out, batch, rows, rows_alloc, kdim, dims, bias=None,
             pin *= 8
         b_bstride = (kdim // 8) * 2 * pin * 8
     args.b_bstride = b_bstride
+    part = None
+    if ksplit > 1:
+        if out_mode != OUT_F32B:
+            raise ValueError("split-K supports F32B output only")
+        args.ksplit = ksplit
+        part = torch.empty((ksplit * batch * rows_alloc * D * H * W,), dtype=torch.float32, device=out.device)
+        args.partial = part.data_ptr()
     if PROFILE is None:
         check(lib.md_gemm_conv(C.byref(args), _stream()), f"md_gemm_conv(cfg={cfg})")
     else:  # bench.py: HIP events on the launch stream around this launch (algorithmic flops, 1x)
@@ -253,6 +260,17 @@ def inpaint_renoise_(x, x_mean, z, pmask, gmask, coef, ch):
     check(lib.md_inpaint_renoise(_ptr(x), _ptr(x_mean), _ptr(z), _ptr(pmask), _ptr(gmask), _ptr(coef), B, Cc,
                                  ch, P, _stream()), "md_inpaint_renoise")
     return x
+
+
+def ksplit_for(cfg, batch, rows, kdim, spatial_out):
+    """Split the K-chunk loop when output tiles alone cannot fill the 256 CUs (4^3 / 8^3 levels)."""
+    info = _lib.cfg_info(cfg)
+    tiles = max(1, spatial_out ** 3 // info["cols"]) * batch * ((rows + info["nt"] - 1) // info["nt"])
+    ncc = kdim // info["kc"]
+    ks = 1
+    while tiles * ks < 256 and ks * 2 <= ncc and ks < 32:
+        ks *= 2
+    return ks
 
 
 def conv_cfg_for(spatial, stride=1):

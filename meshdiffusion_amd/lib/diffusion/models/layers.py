@@ -117,10 +117,11 @@ def run_conv3(pw, act_s16, B, S_out, *, bias=None, bias_bstride=0, residual=None
         out = ops.f32b_empty(B, rows_alloc, P, act_s16.device)
     if residual is not None and res_bstride is None:
         res_bstride = rows_alloc * P
+    ksplit = ops.ksplit_for(pw.cfg, B, pw.rows, pw.kdim, S_out) if out_mode == ops.OUT_F32B else 1
     return ops.gemm_conv(cfg=pw.cfg, a=pw.data, b=act_s16, out=out, batch=B, rows=pw.rows,
                          rows_alloc=rows_alloc, kdim=pw.kdim, dims=(S_out, S_out, S_out), bias=bias,
                          bias_bstride=bias_bstride, residual=residual, res_bstride=res_bstride or 0, ups=ups,
-                         out_mode=out_mode)
+                         out_mode=out_mode, ksplit=ksplit)
 
 
 def run_gemm(pw, act_s16, B, P, *, bias=None, bias_bstride=0, residual=None, out=None, out_mode=ops.OUT_F32B,

@@ -83,6 +83,26 @@ def test_conv3_main(ops, cin, cout, S, B, cfg_name):
     assert rel_l2(y, ref) < TOL_MFMA
 
 
+@pytest.mark.parametrize("cfg_name,S,ks", [("CFG_C3_128_FAST", 8, 4), ("CFG_C3_LOW", 4, 4), ("CFG_C3_128", 8, 2), ("CFG_C3_LOW", 4, 3)])
+def test_conv3_split_k(ops, cfg_name, S, ks):
+    """split-K (grid.z partial sums + ordered reduce) == single-pass result up to fp32 summation order."""
+    cfg = getattr(ops, cfg_name)
+    B, cin, cout = 2, 128, 128
+    x = _rand((B, cin, S, S, S), 40); w = _rand((cout, cin, 3, 3, 3), 41, 0.05)
+    bias = _rand((B, cout), 42); res = _rand((B, cout, S, S, S), 43)
+    s, _, P = _to_s16(ops, x)
+    pw = ops.PackedWeight(w.cuda(), "conv", cfg, "cuda")
+    outs = []
+    for k in (1, ks):
+        out = ops.f32b_empty(B, cout, P, "cuda")
+        ops.gemm_conv(cfg=cfg, a=pw.data, b=s, out=out, batch=B, rows=cout, rows_alloc=cout, kdim=cin, dims=(S, S, S),
+                      bias=bias.cuda(), bias_bstride=cout, residual=ops.ncdhw_to_f32b(res.cuda()), res_bstride=cout * P,
+                      ksplit=k)
+        outs.append(ops.f32b_to_ncdhw(out, (S, S, S)).cpu())
+    ref = F.conv3d(x, w, padding=1) + bias[:, :, None, None, None] + res
+    assert rel_l2(outs[1], ref) < TOL_MFMA and rel_l2(outs[1], outs[0]) < 1e-6
+
+
 def test_conv3_low_tile(ops):
     x = _rand((2, 64, 4, 4, 4), 5); w = _rand((128, 64, 3, 3, 3), 6, 0.05)
     s, B, P = _to_s16(ops, x)
