@@ -3,6 +3,7 @@
 // ddpm_res64.py:120,186) and the torch.cat before it (ddpm_res64.py:174-176).
 // All three kernels are pure HBM streaming: 16 B per lane, consecutive lanes contiguous.
 #include "md_common.h"
+#include <hip/hip_fp16.h>
 
 static constexpr int GN_BLOCK = 256;
 static constexpr int GN_ITEMS = 16;                              // float4 items per thread
@@ -107,7 +108,10 @@ __global__ __launch_bounds__(GN_BLOCK) void md_gn_apply_kernel(const float* __re
       for (int e = 0; e < 4; ++e) {
         float y = v[e];
         if (norm) y = (y - mean[e]) * a[e] + bt[e];
-        if (silu) y = md_silu(y);
+        if (silu & 1) y = md_silu(y);
+        // experiment hook (tools/longrun_parity.py --act-fp16): round the operand to fp16 first, which is
+        // what a weights-split-only fp16 scheme (2 MFMAs per product) would feed the matrix cores
+        if (silu & 2) y = __half2float(__float2half_rn(y));
         md_split(y, hi[e], lo[e]);
       }
       const int64_t o = pos * 8 + half * 4;

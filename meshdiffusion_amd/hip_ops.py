@@ -5,6 +5,7 @@ Blocked device layouts: F32B float32 [B][C/8][P][8]; S16B bf16 [B][C
 """
 import ctypes as C
 import math
+import os
 
 import torch
 
@@ -16,6 +17,7 @@ from ._lib import (A_PACKED, A_S16B, CFG_C3_128, CFG_C3_128_V2, CFG_C3_128_SW, C
 
 CFG_ABL1, CFG_ABL2, CFG_ABL3, CFG_ABL4, CFG_ABL5 = 101, 102, 103, 104, 105
 CFG_F1, CFG_F3, CFG_F4, CFG_F6, CFG_F7, CFG_F8 = 111, 113, 114, 116, 117, 118   # ablations of the dedicated kernel  # timing-only ablation kernels (tools/bench_conv.py)
+DEBUG_ACT_FP16 = 2 if os.environ.get("MD_DEBUG_ACT_FP16") == "1" else 0   # precision experiment only
 PROFILE = None   # set to a list by bench.py to collect (cfg, flops, start_event, end_event) per GEMM/conv launch
 
 
@@ -156,7 +158,7 @@ def gn_apply(parts, params, B, P, norm=True, silu=True, out=None):
     off = 0
     for t, c in parts:
         check(lib.md_gn_apply(_ptr(t), _ptr(params) if norm else None, _ptr(out), B, c, P, ctot, off,
-                              1 if norm else 0, 1 if silu else 0, _stream()), "md_gn_apply")
+                              1 if norm else 0, (1 if silu else 0) | DEBUG_ACT_FP16, _stream()), "md_gn_apply")
         off += c
     return out
 

@@ -174,7 +174,8 @@ def test_unet_res64_vs_reference_golden(env):
     lb = torch.cat([torch.tensor(gold["labels"]), torch.linspace(10.0, 990.0, 7)])
     with torch.no_grad():
         yb = model(xb.cuda(), lb.cuda())
-    assert rel_l2(yb[0:1].cpu(), y) < 1e-6
+    # not bit-equal: the split-K factor of the 4^3/8^3 convs depends on the batch (fp32 summation order)
+    assert rel_l2(yb[0:1].cpu(), y) < 1e-5
 
 
 @pytest.mark.skipif(not os.path.exists(os.path.join(GOLD, "sampler_res64.npz")), reason="res64 golden not generated")
