@@ -57,7 +57,9 @@ enum {
   MD_CFG_C3_128_V3B = 12, /* same, 2x4 wave grid                                              */
   MD_CFG_C3_128_V4 = 13, /* C3_128_V2 with the barrier between the two K=16 half-steps (LDS latency hidden) */
   MD_CFG_C3_128_FAST = 14, /* dedicated kernel for the hot conv: C3_128_V2 layout, taps unrolled, F32B out */
-  MD_CFG_COUNT = 15
+  MD_CFG_C5_128_K16 = 15, /* 5x5x5 s1 pad 2, tile 4x8x8, NT=128, KC=16 (ddpm_res128 stem / mask_layer)  */
+  MD_CFG_C5_32_K16 = 16,  /* 5x5x5 s1 pad 2, tile 4x8x8, NT=32,  KC=16 (ddpm_res128 head)               */
+  MD_CFG_COUNT = 17
 };
 
 enum { MD_OUT_F32B = 0, MD_OUT_S16B = 1, MD_OUT_NCDHW = 2 };

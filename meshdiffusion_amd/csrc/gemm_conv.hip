@@ -31,9 +31,10 @@ struct GCfg {
   static constexpr int NTHREADS = NW * 64;
   static constexpr int RM = NT / (32 * WR);
   static constexpr int CM = MT / (32 * WC);
-  static constexpr int ZH = (TAPS == 27) ? (TZ - 1) * STRIDE + 3 : 1;
-  static constexpr int YH = (TAPS == 27) ? (TY - 1) * STRIDE + 3 : 1;
-  static constexpr int XH = (TAPS == 27) ? (TX - 1) * STRIDE + 3 : MT;
+  static constexpr int KSZ = (TAPS == 125) ? 5 : (TAPS == 27) ? 3 : 1;  // cubic kernel extent
+  static constexpr int ZH = (TAPS > 1) ? (TZ - 1) * STRIDE + KSZ : 1;
+  static constexpr int YH = (TAPS > 1) ? (TY - 1) * STRIDE + KSZ : 1;
+  static constexpr int XH = (TAPS > 1) ? (TX - 1) * STRIDE + KSZ : MT;
   static constexpr int XHP = XH;
   // SW=1 (tile x-extent 8, stride 1): y-rows are 24 slots apart with odd z-planes interleaved at +12,
   // so a 32-position fragment (8 x by 4 y) touches every 16-byte LDS slot class exactly twice, once
@@ -52,11 +53,12 @@ struct GCfg {
   static constexpr int W_LDS_ITEMS = (PIPE_ == 2) ? 0 : 2 * W_ITEMS;  // PIPE=2 keeps weights out of LDS
   static constexpr int LDS_ITEMS = W_LDS_ITEMS + KG * 2 * HS;
   static constexpr int LDS_BYTES = LDS_ITEMS * 16;
-  static constexpr int PADLO = (STRIDE == 2) ? 0 : 1;
+  static constexpr int PADLO = (STRIDE == 2) ? 0 : (KSZ - 1) / 2;  // 'same' padding; Downsample pads (0,1)
+  static_assert(TAPS == 1 || TAPS == 27 || TAPS == 125, "1x1x1, 3x3x3 or 5x5x5");
   static_assert(RM >= 1 && CM >= 1, "tile too small for the wave grid");
   static_assert(NT % (32 * WR) == 0 && MT % (32 * WC) == 0, "tile / wave grid mismatch");
   static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
-  static_assert(SW == 0 || (TAPS == 27 && STRIDE == 1 && TX == 8), "SW=1 layout is for x-extent 8, stride 1");
+  static_assert(SW == 0 || (TAPS == 27 && STRIDE == 1 && TX == 8), "SW=1 layout is for 3x3x3, x-extent 8, stride 1");
 };
 
 template <class C>
@@ -76,7 +78,7 @@ __global__ __launch_bounds__(C::NTHREADS) void md_gemm_conv_kernel(const MdGemmC
   const int64_t P = (int64_t)D * H * W;
   int tiles, z0 = 0, y0 = 0, x0 = 0;
   int Di = D, Hi = H, Wi = W;  // input extents
-  if constexpr (C::TAPS == 27) {
+  if constexpr (C::TAPS > 1) {
     const int ntx = W / C::TX, nty = H / C::TY, ntz = D / C::TZ;
     tiles = ntx * nty * ntz;
     if constexpr (C::STRIDE == 2) { Di = 2 * D; Hi = 2 * H; Wi = 2 * W; }
@@ -90,7 +92,7 @@ __global__ __launch_bounds__(C::NTHREADS) void md_gemm_conv_kernel(const MdGemmC
   if ((gridDim.x & 7) == 0) bid = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
   const int b = bid / tiles;
   const int t = bid % tiles;
-  if constexpr (C::TAPS == 27) {
+  if constexpr (C::TAPS > 1) {
     const int ntx = W / C::TX, nty = H / C::TY;
     x0 = (t % ntx) * C::TX;
     y0 = ((t / ntx) % nty) * C::TY;
@@ -117,7 +119,7 @@ __global__ __launch_bounds__(C::NTHREADS) void md_gemm_conv_kernel(const MdGemmC
 #pragma unroll
   for (int cm = 0; cm < C::CM; ++cm) {
     const int p = (wc * C::CM + cm) * 32 + j;
-    if constexpr (C::TAPS == 27) {
+    if constexpr (C::TAPS > 1) {
       bx[cm] = (p % C::TX) * C::STRIDE; by[cm] = ((p / C::TX) % C::TY) * C::STRIDE; bz[cm] = (p / (C::TX * C::TY)) * C::STRIDE;
     } else {
       bx[cm] = p; by[cm] = 0; bz[cm] = 0;
@@ -171,7 +173,7 @@ __global__ __launch_bounds__(C::NTHREADS) void md_gemm_conv_kernel(const MdGemmC
         const int gp = item / C::HPOS, r = item % C::HPOS;
         int64_t src;
         bool inb = true;
-        if constexpr (C::TAPS == 27) {
+        if constexpr (C::TAPS > 1) {
           const int hx = r % C::XH, hy = (r / C::XH) % C::YH, hz = r / (C::XH * C::YH);
           int uz = z0 * C::STRIDE + hz - C::PADLO;
           int uy = y0 * C::STRIDE + hy - C::PADLO;
@@ -198,7 +200,7 @@ __global__ __launch_bounds__(C::NTHREADS) void md_gemm_conv_kernel(const MdGemmC
       if (item < C::A_ITEMS) {
         const int gp = item / C::HPOS, r = item % C::HPOS;
         int slot = r;
-        if constexpr (C::TAPS == 27) slot = C::slot_of(r / (C::XH * C::YH), (r / C::XH) % C::YH, r % C::XH);
+        if constexpr (C::TAPS > 1) slot = C::slot_of(r / (C::XH * C::YH), (r / C::XH) % C::YH, r % C::XH);
         al[gp * C::HS + slot] = hreg[i];
       }
     }
@@ -263,9 +265,9 @@ __global__ __launch_bounds__(C::NTHREADS) void md_gemm_conv_kernel(const MdGemmC
   };
   auto advance = [&](int& cc, int& tap, int& dz, int& dy, int& dx) {
     ++tap; ++dx;
-    if constexpr (C::TAPS == 27) {
-      if (dx == 3) { dx = 0; ++dy; }
-      if (dy == 3) { dy = 0; ++dz; }
+    if constexpr (C::TAPS > 1) {
+      if (dx == C::KSZ) { dx = 0; ++dy; }
+      if (dy == C::KSZ) { dy = 0; ++dz; }
     }
     if (tap == C::TAPS) { tap = 0; dz = dy = dx = 0; ++cc; }
   };
@@ -460,7 +462,7 @@ __global__ __launch_bounds__(C::NTHREADS) void md_gemm_conv_kernel(const MdGemmC
     for (int cm = 0; cm < C::CM; ++cm) {
       const int p = (wc * C::CM + cm) * 32 + j;
       int64_t gp;
-      if constexpr (C::TAPS == 27) {
+      if constexpr (C::TAPS > 1) {
         const int x = p % C::TX, y = (p / C::TX) % C::TY, z = p / (C::TX * C::TY);
         gp = ((int64_t)(z0 + z) * H + (y0 + y)) * W + (x0 + x);
       } else {
@@ -485,7 +487,7 @@ __global__ __launch_bounds__(C::NTHREADS) void md_gemm_conv_kernel(const MdGemmC
   for (int cm = 0; cm < C::CM; ++cm) {
     const int p = (wc * C::CM + cm) * 32 + j;
     int64_t gp;
-    if constexpr (C::TAPS == 27) {
+    if constexpr (C::TAPS > 1) {
       const int x = p % C::TX, y = (p / C::TX) % C::TY, z = p / (C::TX * C::TY);
       gp = ((int64_t)(z0 + z) * H + (y0 + y)) * W + (x0 + x);
     } else {
@@ -541,6 +543,8 @@ using Cfg_C3_128_PIPE = GCfg<128, 32, 4, 8, 8, 27, 1, 2, 4, 0, 1>;
 using Cfg_C3_128_V3 = GCfg<128, 32, 4, 8, 8, 27, 1, 4, 2, 1, 2>;   // weights L2->registers, no per-tap barrier
 using Cfg_C3_128_V3B = GCfg<128, 32, 4, 8, 8, 27, 1, 2, 4, 1, 2>;  // same with the 2x4 wave grid
 using Cfg_C3_128_V4 = GCfg<128, 32, 4, 8, 8, 27, 1, 2, 4, 1, 3>;   // mid-step barrier pipeline
+using Cfg_C5_128_K16 = GCfg<128, 16, 4, 8, 8, 125, 1, 2, 4>;  // 5x5x5 stem of ddpm_res128 (Cin<=16)
+using Cfg_C5_32_K16 = GCfg<32, 16, 4, 8, 8, 125, 1, 1, 8>;    // 5x5x5 head of ddpm_res128 (Cout<=32)
 using Cfg_ABL1 = GCfg<128, 32, 4, 8, 8, 27, 1, 2, 4, 1, 1, 1>;
 using Cfg_ABL2 = GCfg<128, 32, 4, 8, 8, 27, 1, 2, 4, 1, 1, 2>;
 using Cfg_ABL3 = GCfg<128, 32, 4, 8, 8, 27, 1, 2, 4, 1, 1, 3>;
@@ -607,7 +611,7 @@ static int launch_cfg(const MdGemmConvArgs& a, hipStream_t stream) {
   if (a.kdim % C::KC != 0 || a.kdim <= 0) return MD_ERR_BAD_ARG;
   if (a.rows <= 0 || a.rows_alloc % 8 != 0 || a.batch <= 0) return MD_ERR_BAD_ARG;
   int tiles;
-  if (C::TAPS == 27) {
+  if (C::TAPS > 1) {
     if (a.D % C::TZ || a.H % C::TY || a.W % C::TX) return MD_ERR_BAD_ARG;
     if (a.ups && ((a.D | a.H | a.W) & 1)) return MD_ERR_BAD_ARG;
     if (a.ups && C::STRIDE != 1) return MD_ERR_BAD_ARG;
@@ -655,6 +659,8 @@ static void cfg_info(int32_t* nt, int32_t* kc, int32_t* cols, int32_t* taps, int
     case MD_CFG_C3_128_V3: F<Cfg_C3_128_V3>(__VA_ARGS__); break; \
     case MD_CFG_C3_128_V3B: F<Cfg_C3_128_V3B>(__VA_ARGS__); break; \
     case MD_CFG_C3_128_V4: F<Cfg_C3_128_V4>(__VA_ARGS__); break; \
+    case MD_CFG_C5_128_K16: F<Cfg_C5_128_K16>(__VA_ARGS__); break; \
+    case MD_CFG_C5_32_K16: F<Cfg_C5_32_K16>(__VA_ARGS__); break; \
     case 101: F<Cfg_ABL1>(__VA_ARGS__); break; \
     case 102: F<Cfg_ABL2>(__VA_ARGS__); break; \
     case 103: F<Cfg_ABL3>(__VA_ARGS__); break; \

@@ -10,7 +10,7 @@ import numpy as np
 import torch
 
 from . import losses, sampling, sde_lib
-from .models import ddpm_res64  # noqa: F401  (registers the model, like trainer.py:7 does in the reference)
+from .models import ddpm_res64, ddpm_res128  # noqa: F401  (registers the models, like trainer.py:7 in the reference)
 from .models import utils as mutils
 from .models.ema import ExponentialMovingAverage
 from .utils import restore_checkpoint

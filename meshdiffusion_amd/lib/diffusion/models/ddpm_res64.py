@@ -33,8 +33,12 @@ def _dense(in_dim, out_dim):
     return lin
 
 
-@utils.register_model(name="ddpm_res64")
-class DDPMRes64(layers.HipLayer):
+class DDPMUNet3D(layers.HipLayer):
+    """Shared U-Net body; the two registered models differ only in the three class attributes."""
+    KSIZE = 3            # stem / mask_layer / pos_layer / head kernel extent
+    USE_COORDS = True    # h0 += pos_layer(coords)
+    LEVEL0_BLOCKS = None  # None -> num_res_blocks
+
     def __init__(self, config):
         super().__init__()
         m = config.model
@@ -56,17 +60,20 @@ class DDPMRes64(layers.HipLayer):
             raise NotImplementedError("unconditional (no timestep) variant is not used by this path")
         block = lambda **kw: ResnetBlockDDPM(act=self.act, temb_dim=4 * nf, dropout=m.dropout, **kw)  # noqa: E731
 
+        ks = self.KSIZE
+        edge_conv = (lambda i, o, **kw: layers._conv(i, o, ks, 1, ks // 2, kw.get("init_scale", 1.0)))
         mods = [_dense(nf, 4 * nf), _dense(4 * nf, 4 * nf)]
         # constant inputs kept as (frozen) parameters because they are part of the checkpoint
-        self.coords = nn.Parameter(torch.zeros(1, 3, R, R, R), requires_grad=False)
+        if self.USE_COORDS:
+            self.coords = nn.Parameter(torch.zeros(1, 3, R, R, R), requires_grad=False)
         self.mask = nn.Parameter(torch.zeros(1, 1, R, R, R), requires_grad=False)
-        self.pos_layer = conv3x3(3, nf)
-        self.mask_layer = conv3x3(1, nf)
-        mods.append(conv3x3(channels, nf))
+        self.pos_layer = edge_conv(3, nf)
+        self.mask_layer = edge_conv(1, nf)
+        mods.append(edge_conv(channels, nf))
         skip_ch, in_ch = [nf], nf
         for lvl in range(nres):
             out_ch = nf * ch_mult[lvl]
-            for _ in range(nrb):
+            for _ in range(self._blocks_at(lvl)):
                 mods.append(block(in_ch=in_ch, out_ch=out_ch))
                 in_ch = out_ch
                 if all_res[lvl] in attn_res:
@@ -78,7 +85,7 @@ class DDPMRes64(layers.HipLayer):
         mods += [block(in_ch=in_ch), AttnBlock(channels=in_ch), block(in_ch=in_ch)]
         for lvl in reversed(range(nres)):
             out_ch = nf * ch_mult[lvl]
-            for _ in range(nrb + 1):
+            for _ in range(self._blocks_at(lvl) + 1):
                 mods.append(block(in_ch=in_ch + skip_ch.pop(), out_ch=out_ch))
                 in_ch = out_ch
             if all_res[lvl] in attn_res:
@@ -87,33 +94,45 @@ class DDPMRes64(layers.HipLayer):
                 mods.append(Upsample(channels=in_ch, with_conv=m.resamp_with_conv))
         assert not skip_ch
         mods.append(nn.GroupNorm(num_channels=in_ch, num_groups=32, eps=1e-6))
-        mods.append(conv3x3(in_ch, channels, init_scale=0.0))
+        mods.append(edge_conv(in_ch, channels, init_scale=0.0))
         self.all_modules = nn.ModuleList(mods)
         self.out_channels = channels
+
+    def _blocks_at(self, lvl):
+        return self.LEVEL0_BLOCKS if (lvl == 0 and self.LEVEL0_BLOCKS) else self.num_res_blocks
 
     # ---- cached, input-independent pieces --------------------------------------------------
     def _stem_const(self):
         """pos_layer(coords) + mask_layer(mask) (+ both biases) as one F32B [1][nf][P] tensor."""
-        ps = [self.coords, self.mask, self.pos_layer.weight, self.pos_layer.bias,
-              self.mask_layer.weight, self.mask_layer.bias]
+        ps = [self.mask, self.mask_layer.weight, self.mask_layer.bias]
+        if self.USE_COORDS:
+            ps += [self.coords, self.pos_layer.weight, self.pos_layer.bias]
 
         def build():
             R = self.img_size
-            dev = self.coords.device
-            cfg = ops.CFG_C3_128_K16
-            wp = ops.PackedWeight(self.pos_layer.weight, "conv", cfg, dev)
+            dev = self.mask.device
+            cfg = self._stem_cfg()
+            t = None
+            if self.USE_COORDS:
+                wp = ops.PackedWeight(self.pos_layer.weight, "conv", cfg, dev)
+                c16 = ops.ncdhw_to_s16b(self.coords.detach(), 16)
+                t = layers.run_conv3(wp, c16, 1, R, bias=self.pos_layer.bias)
             wm = ops.PackedWeight(self.mask_layer.weight, "conv", cfg, dev)
-            c16 = ops.ncdhw_to_s16b(self.coords.detach(), 16)
             m16 = ops.ncdhw_to_s16b(self.mask.detach(), 16)
-            t = layers.run_conv3(wp, c16, 1, R, bias=self.pos_layer.bias)
             return layers.run_conv3(wm, m16, 1, R, bias=self.mask_layer.bias, residual=t)
 
         return self._cached("stem_const", ps, build)
 
+    def _stem_cfg(self):
+        return ops.CFG_C3_128_K16 if self.KSIZE == 3 else ops.CFG_C5_128_K16
+
+    def _head_cfg(self):
+        return ops.CFG_C3_32 if self.KSIZE == 3 else ops.CFG_C5_32_K16
+
     # ---- forward ------------------------------------------------------------------------------
     def forward(self, x, labels):
         if not x.is_cuda:
-            raise RuntimeError("DDPMRes64 (meshdiffusion_amd) runs on the GPU only: no CPU fallback")
+            raise RuntimeError(f"{type(self).__name__} (meshdiffusion_amd) runs on the GPU only: no CPU fallback")
         if torch.is_grad_enabled() and self.training:
             raise NotImplementedError("autograd/backward through the HIP U-Net is not implemented yet; "
                                       "call under torch.no_grad() in eval mode")
@@ -129,12 +148,12 @@ class DDPMRes64(layers.HipLayer):
         h_in = x if self.centered else 2 * x - 1.0
         stem = mods[i]; i += 1
         x16 = ops.ncdhw_to_s16b(h_in, 16)
-        pw = layers.conv3_packed(self, "stem", stem, ops.CFG_C3_128_K16)
+        pw = layers.conv3_packed(self, "stem", stem, self._stem_cfg())
         h = layers.run_conv3(pw, x16, B, R, bias=stem.bias, residual=self._stem_const(), res_bstride=0)
 
         hs = [(h, self.nf, P)]
         for lvl in range(self.num_resolutions):
-            for _ in range(self.num_res_blocks):
+            for _ in range(self._blocks_at(lvl)):
                 t, c, p = hs[-1]
                 h = mods[i].forward_blocked([(t, c)], B, p, temb); c = mods[i].out_ch; i += 1
                 if self.all_resolutions[lvl] in self.attn_resolutions:
@@ -150,7 +169,7 @@ class DDPMRes64(layers.HipLayer):
         h = mods[i].forward_blocked([(h, c)], B, p, temb); i += 1
 
         for lvl in reversed(range(self.num_resolutions)):
-            for _ in range(self.num_res_blocks + 1):
+            for _ in range(self._blocks_at(lvl) + 1):
                 st, sc, sp = hs.pop()
                 assert sp == p
                 h = mods[i].forward_blocked([(h, c), (st, sc)], B, p, temb); c = mods[i].out_ch; i += 1
@@ -166,9 +185,15 @@ class DDPMRes64(layers.HipLayer):
         head = mods[i]; i += 1
         assert i == len(mods)
         out = torch.empty((B, self.out_channels, R, R, R), dtype=torch.float32, device=x.device)
-        pw = layers.conv3_packed(self, "head", head, ops.CFG_C3_32)
+        pw = layers.conv3_packed(self, "head", head, self._head_cfg())
         layers.run_conv3(pw, a, B, R, bias=head.bias, out=out, out_mode=ops.OUT_NCDHW, rows_alloc=8)
 
         if self.scale_by_sigma:
             out = out / self.sigmas[labels.long(), None, None, None, None].to(out.dtype)
         return out
+
+
+@utils.register_model(name="ddpm_res64")
+class DDPMRes64(DDPMUNet3D):
+    """lib/diffusion/models/ddpm_res64.py: 3x3x3 stem/head, `coords` positional input."""
+    KSIZE, USE_COORDS, LEVEL0_BLOCKS = 3, True, None

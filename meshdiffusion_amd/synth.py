@@ -23,10 +23,20 @@ def small_config(image_size=16, nf=32, ch_mult=(1, 2, 2), num_res_blocks=1, attn
     return c
 
 
+def small_config_res128(image_size=16, nf=32, ch_mult=(1, 2, 2), num_res_blocks=1, attn_resolutions=(8,)):
+    """Same idea for the res128 architecture (5x5x5 stem/head, no coords, 2 blocks at level 0)."""
+    c = small_config(image_size, nf, ch_mult, num_res_blocks, attn_resolutions)
+    c.model.name = "ddpm_res128"
+    return c
+
+
 def oracle_cfg(config):
     m = config.model
-    return dict(nf=m.nf, ch_mult=tuple(m.ch_mult), num_res_blocks=m.num_res_blocks,
-                attn_resolutions=tuple(m.attn_resolutions), image_size=config.data.image_size)
+    out = dict(nf=m.nf, ch_mult=tuple(m.ch_mult), num_res_blocks=m.num_res_blocks,
+               attn_resolutions=tuple(m.attn_resolutions), image_size=config.data.image_size)
+    if m.name.startswith("ddpm_res128"):
+        out["level0_blocks"] = 2
+    return out
 
 
 def _gen(seed, key):

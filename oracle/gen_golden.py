@@ -51,7 +51,7 @@ def import_reference():
         torch.Tensor.cuda = lambda self, *a, **k: self  # sde_lib.py / sampling.py hard-code .cuda()
     sys.path.insert(0, REF)
     from lib.diffusion import sampling as rsampling, sde_lib as rsde  # noqa: E402
-    from lib.diffusion.models import ddpm_res64 as rmodel, utils as rmutils  # noqa: F401,E402
+    from lib.diffusion.models import ddpm_res64 as rmodel, ddpm_res128 as rmodel128, utils as rmutils  # noqa: F401,E402
     return rsampling, rsde, rmutils
 
 
@@ -64,7 +64,7 @@ def ref_model(rmutils, config, sd):
 
 def make_sd(config, R, seed=1234):
     # template shapes from OUR module tree (identical keys/shapes are asserted by strict load above)
-    from meshdiffusion_amd.lib.diffusion.models import ddpm_res64, utils as mutils  # noqa: F401
+    from meshdiffusion_amd.lib.diffusion.models import ddpm_res64, ddpm_res128, utils as mutils  # noqa: F401
     c = ConfigDict(config)
     tmpl = mutils.create_model(c, use_parallel=False).state_dict()
     return synth.sensitised_state_dict(tmpl, seed=seed, grid_mask=synth.synthetic_grid_mask(R))
@@ -138,6 +138,21 @@ def gen_unet_and_sampler(skip_res64):
                                  cond=(partial, pmask, 4))
         np.savez_compressed(os.path.join(GOLD, "sampler_small.npz"), uncond=xm_ref.numpy(), cond=xc_ref.numpy(),
                             K=K, uncond_seed=77, cond_seed=78, cond_data_seed=5, freeze_iters=4)
+
+        # ---------------- res128 architecture, small config ----------------
+        cfg = synth.small_config_res128(); cfg.device = torch.device("cpu")
+        R = cfg.data.image_size
+        sd = make_sd(cfg, R, seed=4321)
+        model = ref_model(rmutils, cfg, sd)
+        x = synth.synthetic_inputs(2, 4, R, seed=44)
+        labels = torch.tensor([700.1, 3.3])
+        y_ref = model(x, labels)
+        y_or = unet_oracle.unet_res64_forward(sd, synth.oracle_cfg(cfg), x, labels)
+        e = rel_l2(y_or, y_ref)
+        print(f"[small res128] oracle vs reference U-Net rel-L2 = {e:.3e}; out std {float(y_ref.std()):.3f}")
+        assert e < 1e-5
+        np.savez_compressed(os.path.join(GOLD, "unet_small_res128.npz"), y=y_ref.numpy(), labels=labels.numpy(),
+                            x_seed=44, sd_seed=4321)
 
         if skip_res64:
             return

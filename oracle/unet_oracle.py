@@ -89,10 +89,12 @@ def upsample(p, x):
 
 
 def unet_res64_forward(sd, cfg, x, labels):
-    """lib/diffusion/models/ddpm_res64.py:126-199 driven by a state dict.
+    """lib/diffusion/models/ddpm_res64.py:126-199 and ddpm_res128.py:137-215 driven by a state dict.
 
-    cfg: dict(nf, ch_mult, num_res_blocks, attn_resolutions, image_size); sd keys may carry a
-    leading 'module.' (DataParallel) prefix.
+    cfg: dict(nf, ch_mult, num_res_blocks, attn_resolutions, image_size[, level0_blocks]); sd keys may
+    carry a leading 'module.' (DataParallel) prefix.  The res128 variant is recognised from the state
+    dict itself: 5x5x5 stem/head weights (padding = k//2), no `coords` entry (ddpm_res128.py:77,162),
+    and `level0_blocks` = 2 (ddpm_res128.py:98,118).
     """
     if any(k.startswith("module.") for k in sd):
         sd = {k[len("module."):]: v for k, v in sd.items()}
@@ -101,16 +103,19 @@ def unet_res64_forward(sd, cfg, x, labels):
     nf, ch_mult, nrb = cfg["nf"], cfg["ch_mult"], cfg["num_res_blocks"]
     attn_res, R = cfg["attn_resolutions"], cfg["image_size"]
     nres = len(ch_mult)
+    blocks_at = lambda lvl: cfg.get("level0_blocks") or nrb if lvl == 0 else nrb  # noqa: E731
     i = 0
     temb = timestep_embedding(labels, nf)
     temb = F.linear(temb, mod(i)["weight"], mod(i)["bias"]); i += 1
     temb = F.linear(F.silu(temb), mod(i)["weight"], mod(i)["bias"]); i += 1
-    h0 = F.conv3d(x, mod(i)["weight"], mod(i)["bias"], padding=1); i += 1
-    h0 = h0 + F.conv3d(sd["coords"], sd["pos_layer.weight"], sd["pos_layer.bias"], padding=1) \
-            + F.conv3d(sd["mask"], sd["mask_layer.weight"], sd["mask_layer.bias"], padding=1)
+    pad = mod(i)["weight"].shape[-1] // 2
+    h0 = F.conv3d(x, mod(i)["weight"], mod(i)["bias"], padding=pad); i += 1
+    if "coords" in sd:
+        h0 = h0 + F.conv3d(sd["coords"], sd["pos_layer.weight"], sd["pos_layer.bias"], padding=pad)
+    h0 = h0 + F.conv3d(sd["mask"], sd["mask_layer.weight"], sd["mask_layer.bias"], padding=pad)
     hs = [h0]
     for lvl in range(nres):
-        for _ in range(nrb):
+        for _ in range(blocks_at(lvl)):
             h = resnet_block(mod(i), hs[-1], temb); i += 1
             if h.shape[-1] in attn_res:
                 h = attn_block(mod(i), h); i += 1
@@ -122,7 +127,7 @@ def unet_res64_forward(sd, cfg, x, labels):
     h = attn_block(mod(i), h); i += 1
     h = resnet_block(mod(i), h, temb); i += 1
     for lvl in reversed(range(nres)):
-        for _ in range(nrb + 1):
+        for _ in range(blocks_at(lvl) + 1):
             h = resnet_block(mod(i), torch.cat([h, hs.pop()], dim=1), temb); i += 1
         if h.shape[-1] in attn_res:
             h = attn_block(mod(i), h); i += 1
@@ -130,7 +135,7 @@ def unet_res64_forward(sd, cfg, x, labels):
             h = upsample(mod(i), h); i += 1
     assert not hs
     h = F.silu(group_norm(h, mod(i)["weight"], mod(i)["bias"])); i += 1
-    h = F.conv3d(h, mod(i)["weight"], mod(i)["bias"], padding=1); i += 1
+    h = F.conv3d(h, mod(i)["weight"], mod(i)["bias"], padding=mod(i)["weight"].shape[-1] // 2); i += 1
     assert f"all_modules.{i}.weight" not in sd
     return h
 

@@ -157,6 +157,25 @@ def test_conv3_stem_and_head(ops):
     assert rel_l2(o.cpu(), F.conv3d(xh, wh, bh, padding=1)) < TOL_MFMA
 
 
+def test_conv5_stem_and_head(ops):
+    """5x5x5 / pad 2 convolutions of ddpm_res128 (stem: Cin 4 -> 128; head: 64 -> 4 straight to NCDHW)."""
+    S = 8
+    x = _rand((2, 4, S, S, S), 50); w = _rand((128, 4, 5, 5, 5), 51, 0.05); b = _rand((128,), 52)
+    x16 = ops.ncdhw_to_s16b(x.cuda(), 16)
+    pw = ops.PackedWeight(w.cuda(), "conv", ops.CFG_C5_128_K16, "cuda")
+    out = ops.f32b_empty(2, 128, S ** 3, "cuda")
+    ops.gemm_conv(cfg=ops.CFG_C5_128_K16, a=pw.data, b=x16, out=out, batch=2, rows=128, rows_alloc=128,
+                  kdim=16, dims=(S, S, S), bias=b.cuda())
+    assert rel_l2(ops.f32b_to_ncdhw(out, (S, S, S)).cpu(), F.conv3d(x, w, b, padding=2)) < TOL_MFMA
+    xh = _rand((2, 64, S, S, S), 53); wh = _rand((4, 64, 5, 5, 5), 54, 0.03); bh = _rand((4,), 55)
+    s, _, _ = _to_s16(ops, xh)
+    pwh = ops.PackedWeight(wh.cuda(), "conv", ops.CFG_C5_32_K16, "cuda")
+    o = torch.empty((2, 4, S, S, S), device="cuda")
+    ops.gemm_conv(cfg=ops.CFG_C5_32_K16, a=pwh.data, b=s, out=o, batch=2, rows=4, rows_alloc=8, kdim=64, dims=(S, S, S),
+                  bias=bh.cuda(), out_mode=ops.OUT_NCDHW)
+    assert rel_l2(o.cpu(), F.conv3d(xh, wh, bh, padding=2)) < TOL_MFMA
+
+
 @pytest.mark.parametrize("P,cin,cout,cfg_name", [(512, 64, 128, "CFG_G1_128"), (64, 96, 128, "CFG_G1_128_LOW"),
                                                  (64, 64, 64, "CFG_G1_64_LOW")])
 def test_nin_gemm_and_s16b_out(ops, P, cin, cout, cfg_name):
