@@ -42,6 +42,9 @@ def parse():
     ap.add_argument("--batch", type=int, default=8, help="samples per GPU (configs[1]: 8)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "fp16x2"],
+                    help="arithmetic of the hot conv kernel for the headline number (DESIGN.md section 3)")
+    ap.add_argument("--no-fast-mode", action="store_true", help="skip the extra fp16x2 measurement")
     return ap.parse_args()
 
 
@@ -69,6 +72,7 @@ def main():
 
     cfg = get_config_res64()
     cfg.device = dev
+    cfg.model.hip_precision = a.precision
     cfg.eval.batch_size = a.batch
     R, B = cfg.data.image_size, a.batch
     t_setup = time.time()
@@ -107,6 +111,28 @@ def main():
     events, hip_ops.PROFILE = hip_ops.PROFILE, None
     assert bool(torch.isfinite(xm).all()), "non-finite samples"
 
+    # ---- optional second measurement: the opt-in fp16x2 arithmetic on the same workload ----
+    fast = None
+    if a.precision == "bf16x3" and not a.no_fast_mode and world == 1:
+        model.module.hip_precision = "fp16x2"
+        with torch.no_grad():
+            xf = stepper.prior()
+            for k in range(max(a.warmup, 1)):
+                xf, _ = stepper.step(model_fn, xf, k)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for k in range(a.steps):
+                xf, xmf = stepper.step(model_fn, xf, a.warmup + k)
+            torch.cuda.synchronize()
+            wf = time.perf_counter() - t1
+        model.module.hip_precision = a.precision
+        hip_ops.set_precision(a.precision)
+        fast = {"precision": "fp16x2 (weights split fp16, activations fp16, 2 MFMAs/product; opt-in: "
+                             "config.model.hip_precision)", "value": round(B * a.steps / wf, 3),
+                "unit": "sample-steps/s", "ms_per_step": round(wf / a.steps * 1e3, 3),
+                "parity": "999-step sampled grids 6.9e-5 rel-L2 vs fp32 (profiles/r01_longrun_999step_act_fp16_experiment.json); "
+                          "~1e-3 per U-Net evaluation"}
+
     wall_t = torch.tensor([wall], dtype=torch.float64, device=dev)
     if dist is not None:
         dist.all_reduce(wall_t, op=dist.ReduceOp.MAX)
@@ -144,12 +170,13 @@ def main():
             "metric": "denoise steps/sec on 64^3x4 DMTet grids (sample-steps/s = n_gpus*batch*steps/wall)",
             "value": round(value, 3), "unit": "sample-steps/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "bf16x3 (split-bf16 MFMA operands, fp32 accumulate/IO)",
+            "scaling": "weak", "vs_baseline": None, "dtype": ("bf16x3 (split-bf16 MFMA operands, fp32 accumulate/IO)" if a.precision == "bf16x3" else
+                                           "fp16x2 (weights split fp16, activations fp16, fp32 accumulate/IO)"),
             "data": "synthetic (seeded prior noise, sensitised random-init res64 weights, synthetic grid mask)",
             "config": {"workload": "BASELINE configs[1]: res64 4-ch grid DDPM ancestral sampling steps, batch=8 per GPU",
                        "batch_per_gpu": B, "grid": [cfg.data.num_channels, R, R, R],
                        "sharding": "independent sample shards per GPU, no data-path collective"},
-            "roofline": roof, "whole_step": whole, "cpu_baseline": cpu, "setup_s": round(t_setup, 1),
+            "roofline": roof, "whole_step": whole, "cpu_baseline": cpu, "fast_mode": fast, "setup_s": round(t_setup, 1),
         }
         print(json.dumps(line), flush=True)
     if dist is not None:

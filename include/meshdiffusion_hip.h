@@ -64,6 +64,10 @@ enum {
 
 enum { MD_OUT_F32B = 0, MD_OUT_S16B = 1, MD_OUT_NCDHW = 2 };
 enum { MD_A_PACKED = 0, MD_A_S16B = 1 };
+/* MD_PREC_BF16X3: both operands split bf16 (hi, lo), 3 MFMAs per product (default, ~1e-5 per U-Net eval).
+ * MD_PREC_FP16X2: weights split fp16 (hi, lo), activations ONE fp16 (plane 0 only), 2 MFMAs per product
+ *                 (~1e-3 per eval, 7e-5 after 999 sampler steps; MD_CFG_C3_128_FAST only). */
+enum { MD_PREC_BF16X3 = 0, MD_PREC_FP16X2 = 1 };
 
 /*
  * md_gemm_conv: out[b][i][j] = alpha * sum_{tap,k} A[i][tap][k] * B[b][k][pos_j + tap]
@@ -103,7 +107,7 @@ typedef struct MdGemmConvArgs {
   int64_t b_bstride;     /* elements (bf16) between batches of B; 0 = shared                   */
   float* partial;        /* ksplit>1: fp32 workspace [ksplit][B][rows_alloc/8][P][8]            */
   int32_t ksplit;        /* split the K-chunk loop over this many workgroups (grid.z); 0/1 = off */
-  int32_t reserved0;
+  int32_t prec;          /* MD_PREC_*: operand format of A (weights) and B (activations)        */
 } MdGemmConvArgs;
 
 int md_abi_version(void);
@@ -126,7 +130,7 @@ int md_gemm_conv_cfg_info(int32_t cfg, int32_t* nt, int32_t* kc, int32_t* cols,
  */
 int md_pack_weights(const float* w, void* wpk, int32_t rows, int32_t kdim, int32_t taps,
                     int64_t s_row, int64_t s_k, int64_t s_tap, int32_t nt, int32_t kc,
-                    void* stream);
+                    int32_t prec, void* stream);
 int64_t md_packed_weight_bytes(int32_t rows, int32_t kdim, int32_t taps, int32_t nt, int32_t kc);
 
 /*
@@ -143,6 +147,8 @@ int64_t md_packed_weight_bytes(int32_t rows, int32_t kdim, int32_t taps, int32_t
  * md_gn_apply : y = (x-mean)*rstd*gamma + beta (norm=1) ; y = silu(y) (silu=1); writes the
  *               split-bf16 S16B tensor out[B][c_total/8][2][P][8] at c_off.
  *               norm=0 copies/splits raw x (used for the NIN shortcut input).
+ *               `silu` is a bit field: 1 = apply SiLU, 4 = MD_PREC_FP16X2 output (plane 0 = fp16(y),
+ *               plane 1 not written), 2 = debug: round y to fp16 before the bf16 split.
  */
 int md_gn_stats(const float* x, double* sums, int32_t batch, int32_t C, int64_t P,
                 int32_t c_total, int32_t c_off, void* stream);

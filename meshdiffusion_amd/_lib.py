@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libmeshdiffusion_hip.so")
 (CFG_C3_128, CFG_C3_128_K16, CFG_C3_32, CFG_C3_LOW, CFG_C3_S2, CFG_G1_128, CFG_G1_128_LOW, CFG_G1_64_LOW,
  CFG_C3_128_V2, CFG_C3_128_SW, CFG_C3_128_PIPE, CFG_C3_128_V3, CFG_C3_128_V3B, CFG_C3_128_V4, CFG_C3_128_FAST, CFG_C5_128_K16, CFG_C5_32_K16) = range(17)
 OUT_F32B, OUT_S16B, OUT_NCDHW = 0, 1, 2
+PREC_BF16X3, PREC_FP16X2 = 0, 1
 A_PACKED, A_S16B = 0, 1
 
 # (NT, KC) of each cfg -- must match csrc/gemm_conv.hip; checked against the library at load.
@@ -33,7 +34,7 @@ class MdGemmConvArgs(C.Structure):
         ("rows", C.c_int32), ("rows_alloc", C.c_int32), ("kdim", C.c_int32), ("D", C.c_int32),
         ("H", C.c_int32), ("W", C.c_int32), ("ups", C.c_int32), ("a_src", C.c_int32),
         ("out_mode", C.c_int32), ("a_rows", C.c_int32), ("a_bstride", C.c_int64),
-        ("bias_bstride", C.c_int64), ("res_bstride", C.c_int64), ("b_bstride", C.c_int64), ("partial", C.c_void_p), ("ksplit", C.c_int32), ("reserved0", C.c_int32),
+        ("bias_bstride", C.c_int64), ("res_bstride", C.c_int64), ("b_bstride", C.c_int64), ("partial", C.c_void_p), ("ksplit", C.c_int32), ("prec", C.c_int32),
     ]
 
 
@@ -46,7 +47,7 @@ SIGNATURES = {
     "md_gemm_conv": (C.c_int, [C.POINTER(MdGemmConvArgs), _P]),
     "md_gemm_conv_partial_bytes": (_I64, [C.POINTER(MdGemmConvArgs)]),
     "md_gemm_conv_cfg_info": (C.c_int, [_I32] + [C.POINTER(C.c_int32)] * 6),
-    "md_pack_weights": (C.c_int, [_P, _P, _I32, _I32, _I32, _I64, _I64, _I64, _I32, _I32, _P]),
+    "md_pack_weights": (C.c_int, [_P, _P, _I32, _I32, _I32, _I64, _I64, _I64, _I32, _I32, _I32, _P]),
     "md_packed_weight_bytes": (_I64, [_I32, _I32, _I32, _I32, _I32]),
     "md_gn_stats": (C.c_int, [_P, _P, _I32, _I32, _I64, _I32, _I32, _P]),
     "md_gn_finalize": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _I64, _F, _P]),

@@ -38,9 +38,14 @@ __device__ __forceinline__ int slot_of(int hz, int hy, int hx) {
 
 // ABL: timing-only ablations (results invalid): 1 = no LDS fragment reads, 3 = no barriers / weight commits,
 // 4 = no weight global loads, 6 = no barriers only; 7 = (valid results) no MFMA/DS interleave hint
-template <int ABL>
+// PREC: MD_PREC_BF16X3 (both operands split bf16, 3 MFMAs/product) or MD_PREC_FP16X2 (weights split fp16,
+// activations one fp16 plane, 2 MFMAs/product; the halo tile then has one plane and half the LDS/L2 traffic).
+template <int ABL, int PREC>
 __global__ __launch_bounds__(NTHREADS) void md_conv3_main_kernel(const MdGemmConvArgs A) {
-  __shared__ __attribute__((aligned(16))) uint4 smem[LDS_ITEMS];
+  constexpr int PL = (PREC == MD_PREC_FP16X2) ? 1 : 2;        // activation planes staged in LDS
+  constexpr int A_ITEMS_P = KG * PL * HPOS;
+  constexpr int A_PT = (A_ITEMS_P + NTHREADS - 1) / NTHREADS;  // halo items per thread (10 or 5)
+  __shared__ __attribute__((aligned(16))) uint4 smem[2 * W_ITEMS + KG * PL * HS];
   unsigned char* lds = (unsigned char*)smem;
 
   const int tid = threadIdx.x;
@@ -75,13 +80,14 @@ __global__ __launch_bounds__(NTHREADS) void md_conv3_main_kernel(const MdGemmCon
 
   // ---- halo prefetch descriptors: computed ONCE (source offset in uint4 units relative to the chunk
   //      base, -1 = outside the grid => zero fill; LDS destination byte offset) ---------------------
-  int hsrc[A_PER_THREAD], hdst[A_PER_THREAD];
+  int hsrc[A_PT], hdst[A_PT];
 #pragma unroll
-  for (int i = 0; i < A_PER_THREAD; ++i) {
+  for (int i = 0; i < A_PT; ++i) {
     const int item = tid + i * NTHREADS;
     hsrc[i] = -1; hdst[i] = -1;
-    if (item < A_ITEMS) {
-      const int gp = item / HPOS, r = item % HPOS;
+    if (item < A_ITEMS_P) {
+      const int gl = item / HPOS, r = item % HPOS;      // LDS plane index: (g*PL + part)
+      const int gp = (PL == 2) ? gl : gl * 2;            // global plane index: (g*2 + part); fp16x2 reads hi only
       const int hx = r % XH, hy = (r / XH) % YH, hz = r / (XH * YH);
       int uz = z0 + hz - 1, uy = y0 + hy - 1, ux = x0 + hx - 1;
       bool inb;
@@ -91,15 +97,15 @@ __global__ __launch_bounds__(NTHREADS) void md_conv3_main_kernel(const MdGemmCon
       } else {
         inb = (uz >= 0) & (uz < Di) & (uy >= 0) & (uy < Hi) & (ux >= 0) & (ux < Wi);
       }
-      hdst[i] = W_LDS_BYTES + (gp * HS + slot_of(hz, hy, hx)) * 16;
+      hdst[i] = W_LDS_BYTES + (gl * HS + slot_of(hz, hy, hx)) * 16;
       if (inb) hsrc[i] = (int)(gp * Pin + ((int64_t)uz * Hi + uy) * Wi + ux);
     }
   }
-  uint4 hreg[A_PER_THREAD];
+  uint4 hreg[A_PT];
   auto act_issue = [&](int cc) {
     const uint4* cb = bptr + (int64_t)cc * (KG * 2) * Pin;  // scalar chunk base
 #pragma unroll
-    for (int i = 0; i < A_PER_THREAD; ++i) {
+    for (int i = 0; i < A_PT; ++i) {
       uint4 v = make_uint4(0, 0, 0, 0);
       if (hsrc[i] >= 0) v = cb[hsrc[i]];
       hreg[i] = v;
@@ -107,7 +113,7 @@ __global__ __launch_bounds__(NTHREADS) void md_conv3_main_kernel(const MdGemmCon
   };
   auto act_commit = [&]() {
 #pragma unroll
-    for (int i = 0; i < A_PER_THREAD; ++i)
+    for (int i = 0; i < A_PT; ++i)
       if (hdst[i] >= 0) *(uint4*)(lds + hdst[i]) = hreg[i];
   };
 
@@ -116,7 +122,7 @@ __global__ __launch_bounds__(NTHREADS) void md_conv3_main_kernel(const MdGemmCon
   const int vA = (h * 2 * NT + wr * 64 + j) * 16;
   // halo     [KG][2][HS][8]: byte = W_LDS_BYTES + ((ks*2+h)*2+part)*HS*16 + slot*16,
   //          slot = zterm(z+dz) + (y+dy)*24 + (x+dx),  y = cm*4 + (j>>3), x = j&7, z = wc
-  const int laneB = W_LDS_BYTES + (h * 2 * HS + (j >> 3) * 24 + (j & 7)) * 16;
+  const int laneB = W_LDS_BYTES + (h * PL * HS + (j >> 3) * 24 + (j & 7)) * 16;
   int vB[3];
 #pragma unroll
   for (int dz = 0; dz < 3; ++dz) {
@@ -177,16 +183,27 @@ __global__ __launch_bounds__(NTHREADS) void md_conv3_main_kernel(const MdGemmCon
   }                                                                                          \
   if constexpr (ABL != 1)                                                                    \
   _Pragma("unroll") for (int cm = 0; cm < 2; ++cm) {                                         \
-    F.bhi[cm] = *(const bf16x8*)((PB) + (((KS) * 4 + 0) * HS + cm * 4 * 24) * 16);           \
-    F.blo[cm] = *(const bf16x8*)((PB) + (((KS) * 4 + 1) * HS + cm * 4 * 24) * 16);           \
+    F.bhi[cm] = *(const bf16x8*)((PB) + (((KS) * 2 * PL + 0) * HS + cm * 4 * 24) * 16);      \
+    if constexpr (PL == 2)                                                                   \
+      F.blo[cm] = *(const bf16x8*)((PB) + (((KS) * 2 * PL + 1) * HS + cm * 4 * 24) * 16);    \
   }
+#define MD_MFMA_BF16(a_, b_, c_) c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_, b_, c_, 0, 0, 0)
+#define MD_MFMA_F16(a_, b_, c_) \
+  c_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a_), __builtin_bit_cast(f16x8, b_), c_, 0, 0, 0)
 #define MD_MMA(F)                                                                                            \
-  _Pragma("unroll") for (int rm = 0; rm < 2; ++rm) _Pragma("unroll") for (int cm = 0; cm < 2; ++cm)          \
-    acc[rm][cm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.alo[rm], F.bhi[cm], acc[rm][cm], 0, 0, 0);       \
-  _Pragma("unroll") for (int rm = 0; rm < 2; ++rm) _Pragma("unroll") for (int cm = 0; cm < 2; ++cm)          \
-    acc[rm][cm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.ahi[rm], F.blo[cm], acc[rm][cm], 0, 0, 0);       \
-  _Pragma("unroll") for (int rm = 0; rm < 2; ++rm) _Pragma("unroll") for (int cm = 0; cm < 2; ++cm)          \
-    acc[rm][cm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.ahi[rm], F.bhi[cm], acc[rm][cm], 0, 0, 0);
+  if constexpr (PL == 2) {                                                                                   \
+    _Pragma("unroll") for (int rm = 0; rm < 2; ++rm) _Pragma("unroll") for (int cm = 0; cm < 2; ++cm)        \
+      MD_MFMA_BF16(F.alo[rm], F.bhi[cm], acc[rm][cm]);                                                       \
+    _Pragma("unroll") for (int rm = 0; rm < 2; ++rm) _Pragma("unroll") for (int cm = 0; cm < 2; ++cm)        \
+      MD_MFMA_BF16(F.ahi[rm], F.blo[cm], acc[rm][cm]);                                                       \
+    _Pragma("unroll") for (int rm = 0; rm < 2; ++rm) _Pragma("unroll") for (int cm = 0; cm < 2; ++cm)        \
+      MD_MFMA_BF16(F.ahi[rm], F.bhi[cm], acc[rm][cm]);                                                       \
+  } else {                                                                                                   \
+    _Pragma("unroll") for (int rm = 0; rm < 2; ++rm) _Pragma("unroll") for (int cm = 0; cm < 2; ++cm)        \
+      MD_MFMA_F16(F.alo[rm], F.bhi[cm], acc[rm][cm]);                                                        \
+    _Pragma("unroll") for (int rm = 0; rm < 2; ++rm) _Pragma("unroll") for (int cm = 0; cm < 2; ++cm)        \
+      MD_MFMA_F16(F.ahi[rm], F.bhi[cm], acc[rm][cm]);                                                        \
+  }
 
   // All wavefronts run the same code in step, so a block of 8 back-to-back ds_read_b128 per wave arrives at
   // the LDS as a 64-instruction burst and every wave's (in-order) MFMA issue stalls behind its own queued
@@ -194,8 +211,8 @@ __global__ __launch_bounds__(NTHREADS) void md_conv3_main_kernel(const MdGemmCon
   // groups so each read is issued in the shadow of the previous MFMA.
 #define MD_INTERLEAVE()                                                  \
   if constexpr (ABL != 7) {                                              \
-    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                   \
-      __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);                 \
+    _Pragma("unroll") for (int i_ = 0; i_ < (PL == 2 ? 4 : 3); ++i_) {   \
+      __builtin_amdgcn_sched_group_barrier(0x008, (PL == 2 ? 3 : 3), 0); \
       __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                 \
     }                                                                    \
   }
@@ -253,6 +270,8 @@ __global__ __launch_bounds__(NTHREADS) void md_conv3_main_kernel(const MdGemmCon
   }
 #undef MD_LOAD_FRAGS
 #undef MD_MMA
+#undef MD_MFMA_BF16
+#undef MD_MFMA_F16
 #undef MD_INTERLEAVE
 
   // ---- epilogue: bias + residual loads batched, 16-byte stores into the F32B layout -------------------
@@ -324,14 +343,20 @@ int md_launch_conv3_main(const MdGemmConvArgs& a, hipStream_t stream) {
   if (ks > 1 && (a.partial == nullptr || ks > a.kdim / KC)) return MD_ERR_BAD_ARG;
   dim3 grid((unsigned)(tiles * a.batch), (unsigned)((a.rows + NT - 1) / NT), (unsigned)ks);
   MD_HIP_CLEAR_ERROR();
-  switch (a.cfg) {
-    case 111: hipLaunchKernelGGL(md_conv3_main_kernel<1>, grid, dim3(NTHREADS), 0, stream, a); break;
-    case 113: hipLaunchKernelGGL(md_conv3_main_kernel<3>, grid, dim3(NTHREADS), 0, stream, a); break;
-    case 114: hipLaunchKernelGGL(md_conv3_main_kernel<4>, grid, dim3(NTHREADS), 0, stream, a); break;
-    case 116: hipLaunchKernelGGL(md_conv3_main_kernel<6>, grid, dim3(NTHREADS), 0, stream, a); break;
-    case 117: hipLaunchKernelGGL(md_conv3_main_kernel<7>, grid, dim3(NTHREADS), 0, stream, a); break;
-    case 118: hipLaunchKernelGGL(md_conv3_main_kernel<8>, grid, dim3(NTHREADS), 0, stream, a); break;
-    default: hipLaunchKernelGGL(md_conv3_main_kernel<0>, grid, dim3(NTHREADS), 0, stream, a); break;
+  if (a.prec == MD_PREC_FP16X2) {
+    hipLaunchKernelGGL((md_conv3_main_kernel<0, MD_PREC_FP16X2>), grid, dim3(NTHREADS), 0, stream, a);
+  } else if (a.prec != MD_PREC_BF16X3) {
+    return MD_ERR_BAD_ARG;
+  } else {
+    switch (a.cfg) {
+      case 111: hipLaunchKernelGGL((md_conv3_main_kernel<1, 0>), grid, dim3(NTHREADS), 0, stream, a); break;
+      case 113: hipLaunchKernelGGL((md_conv3_main_kernel<3, 0>), grid, dim3(NTHREADS), 0, stream, a); break;
+      case 114: hipLaunchKernelGGL((md_conv3_main_kernel<4, 0>), grid, dim3(NTHREADS), 0, stream, a); break;
+      case 116: hipLaunchKernelGGL((md_conv3_main_kernel<6, 0>), grid, dim3(NTHREADS), 0, stream, a); break;
+      case 117: hipLaunchKernelGGL((md_conv3_main_kernel<7, 0>), grid, dim3(NTHREADS), 0, stream, a); break;
+      case 118: hipLaunchKernelGGL((md_conv3_main_kernel<8, 0>), grid, dim3(NTHREADS), 0, stream, a); break;
+      default: hipLaunchKernelGGL((md_conv3_main_kernel<0, 0>), grid, dim3(NTHREADS), 0, stream, a); break;
+    }
   }
   MD_HIP_CHECK_LAUNCH();
   if (ks > 1) return md_launch_splitk_reduce(a, stream);

@@ -621,6 +621,7 @@ static int launch_cfg(const MdGemmConvArgs& a, hipStream_t stream) {
     tiles = a.W / C::MT;
   }
   if (a.a_src == MD_A_S16B && a.a_rows <= 0) return MD_ERR_BAD_ARG;
+  if (a.prec != MD_PREC_BF16X3) return MD_ERR_UNSUPPORTED;  // fp16x2 lives in the dedicated conv kernel only
   if (C::PIPE == 2 && a.a_src != MD_A_PACKED) return MD_ERR_UNSUPPORTED;
   const int row_tiles = (a.rows + C::NT - 1) / C::NT;
   const int ks = a.ksplit > 1 ? a.ksplit : 1;
@@ -691,7 +692,7 @@ extern "C" int md_gemm_conv_cfg_info(int32_t cfg, int32_t* nt, int32_t* kc, int3
 // ---- weight packing: fp32 -> WPK split-bf16 tiles ------------------------------------
 __global__ void md_pack_weights_kernel(const float* __restrict__ w, uint4* __restrict__ out,
                                        int rows, int kdim, int taps, int64_t s_row, int64_t s_k,
-                                       int64_t s_tap, int nt, int kc, int64_t n_items) {
+                                       int64_t s_tap, int nt, int kc, int64_t n_items, int prec) {
   const int kg = kc / 8;
   const int ncc = (kdim + kc - 1) / kc;
   for (int64_t item = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; item < n_items;
@@ -711,7 +712,7 @@ __global__ void md_pack_weights_kernel(const float* __restrict__ w, uint4* __res
       float x = 0.f;
       if (row < rows && k < kdim) x = w[row * s_row + k * s_k + tap * s_tap];
       uint32_t hi, lo;
-      md_split(x, hi, lo);
+      if (prec == MD_PREC_FP16X2) md_split_f16(x, hi, lo); else md_split(x, hi, lo);
       v[e] = part ? lo : hi;
     }
     out[item] = make_uint4(v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16),
@@ -728,15 +729,15 @@ extern "C" int64_t md_packed_weight_bytes(int32_t rows, int32_t kdim, int32_t ta
 
 extern "C" int md_pack_weights(const float* w, void* wpk, int32_t rows, int32_t kdim, int32_t taps,
                                int64_t s_row, int64_t s_k, int64_t s_tap, int32_t nt, int32_t kc,
-                               void* stream) {
+                               int32_t prec, void* stream) {
   const int64_t bytes = md_packed_weight_bytes(rows, kdim, taps, nt, kc);
-  if (bytes < 0 || w == nullptr || wpk == nullptr) return MD_ERR_BAD_ARG;
+  if (bytes < 0 || w == nullptr || wpk == nullptr || prec < 0 || prec > 1) return MD_ERR_BAD_ARG;
   const int64_t n_items = bytes / 16;
   int blocks = (int)((n_items + 255) / 256);
   if (blocks > 4096) blocks = 4096;
   MD_HIP_CLEAR_ERROR();
   hipLaunchKernelGGL(md_pack_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w,
-                     (uint4*)wpk, rows, kdim, taps, s_row, s_k, s_tap, nt, kc, n_items);
+                     (uint4*)wpk, rows, kdim, taps, s_row, s_k, s_tap, nt, kc, n_items, prec);
   MD_HIP_CHECK_LAUNCH();
   return MD_OK;
 }

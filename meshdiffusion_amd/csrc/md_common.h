@@ -1,6 +1,7 @@
 // Shared device helpers for the gfx950 kernels (wave64, CDNA4).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
 #include <stdint.h>
 #include "meshdiffusion_hip.h"
 
@@ -29,6 +30,19 @@ __device__ __forceinline__ float md_bf2f(uint32_t h) { return __uint_as_float(h 
 __device__ __forceinline__ void md_split(float x, uint32_t& hi, uint32_t& lo) {
   hi = md_f2bf(x);
   lo = md_f2bf(x - md_bf2f(hi));
+}
+
+// fp16x2 mode ("weights split, activations single"): w ~= hi + lo with hi = fp16(w), lo = fp16(w - hi);
+// activations are one fp16 (saturated to the finite range).
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ uint32_t md_f2h(float f) {
+  f = fminf(fmaxf(f, -65504.f), 65504.f);
+  return (uint32_t)__half_as_ushort(__float2half_rn(f));
+}
+__device__ __forceinline__ float md_h2f(uint32_t h) { return __half2float(__ushort_as_half((unsigned short)h)); }
+__device__ __forceinline__ void md_split_f16(float x, uint32_t& hi, uint32_t& lo) {
+  hi = md_f2h(x);
+  lo = md_f2h(x - md_h2f(hi));
 }
 
 __device__ __forceinline__ float md_silu(float x) { return x / (1.0f + expf(-x)); }

@@ -112,11 +112,11 @@ __global__ __launch_bounds__(GN_BLOCK) void md_gn_apply_kernel(const float* __re
         // experiment hook (tools/longrun_parity.py --act-fp16): round the operand to fp16 first, which is
         // what a weights-split-only fp16 scheme (2 MFMAs per product) would feed the matrix cores
         if (silu & 2) y = __half2float(__float2half_rn(y));
-        md_split(y, hi[e], lo[e]);
+        if (silu & 4) { hi[e] = md_f2h(y); lo[e] = 0; } else md_split(y, hi[e], lo[e]);
       }
       const int64_t o = pos * 8 + half * 4;
       *(uint2*)(ohi + o) = make_uint2(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16));
-      *(uint2*)(ohi + plane + o) = make_uint2(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16));
+      if (!(silu & 4)) *(uint2*)(ohi + plane + o) = make_uint2(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16));
     }
   }
 }

@@ -10,7 +10,7 @@ import os
 import torch
 
 from . import _lib
-from ._lib import (A_PACKED, A_S16B, CFG_C3_128, CFG_C3_128_V2, CFG_C3_128_SW, CFG_C3_128_PIPE, CFG_C3_128_V3, CFG_C3_128_V3B, CFG_C3_128_V4, CFG_C3_128_FAST, CFG_C5_128_K16, CFG_C5_32_K16, CFG_C3_128_K16, CFG_C3_32, CFG_C3_LOW, CFG_C3_S2,
+from ._lib import (A_PACKED, A_S16B, PREC_BF16X3, PREC_FP16X2, CFG_C3_128, CFG_C3_128_V2, CFG_C3_128_SW, CFG_C3_128_PIPE, CFG_C3_128_V3, CFG_C3_128_V3B, CFG_C3_128_V4, CFG_C3_128_FAST, CFG_C5_128_K16, CFG_C5_32_K16, CFG_C3_128_K16, CFG_C3_32, CFG_C3_LOW, CFG_C3_S2,
                    CFG_G1_128, CFG_G1_128_LOW, CFG_G1_64_LOW, CFG_NT_KC, OUT_F32B, OUT_NCDHW, OUT_S16B,
                    MdGemmConvArgs, check)
 
@@ -18,6 +18,23 @@ from ._lib import (A_PACKED, A_S16B, CFG_C3_128, CFG_C3_128_V2, CFG_C3_128_SW, C
 CFG_ABL1, CFG_ABL2, CFG_ABL3, CFG_ABL4, CFG_ABL5 = 101, 102, 103, 104, 105
 CFG_F1, CFG_F3, CFG_F4, CFG_F6, CFG_F7, CFG_F8 = 111, 113, 114, 116, 117, 118   # ablations of the dedicated kernel  # timing-only ablation kernels (tools/bench_conv.py)
 DEBUG_ACT_FP16 = 2 if os.environ.get("MD_DEBUG_ACT_FP16") == "1" else 0   # precision experiment only
+# Arithmetic of the dedicated 3x3x3 conv kernel: "bf16x3" (default; ~1e-5 per U-Net evaluation) or "fp16x2"
+# (weights split fp16, activations one fp16; ~1e-3 per evaluation, 7e-5 after the 999-step sampler).
+PRECISION = os.environ.get("MD_PRECISION", "bf16x3")
+
+
+def set_precision(mode):
+    global PRECISION
+    if mode not in ("bf16x3", "fp16x2"):
+        raise ValueError(f"unknown precision mode {mode!r}")
+    PRECISION = mode
+
+
+def fast_prec(cfg):
+    """Operand format to use for a conv that will run on configuration `cfg`."""
+    return PREC_FP16X2 if (PRECISION == "fp16x2" and cfg == CFG_C3_128_FAST) else PREC_BF16X3
+
+
 PROFILE = None   # set to a list by bench.py to collect (cfg, flops, start_event, end_event) per GEMM/conv launch
 
 
@@ -48,8 +65,9 @@ def s16b_empty(B, Cc, P, device):
 class PackedWeight:
     """Split-bf16 WPK tiles of one conv / NIN weight (built on the device by md_pack_weights)."""
 
-    def __init__(self, w, kind, cfg, device):
+    def __init__(self, w, kind, cfg, device, prec=PREC_BF16X3):
         lib = _lib.load()
+        self.prec = prec
         nt, kc = CFG_NT_KC[cfg]
         w = w.detach().to(device=device, dtype=torch.float32).contiguous()
         _require_cuda(w, "weight")
@@ -71,7 +89,7 @@ class PackedWeight:
             raise _lib.MeshDiffusionHipError("md_packed_weight_bytes failed")
         self.data = torch.empty(nbytes // 2, dtype=torch.bfloat16, device=device)
         check(lib.md_pack_weights(_ptr(w), _ptr(self.data), rows, kdim, taps, s_row, s_k, s_tap, nt, kc,
-                                  _stream()), "md_pack_weights")
+                                  prec, _stream()), "md_pack_weights")
 
 
 def pack_s16b_from_matrix(w_kp, device):
@@ -89,7 +107,7 @@ def pack_s16b_from_matrix(w_kp, device):
 # ---------------------------------------------------------------------------------------------
 def gemm_conv(*, cfg, a, b, out, batch, rows, rows_alloc, kdim, dims, bias=None, bias_bstride=0,
               residual=None, res_bstride=0, alpha=1.0, ups=0, a_src=A_PACKED, a_rows=0, a_bstride=0,
-              b_bstride=None, out_mode=OUT_F32B, ksplit=1):
+              b_bstride=None, out_mode=OUT_F32B, ksplit=1, prec=PREC_BF16X3):
     lib = _lib.load()
     D, H, W = dims
     args = MdGemmConvArgs()
@@ -109,6 +127,7 @@ def gemm_conv(*, cfg, a, b, out, batch, rows, rows_alloc, kdim, dims, bias=None,
             pin *= 8
         b_bstride = (kdim // 8) * 2 * pin * 8
     args.b_bstride = b_bstride
+    args.prec = prec
     part = None
     if ksplit > 1:
         if out_mode != OUT_F32B:
@@ -149,7 +168,8 @@ def gn_params(parts, gamma, beta, B, P, eps=1e-6, groups=32):
     return params
 
 
-def gn_apply(parts, params, B, P, norm=True, silu=True, out=None):
+def gn_apply(parts, params, B, P, norm=True, silu=True, out=None, fp16=False):
+    """fp16=True: MD_PREC_FP16X2 operand format (plane 0 = fp16(y), plane 1 untouched)."""
     lib = _lib.load()
     dev = parts[0][0].device
     ctot = sum(c for _, c in parts)
@@ -158,7 +178,8 @@ def gn_apply(parts, params, B, P, norm=True, silu=True, out=None):
     off = 0
     for t, c in parts:
         check(lib.md_gn_apply(_ptr(t), _ptr(params) if norm else None, _ptr(out), B, c, P, ctot, off,
-                              1 if norm else 0, (1 if silu else 0) | DEBUG_ACT_FP16, _stream()), "md_gn_apply")
+                              1 if norm else 0, (1 if silu else 0) | DEBUG_ACT_FP16 | (4 if fp16 else 0), _stream()),
+              "md_gn_apply")
         off += c
     return out
 

@@ -97,6 +97,8 @@ class DDPMUNet3D(layers.HipLayer):
         mods.append(edge_conv(in_ch, channels, init_scale=0.0))
         self.all_modules = nn.ModuleList(mods)
         self.out_channels = channels
+        # arithmetic of the hot conv kernel: "bf16x3" (default) or "fp16x2" 
+        self.hip_precision = m.get("hip_precision", None) if hasattr(m, "get") else None
 
     def _blocks_at(self, lvl):
         return self.LEVEL0_BLOCKS if (lvl == 0 and self.LEVEL0_BLOCKS) else self.num_res_blocks
@@ -136,6 +138,8 @@ class DDPMUNet3D(layers.HipLayer):
         if torch.is_grad_enabled() and self.training:
             raise NotImplementedError("autograd/backward through the HIP U-Net is not implemented yet; "
                                       "call under torch.no_grad() in eval mode")
+        if self.hip_precision is not None:
+            ops.set_precision(self.hip_precision)
         mods = self.all_modules
         B, R = x.shape[0], self.img_size
         P = R ** 3

@@ -105,7 +105,9 @@ def _parts_of(x):
 
 
 def conv3_packed(layer, name, conv, cfg):
-    return layer._cached(name, [conv.weight], lambda: ops.PackedWeight(conv.weight, "conv", cfg, conv.weight.device))
+    prec = ops.fast_prec(cfg)
+    return layer._cached(f"{name}/p{prec}", [conv.weight],
+                         lambda: ops.PackedWeight(conv.weight, "conv", cfg, conv.weight.device, prec))
 
 
 def run_conv3(pw, act_s16, B, S_out, *, bias=None, bias_bstride=0, residual=None, res_bstride=None, ups=0,
@@ -121,7 +123,7 @@ def run_conv3(pw, act_s16, B, S_out, *, bias=None, bias_bstride=0, residual=None
     return ops.gemm_conv(cfg=pw.cfg, a=pw.data, b=act_s16, out=out, batch=B, rows=pw.rows,
                          rows_alloc=rows_alloc, kdim=pw.kdim, dims=(S_out, S_out, S_out), bias=bias,
                          bias_bstride=bias_bstride, residual=residual, res_bstride=res_bstride or 0, ups=ups,
-                         out_mode=out_mode, ksplit=ksplit)
+                         out_mode=out_mode, ksplit=ksplit, prec=pw.prec)
 
 
 def run_gemm(pw, act_s16, B, P, *, bias=None, bias_bstride=0, residual=None, out=None, out_mode=ops.OUT_F32B,
@@ -236,8 +238,8 @@ class Upsample(HipLayer):
 
     def forward_blocked(self, x, Cc, B, P):
         s_out = 2 * _spatial_edge(P)
-        act = ops.gn_apply([(x, Cc)], None, B, P, norm=False, silu=False)
         pw = conv3_packed(self, "w", self.Conv_0, ops.conv_cfg_for(s_out))
+        act = ops.gn_apply([(x, Cc)], None, B, P, norm=False, silu=False, fp16=pw.prec == ops.PREC_FP16X2)
         return run_conv3(pw, act, B, s_out, bias=self.Conv_0.bias, ups=1)
 
     def forward(self, x):
@@ -301,22 +303,24 @@ class ResnetBlockDDPM(HipLayer):
         assert cin == self.in_ch
         cfg = ops.conv_cfg_for(S)
         g0, g1 = self.GroupNorm_0, self.GroupNorm_1
+        pw0, pw1 = conv3_packed(self, "w0", self.Conv_0, cfg), conv3_packed(self, "w1", self.Conv_1, cfg)
+        f16 = pw0.prec == ops.PREC_FP16X2   # operand format follows the kernel that consumes the tensor
         prm = ops.gn_params(parts, g0.weight, g0.bias, B, P, eps=g0.eps, groups=g0.num_groups)
-        a0 = ops.gn_apply(parts, prm, B, P, norm=True, silu=True)
+        a0 = ops.gn_apply(parts, prm, B, P, norm=True, silu=True, fp16=f16)
         if temb is not None:   # per-(sample, channel) additive bias = Conv_0.b + Dense_0(SiLU(temb))
             bias0 = ops.linear(temb, self.Dense_0.weight, self._bias0(), silu_in=True)
-            h = run_conv3(conv3_packed(self, "w0", self.Conv_0, cfg), a0, B, S, bias=bias0, bias_bstride=self.out_ch)
+            h = run_conv3(pw0, a0, B, S, bias=bias0, bias_bstride=self.out_ch)
         else:
-            h = run_conv3(conv3_packed(self, "w0", self.Conv_0, cfg), a0, B, S, bias=self.Conv_0.bias)
+            h = run_conv3(pw0, a0, B, S, bias=self.Conv_0.bias)
         prm1 = ops.gn_params([(h, self.out_ch)], g1.weight, g1.bias, B, P, eps=g1.eps, groups=g1.num_groups)
-        a1 = ops.gn_apply([(h, self.out_ch)], prm1, B, P, norm=True, silu=True)
+        a1 = ops.gn_apply([(h, self.out_ch)], prm1, B, P, norm=True, silu=True, fp16=f16)
         if self.in_ch != self.out_ch:
             xs = ops.gn_apply(parts, None, B, P, norm=False, silu=False)
             res = self.NIN_0.forward_s16(xs, B, P)
         else:
             assert len(parts) == 1
             res = parts[0][0]
-        return run_conv3(conv3_packed(self, "w1", self.Conv_1, cfg), a1, B, S, bias=self.Conv_1.bias, residual=res)
+        return run_conv3(pw1, a1, B, S, bias=self.Conv_1.bias, residual=res)
 
     def forward(self, x, temb=None):
         parts, B, P, spatial = _parts_of(x)

@@ -174,12 +174,30 @@ def gen_unet_and_sampler(skip_res64):
         np.savez_compressed(os.path.join(GOLD, "unet_res64.npz"), y_sub=y_ref[:, :, ::4, ::4, ::4].numpy(),
                             y_norm=float(y_ref.double().norm()), y_sum=y_ref.double().sum(dim=(0, 2, 3, 4)).numpy(),
                             y_row=y_ref[0, :, 31, 17, :].numpy(), labels=labels.numpy(), x_seed=42, sd_seed=1234)
+        if os.environ.get("MD_GOLD_RES128", "1") == "1":
+            gen_res128_full(rmutils)
         mask = synth.synthetic_grid_mask(R).view(1, R, R, R)
         t0 = time.time()
         xm = run_ref_sampler(rsampling, rsde, cfg, model, (1, 4, R, R, R), mask, 10, seed=42)
         print(f"[res64] reference 10-step sampler {time.time() - t0:.1f}s")
         np.savez_compressed(os.path.join(GOLD, "sampler_res64.npz"), xm_sub=xm[:, :, ::4, ::4, ::4].numpy(),
                             xm_norm=float(xm.double().norm()), xm_row=xm[0, :, 33, 17, :].numpy(), K=10, seed=42)
+
+
+def gen_res128_full(rmutils):
+    """Reference DDPMRes128 at 128^3 (BASELINE config #4 shape), one evaluation: ::8 subsample + statistics."""
+    from meshdiffusion_amd.config import get_config_res128
+    cfg = get_config_res128(); cfg.device = torch.device("cpu")
+    sd = make_sd(cfg, 128, seed=99)
+    model = ref_model(rmutils, cfg, sd)
+    x = synth.synthetic_inputs(1, 4, 128, seed=5)
+    labels = torch.tensor([321.5])
+    t0 = time.time(); y = model(x, labels); dt = time.time() - t0
+    print(f"[res128] reference forward {dt:.1f}s; std {float(y.std()):.3f}")
+    np.savez_compressed(os.path.join(GOLD, "unet_res128.npz"), y_sub=y[:, :, ::8, ::8, ::8].numpy(),
+                        y_norm=float(y.double().norm()), y_row=y[0, :, 63, 17, :].numpy(), labels=labels.numpy(),
+                        x_seed=5, sd_seed=99)
+    del model, sd
 
 
 # -------------------------------------------------------------------------------------------------

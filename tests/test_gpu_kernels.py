@@ -103,6 +103,27 @@ def test_conv3_split_k(ops, cfg_name, S, ks):
     assert rel_l2(outs[1], ref) < TOL_MFMA and rel_l2(outs[1], outs[0]) < 1e-6
 
 
+@pytest.mark.parametrize("cin,cout,S,B,ups", [(64, 128, 8, 2, 0), (96, 256, 16, 1, 0), (64, 64, 8, 1, 1)])
+def test_conv3_fp16x2_mode(ops, cin, cout, S, B, ups):
+    """MD_PREC_FP16X2: weights split fp16 (exact to ~2^-21), activations ONE fp16.  Checked two ways:
+    against the conv of the fp16-rounded activations (isolates the kernel: 3e-5) and against the exact
+    conv (shows the mode's own error, ~2e-4 for one layer)."""
+    Sin = S // 2 if ups else S
+    x = _rand((B, cin, Sin, Sin, Sin), 60); w = _rand((cout, cin, 3, 3, 3), 61, 0.05); bias = _rand((B, cout), 62)
+    parts = [(ops.ncdhw_to_f32b(x.cuda()), cin)]
+    act = ops.gn_apply(parts, None, B, Sin ** 3, norm=False, silu=False, fp16=True)
+    pw = ops.PackedWeight(w.cuda(), "conv", ops.CFG_C3_128_FAST, "cuda", ops.PREC_FP16X2)
+    out = ops.f32b_empty(B, cout, S ** 3, "cuda")
+    ops.gemm_conv(cfg=ops.CFG_C3_128_FAST, a=pw.data, b=act, out=out, batch=B, rows=cout, rows_alloc=cout, kdim=cin,
+                  dims=(S, S, S), bias=bias.cuda(), bias_bstride=cout, ups=ups, prec=ops.PREC_FP16X2)
+    y = ops.f32b_to_ncdhw(out, (S, S, S)).cpu()
+    up = (lambda t: F.interpolate(t, scale_factor=2, mode="nearest")) if ups else (lambda t: t)
+    ref_q = F.conv3d(up(x.half().float()), w, padding=1) + bias[:, :, None, None, None]
+    ref = F.conv3d(up(x), w, padding=1) + bias[:, :, None, None, None]
+    assert rel_l2(y, ref_q) < TOL_MFMA
+    assert rel_l2(y, ref) < 5e-4
+
+
 def test_conv3_low_tile(ops):
     x = _rand((2, 64, 4, 4, 4), 5); w = _rand((128, 64, 3, 3, 3), 6, 0.05)
     s, B, P = _to_s16(ops, x)
