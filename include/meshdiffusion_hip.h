@@ -215,6 +215,25 @@ int md_inpaint_renoise(float* x, float* x_mean, const float* z, const float* pma
                        int32_t ch, int64_t P, void* stream);
 
 /*
+ * Training-step pieces that do not need the U-Net backward (lib/diffusion/losses.py:38-78, models/ema.py:32-51).
+ *   md_ddpm_perturb : out = (coef[b][0]*x0 + coef[b][1]*noise) * mask            (losses.py:63-65)
+ *   md_masked_sq_err: sums[b] += sum_i (eps_hat-noise)^2 * mask (fp64; zero `sums` first);
+ *                     grad (may be NULL) = gscale * 2 (eps_hat-noise) * mask = dLoss/d eps_hat   (losses.py:68-78)
+ *   md_grad_sqnorm  : *out += sum g^2 (fp64; zero first)          (clip_grad_norm_, losses.py:48)
+ *   md_adam_ema_step: clip by min(1, max_norm/(sqrt(*grad_sqnorm)+1e-6)) (skipped when grad_sqnorm NULL or
+ *                     max_norm < 0), torch.optim.Adam update with bias correction for `step` (1-based),
+ *                     then ema -= (1-ema_decay)*(ema - p) (ema may be NULL).  One pass over 5 flat arrays.
+ */
+int md_ddpm_perturb(const float* x0, const float* noise, const float* mask, const float* coef, float* out,
+                    int32_t batch, int32_t C, int64_t P, void* stream);
+int md_masked_sq_err(const float* eps_hat, const float* noise, const float* mask, double* sums, float* grad,
+                     float gscale, int32_t batch, int32_t C, int64_t P, void* stream);
+int md_grad_sqnorm(const float* g, int64_t n, double* out, void* stream);
+int md_adam_ema_step(float* p, const float* g, float* m, float* v, float* ema, int64_t n, float lr, float beta1,
+                     float beta2, float eps, float weight_decay, int32_t step, float ema_decay,
+                     const double* grad_sqnorm, float max_norm, void* stream);
+
+/*
  * Marching tetrahedra on a STATIC tet grid (nvdiffrec/lib/geometry/dmtet.py:105-163),
  * one workgroup per mesh, n_meshes meshes per call.
  * Static tables (built once on the host from the tet file, see meshdiffusion_amd/dmtet.py):

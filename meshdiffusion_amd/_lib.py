@@ -63,6 +63,10 @@ SIGNATURES = {
     "md_ancestral_step": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I64, _P]),
     "md_inpaint_blend": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _I64, _I64, _P]),
     "md_inpaint_renoise": (C.c_int, [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I64, _P]),
+    "md_ddpm_perturb": (C.c_int, [_P, _P, _P, _P, _P, _I32, _I32, _I64, _P]),
+    "md_masked_sq_err": (C.c_int, [_P, _P, _P, _P, _P, _F, _I32, _I32, _I64, _P]),
+    "md_grad_sqnorm": (C.c_int, [_P, _I64, _P, _P]),
+    "md_adam_ema_step": (C.c_int, [_P, _P, _P, _P, _P, _I64, _F, _F, _F, _F, _F, _I32, _F, _P, _F, _P]),
     "md_marching_tets_workspace_bytes": (_I64, [_I32, _I32]),
     "md_marching_tets": (C.c_int, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _I64, _P]),
 }

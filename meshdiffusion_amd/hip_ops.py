@@ -35,6 +35,14 @@ def fast_prec(cfg):
     return PREC_FP16X2 if (PRECISION == "fp16x2" and cfg == CFG_C3_128_FAST) else PREC_BF16X3
 
 
+PARAM_EPOCH = 0   # bumped by optimisers that update parameters through raw pointers (no tensor _version bump)
+
+
+def bump_param_epoch():
+    global PARAM_EPOCH
+    PARAM_EPOCH += 1
+
+
 PROFILE = None   # set to a list by bench.py to collect (cfg, flops, start_event, end_event) per GEMM/conv launch
 
 

@@ -83,7 +83,7 @@ class HipLayer(nn.Module):
 
     def _cached(self, name, params, builder):
         cache = self.__dict__.setdefault("_md_cache", {})
-        key = tuple((p.data_ptr(), p._version, str(p.device)) for p in params)
+        key = (ops.PARAM_EPOCH,) + tuple((p.data_ptr(), p._version, str(p.device)) for p in params)
         hit = cache.get(name)
         if hit is None or hit[0] != key:
             hit = (key, builder())

@@ -66,3 +66,14 @@ def sharded_sample(sample_fn, total_batch, seed, gather=True):
     if rank != 0:
         return None
     return torch.cat([o[:n] for o, n in zip(out, sizes)], dim=0)
+
+
+def allreduce_grads_(flat_grad):
+    """Average a flat fp32 gradient buffer over all ranks in place (one RCCL all-reduce of 1.456 GB for
+    res64 instead of DataParallel's reduce-to-GPU0).  Equal shards + mean-over-local-batch
+    loss => the average reproduces the large-batch gradient.  No-op for world size 1."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return flat_grad
+    dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
+    flat_grad.div_(dist.get_world_size())
+    return flat_grad

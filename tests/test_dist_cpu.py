@@ -59,3 +59,36 @@ def test_sharded_sampling_two_ranks_gloo(total):
     assert res[1][0] is None
     assert torch.equal(res[0][0], expect)                       # rank-0 gather == per-shard reference runs
     assert torch.equal(res[1][1], _stub_sampler(sizes[1], 101))  # each rank == a run with its own seed
+
+
+def _grad_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from meshdiffusion_amd.lib.diffusion import parallel
+    parallel.init_distributed(backend="gloo")
+    # local "gradient" of a mean-over-local-batch loss on this rank's shard of a batch of 8
+    g = torch.Generator().manual_seed(3)
+    data = torch.randn((8, 1000), generator=g)
+    shard = data[rank * 4:(rank + 1) * 4]
+    flat = shard.mean(dim=0).clone()
+    parallel.allreduce_grads_(flat)
+    q.put((rank, flat.clone()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_grad_allreduce_equals_large_batch_gradient_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    g = torch.Generator().manual_seed(3)
+    full = torch.randn((8, 1000), generator=g).mean(dim=0)
+    assert torch.allclose(res[0], full, atol=1e-6) and torch.equal(res[0], res[1])
