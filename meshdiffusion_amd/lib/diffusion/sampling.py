@@ -155,6 +155,52 @@ class AncestralStepper:
         return ops.ancestral_step(x, eps_hat, z, self.gm_flat, self.coef[i])
 
 
+class GraphedStepper:
+    """One denoise step (U-Net evaluation + ancestral update) captured in a hipGraph and replayed.
+
+    ~700 kernel launches per step go through ctypes; at small batch (B=1: 23 ms/step) their host cost is a
+    visible fraction of the step.  The graph is captured on a side stream with static input buffers
+    (x, labels, coef, z); the per-step noise is still drawn eagerly by `torch.randn_like` (one tiny launch)
+    so the random stream is exactly the eager sampler's.  Weight packing / caches are warmed by eager steps
+    before capture.
+    """
+
+    def __init__(self, stepper, model_fn, warmup=2):
+        self.st, self.model_fn = stepper, model_fn
+        dev = stepper.dev
+        self.x = torch.zeros(stepper.shape, dtype=torch.float32, device=dev)
+        self.labels = torch.zeros(stepper.B, dtype=torch.float32, device=dev)
+        self.coef = torch.zeros((stepper.B, 4), dtype=torch.float32, device=dev)
+        self.z = torch.zeros(stepper.shape, dtype=torch.float32, device=dev)
+        self.graph = None
+        self._warm = warmup
+
+    def _body(self):
+        eps_hat = self.model_fn(self.x, self.labels)
+        return ops.ancestral_step(self.x, eps_hat, self.z, self.st.gm_flat, self.coef)
+
+    def step(self, x, i, draw=torch.randn_like):
+        self.x.copy_(x)
+        self.labels.copy_(self.st.labels[i])
+        self.coef.copy_(self.st.coef[i])
+        self.z.copy_(draw(x))
+        if self.graph is None:
+            if self._warm > 0:           # eager warm-up: packs weights, fills allocator pools
+                self._warm -= 1
+                return self._body()
+            g = torch.cuda.CUDAGraph()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                self._body()             # one more eager pass on the capture stream
+            torch.cuda.current_stream().wait_stream(side)
+            with torch.cuda.graph(g):
+                self.out = self._body()
+            self.graph = g
+        self.graph.replay()
+        return self.out[0].clone(), self.out[1].clone()
+
+
 def get_pc_sampler(sde, shape, predictor, corrector, inverse_scaler, snr, n_steps=1, probability_flow=False,
                    continuous=False, denoise=True, eps=1e-3, device="cuda", grid_mask=None, return_traj=False):
     if predictor is not AncestralSamplingPredictor or corrector is not NoneCorrector:
