@@ -32,6 +32,7 @@ ACT_BYTES_PER_SAMPLE_STEP = 8.21e9
 WEIGHT_BYTES_PER_STEP = 1.456e9
 PEAK_BF16_TFLOPS = 2500.0     # dense bf16 MFMA peak, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
+PMC_TRAFFIC_BYTES_PER_LAUNCH = 1.469e9   # measured: (2*FETCH_SIZE + WRITE_SIZE) KiB per md_conv3_main_kernel launch
 
 
 def parse():
@@ -158,13 +159,18 @@ def main():
         # ---- roofline of the dominant kernel from in-region HIP events ----
         roof = None
         if events:
-            main = [(f, s.elapsed_time(e) * 1e-3) for (c, f, s, e) in events if c == hip_ops.CFG_C3_128_FAST]
-            tot_f, tot_t = sum(f for f, _ in main), sum(t for _, t in main)
-            allt = sum(s.elapsed_time(e) * 1e-3 for (_, _, s, e) in events)
+            main = [(f, s.elapsed_time(e) * 1e-3, ab) for (c, f, s, e, ab) in events if c == hip_ops.CFG_C3_128_FAST]
+            tot_f, tot_t = sum(f for f, _, _ in main), sum(t for _, t, _ in main)
+            alg_bytes = sum(ab for _, _, ab in main) / max(len(main), 1)
+            allt = sum(s.elapsed_time(e) * 1e-3 for (_, _, s, e, _) in events)
             ach = tot_f / tot_t / 1e12
             roof = {"bound": "mfma", "kernel": "md_conv3_main_kernel<0> (3x3x3 conv, implicit GEMM, bf16x3 MFMA)",
                     "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                    "frac": round(ach / PEAK_BF16_TFLOPS, 4),
+                    # HBM bytes per launch from rocprofv3 PMC passes of this same command (FETCH_SIZE doubled as
+                    # MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE): profiles/r01_final_pmc_*.summary.txt
+                    "traffic": PMC_TRAFFIC_BYTES_PER_LAUNCH if a.precision == "bf16x3" and B == 8 else None,
+                    "algorithmic_bytes_per_launch": round(alg_bytes),
                     "launches": len(main), "avg_launch_ms": round(tot_t / max(len(main), 1) * 1e3, 4),
                     "kernel_time_share_of_step": round(tot_t / wall, 4),
                     "all_gemm_conv_time_share_of_step": round(allt / wall, 4),

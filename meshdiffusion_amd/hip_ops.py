@@ -148,11 +148,14 @@ def gemm_conv(*, cfg, a, b, out, batch, rows, rows_alloc, kdim, dims, bias=None,
     else:  # bench.py: HIP events on the launch stream around this launch (algorithmic flops, 1x)
         taps = _lib.cfg_info(cfg)["taps"]
         flops = 2.0 * batch * rows * kdim * taps * D * H * W
+        # algorithmic HBM bytes of this launch: operand in, weights, output (+ residual), each once
+        pin = D * H * W // (8 if ups else 1) * (8 if cfg == CFG_C3_S2 else 1)
+        abytes = 4.0 * (batch * kdim * pin + rows * kdim * taps + batch * rows * D * H * W * (2 if residual is not None else 1))
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         check(lib.md_gemm_conv(C.byref(args), _stream()), f"md_gemm_conv(cfg={cfg})")
         e1.record()
-        PROFILE.append((cfg, flops, e0, e1))
+        PROFILE.append((cfg, flops, e0, e1, abytes))
     return out
 
 
