@@ -47,6 +47,8 @@ def parse():
                     help="arithmetic of the hot conv kernel for the headline number (DESIGN.md section 3)")
     ap.add_argument("--no-fast-mode", action="store_true", help="skip the extra fp16x2 measurement")
     ap.add_argument("--graph", action="store_true", help="replay the denoise step from a captured hipGraph")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="CPU-only check of the multi-process control flow (gloo, no kernels, fake timing)")
     return ap.parse_args()
 
 
@@ -57,6 +59,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != a.gpus and world > 1:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if a.dry_run:
+        return dry_run(a, rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -201,6 +205,25 @@ def main():
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
+        dist.destroy_process_group()
+
+
+def dry_run(a, rank, world):
+    """Exercise rendezvous, barrier, MAX-reduction and the rank-0 JSON line without a GPU."""
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dist.barrier()
+    wall_t = torch.tensor([0.1 * (rank + 1)], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(wall_t, op=dist.ReduceOp.MAX)
+        dist.barrier()
+    if rank == 0:
+        wall = float(wall_t.item())
+        print(json.dumps({"metric": "dry-run", "value": world * a.batch * a.steps / wall, "n_gpus": world,
+                          "steps": a.steps, "warmup": a.warmup, "max_wall": wall}), flush=True)
+    if world > 1:
         dist.destroy_process_group()
 
 

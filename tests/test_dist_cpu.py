@@ -92,3 +92,20 @@ def test_grad_allreduce_equals_large_batch_gradient_gloo():
     g = torch.Generator().manual_seed(3)
     full = torch.randn((8, 1000), generator=g).mean(dim=0)
     assert torch.allclose(res[0], full, atol=1e-6) and torch.equal(res[0], res[1])
+
+
+def test_bench_multi_process_control_flow_dry_run():
+    """bench.py under torch.distributed.run with 2 ranks: rendezvous on 127.0.0.1, barrier, MAX over ranks,
+    exactly one JSON line from rank 0 (the GPU work itself is covered by the -m gpu suite and `bench.py`)."""
+    import json
+    import subprocess
+    port = _free_port()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
+           "--warmup", "1", "--dry-run"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=180, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and abs(d["max_wall"] - 0.2) < 1e-9 and d["value"] == 2 * 8 * 3 / 0.2
