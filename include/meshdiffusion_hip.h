@@ -147,6 +147,8 @@ int64_t md_packed_weight_bytes(int32_t rows, int32_t kdim, int32_t taps, int32_t
  * md_gn_apply : y = (x-mean)*rstd*gamma + beta (norm=1) ; y = silu(y) (silu=1); writes the
  *               split-bf16 S16B tensor out[B][c_total/8][2][P][8] at c_off.
  *               norm=0 copies/splits raw x (used for the NIN shortcut input).
+ *               out_raw (may be NULL): second S16B tensor of the same shape receiving the bf16 split of
+ *               the raw x from the same read (ResnetBlock: GN path and NIN shortcut share one pass).
  *               `silu` is a bit field: 1 = apply SiLU, 4 = MD_PREC_FP16X2 output (plane 0 = fp16(y),
  *               plane 1 not written), 2 = debug: round y to fp16 before the bf16 split.
  */
@@ -155,7 +157,7 @@ int md_gn_stats(const float* x, double* sums, int32_t batch, int32_t C, int64_t 
 int md_gn_finalize(const double* sums, const float* gamma, const float* beta,
                    float* params, int32_t batch, int32_t c_total, int32_t groups,
                    int64_t P, float eps, void* stream);
-int md_gn_apply(const float* x, const float* params, void* out, int32_t batch,
+int md_gn_apply(const float* x, const float* params, void* out, void* out_raw, int32_t batch,
                 int32_t C, int64_t P, int32_t c_total, int32_t c_off, int32_t norm,
                 int32_t silu, void* stream);
 int md_zero(void* p, int64_t bytes, void* stream);

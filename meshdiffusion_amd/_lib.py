@@ -51,7 +51,7 @@ SIGNATURES = {
     "md_packed_weight_bytes": (_I64, [_I32, _I32, _I32, _I32, _I32]),
     "md_gn_stats": (C.c_int, [_P, _P, _I32, _I32, _I64, _I32, _I32, _P]),
     "md_gn_finalize": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _I64, _F, _P]),
-    "md_gn_apply": (C.c_int, [_P, _P, _P, _I32, _I32, _I64, _I32, _I32, _I32, _I32, _P]),
+    "md_gn_apply": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I64, _I32, _I32, _I32, _I32, _P]),
     "md_zero": (C.c_int, [_P, _I64, _P]),
     "md_timestep_embedding": (C.c_int, [_P, _P, _I32, _I32, _P]),
     "md_linear": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _P]),

@@ -79,7 +79,8 @@ __global__ void md_gn_finalize_kernel(const double* __restrict__ sums, const flo
 // out: S16B [B][c_total/8][2][P][8]
 __global__ __launch_bounds__(GN_BLOCK) void md_gn_apply_kernel(const float* __restrict__ x,
                                                                const float* __restrict__ params,
-                                                               uint16_t* __restrict__ out, int C,
+                                                               uint16_t* __restrict__ out,
+                                                               uint16_t* __restrict__ out_raw, int C,
                                                                int64_t P, int c_total, int c_off,
                                                                int norm, int silu) {
   const int cg = blockIdx.y, b = blockIdx.z;
@@ -98,12 +99,20 @@ __global__ __launch_bounds__(GN_BLOCK) void md_gn_apply_kernel(const float* __re
   }
   const int64_t plane = P * 8;
   uint16_t* ohi = out + (((int64_t)b * (c_total / 8) + (c_off / 8) + cg) * 2) * plane;
+  uint16_t* rhi = out_raw ? out_raw + (((int64_t)b * (c_total / 8) + (c_off / 8) + cg) * 2) * plane : nullptr;
 #pragma unroll
   for (int i = 0; i < GN_ITEMS; ++i) {
     const int64_t pos = p0 + ((tid + i * GN_BLOCK) >> 1);
     if (pos < P) {
       const f32x4 v = xp[pos * 2 + half];
       uint32_t hi[4], lo[4];
+      if (rhi) {  // second output: bf16 split of the raw input (operand of the NIN shortcut), same read
+#pragma unroll
+        for (int e = 0; e < 4; ++e) md_split(v[e], hi[e], lo[e]);
+        const int64_t o = pos * 8 + half * 4;
+        *(uint2*)(rhi + o) = make_uint2(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16));
+        *(uint2*)(rhi + plane + o) = make_uint2(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16));
+      }
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         float y = v[e];
@@ -145,8 +154,8 @@ extern "C" int md_gn_finalize(const double* sums, const float* gamma, const floa
   return MD_OK;
 }
 
-extern "C" int md_gn_apply(const float* x, const float* params, void* out, int32_t batch, int32_t C,
-                           int64_t P, int32_t c_total, int32_t c_off, int32_t norm, int32_t silu,
+extern "C" int md_gn_apply(const float* x, const float* params, void* out, void* out_raw, int32_t batch,
+                           int32_t C, int64_t P, int32_t c_total, int32_t c_off, int32_t norm, int32_t silu,
                            void* stream) {
   if (!x || !out || (norm && !params) || batch <= 0 || C <= 0 || (C % 8) || (c_off % 8) ||
       (c_total % 8) || c_off + C > c_total || P <= 0)
@@ -154,7 +163,7 @@ extern "C" int md_gn_apply(const float* x, const float* params, void* out, int32
   dim3 grid((unsigned)((P + GN_CHUNK - 1) / GN_CHUNK), (unsigned)(C / 8), (unsigned)batch);
   MD_HIP_CLEAR_ERROR();
   hipLaunchKernelGGL(md_gn_apply_kernel, grid, dim3(GN_BLOCK), 0, (hipStream_t)stream, x, params,
-                     (uint16_t*)out, C, P, c_total, c_off, norm, silu);
+                     (uint16_t*)out, (uint16_t*)out_raw, C, P, c_total, c_off, norm, silu);
   MD_HIP_CHECK_LAUNCH();
   return MD_OK;
 }

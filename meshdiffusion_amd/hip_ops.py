@@ -179,20 +179,22 @@ def gn_params(parts, gamma, beta, B, P, eps=1e-6, groups=32):
     return params
 
 
-def gn_apply(parts, params, B, P, norm=True, silu=True, out=None, fp16=False):
-    """fp16=True: MD_PREC_FP16X2 operand format (plane 0 = fp16(y), plane 1 untouched)."""
+def gn_apply(parts, params, B, P, norm=True, silu=True, out=None, fp16=False, want_raw=False):
+    """fp16=True: MD_PREC_FP16X2 operand format (plane 0 = fp16(y), plane 1 untouched).
+    want_raw=True: also return the bf16 split of the raw input (one read, two writes)."""
     lib = _lib.load()
     dev = parts[0][0].device
     ctot = sum(c for _, c in parts)
     if out is None:
         out = s16b_empty(B, ctot, P, dev)
+    raw = s16b_empty(B, ctot, P, dev) if want_raw else None
     off = 0
     for t, c in parts:
-        check(lib.md_gn_apply(_ptr(t), _ptr(params) if norm else None, _ptr(out), B, c, P, ctot, off,
+        check(lib.md_gn_apply(_ptr(t), _ptr(params) if norm else None, _ptr(out), _ptr(raw), B, c, P, ctot, off,
                               1 if norm else 0, (1 if silu else 0) | DEBUG_ACT_FP16 | (4 if fp16 else 0), _stream()),
               "md_gn_apply")
         off += c
-    return out
+    return (out, raw) if want_raw else out
 
 
 # ---------------------------------------------------------------------------------------------

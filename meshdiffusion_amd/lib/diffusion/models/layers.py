@@ -295,7 +295,9 @@ class ResnetBlockDDPM(HipLayer):
                                 lambda: (self.Conv_0.bias.detach() + self.Dense_0.bias.detach()).contiguous())
         return self.Conv_0.bias
 
-    def forward_blocked(self, parts, B, P, temb=None):
+    def forward_blocked(self, parts, B, P, temb=None, bias0=None, bias0_stride=None):
+        """bias0 (optional): precomputed Conv_0.bias + Dense_0(SiLU(temb)) rows [B, out_ch] with row stride
+        `bias0_stride` floats (the U-Net computes all blocks' FiLM biases in one launch)."""
         if self.training and self.Dropout_0.p > 0:
             raise NotImplementedError("training-mode dropout/backward is not implemented on the HIP path yet")
         S = _spatial_edge(P)
@@ -306,16 +308,21 @@ class ResnetBlockDDPM(HipLayer):
         pw0, pw1 = conv3_packed(self, "w0", self.Conv_0, cfg), conv3_packed(self, "w1", self.Conv_1, cfg)
         f16 = pw0.prec == ops.PREC_FP16X2   # operand format follows the kernel that consumes the tensor
         prm = ops.gn_params(parts, g0.weight, g0.bias, B, P, eps=g0.eps, groups=g0.num_groups)
-        a0 = ops.gn_apply(parts, prm, B, P, norm=True, silu=True, fp16=f16)
-        if temb is not None:   # per-(sample, channel) additive bias = Conv_0.b + Dense_0(SiLU(temb))
+        need_nin = self.in_ch != self.out_ch
+        a0 = ops.gn_apply(parts, prm, B, P, norm=True, silu=True, fp16=f16, want_raw=need_nin)
+        xs = None
+        if need_nin:
+            a0, xs = a0
+        if bias0 is not None:
+            h = run_conv3(pw0, a0, B, S, bias=bias0, bias_bstride=bias0_stride)
+        elif temb is not None:   # per-(sample, channel) additive bias = Conv_0.b + Dense_0(SiLU(temb))
             bias0 = ops.linear(temb, self.Dense_0.weight, self._bias0(), silu_in=True)
             h = run_conv3(pw0, a0, B, S, bias=bias0, bias_bstride=self.out_ch)
         else:
             h = run_conv3(pw0, a0, B, S, bias=self.Conv_0.bias)
         prm1 = ops.gn_params([(h, self.out_ch)], g1.weight, g1.bias, B, P, eps=g1.eps, groups=g1.num_groups)
         a1 = ops.gn_apply([(h, self.out_ch)], prm1, B, P, norm=True, silu=True, fp16=f16)
-        if self.in_ch != self.out_ch:
-            xs = ops.gn_apply(parts, None, B, P, norm=False, silu=False)
+        if need_nin:
             res = self.NIN_0.forward_s16(xs, B, P)
         else:
             assert len(parts) == 1
