@@ -142,7 +142,7 @@ int64_t md_packed_weight_bytes(int32_t rows, int32_t kdim, int32_t taps, int32_t
  * md_gn_stats : accumulates per-(b, channel) sum / sum-of-squares (double) of an
  *               F32B tensor x[B][C/8][P][8] into sums[B][c_total][2] at channel
  *               offset c_off.  `sums` must be zeroed by the caller (md_zero).
- * md_gn_finalize: per-(b,c) params float4 = (mean(group), rstd(group)*gamma[c], beta[c], 0)
+ * md_gn_finalize: per-(b,c) params float4 = (mean(group), rstd(group)*gamma[c], beta[c], rstd(group))
  *               (biased variance, as torch's GroupNorm).
  * md_gn_apply : y = (x-mean)*rstd*gamma + beta (norm=1) ; y = silu(y) (silu=1); writes the
  *               split-bf16 S16B tensor out[B][c_total/8][2][P][8] at c_off.
@@ -234,6 +234,35 @@ int md_grad_sqnorm(const float* g, int64_t n, double* out, void* stream);
 int md_adam_ema_step(float* p, const float* g, float* m, float* v, float* ema, int64_t n, float lr, float beta1,
                      float beta2, float eps, float weight_decay, int32_t step, float ema_decay,
                      const double* grad_sqnorm, float max_norm, void* stream);
+
+/*
+ * Backward-pass support (csrc/backward.hip).  Contractions of the backward re-use md_gemm_conv:
+ *   dgrad  = the forward conv kernels on WPK tiles packed from the flipped/transposed weight
+ *   wgrad  = split-K GEMM over (position, sample) on PB16 operands, one B-pointer offset per tap
+ * PB16: bf16 [guard + (D+2)(H+2)(W+2) + guard][B/8][2][C][8 samples], zero padded.
+ *   md_to_pb16      : F32B (mode 0) / S16B (mode 1) -> PB16; up=1 nearest-upsamples a (D/2)^3 source, stuff=1
+ *                     places it at odd fine positions (stride-2 conv backward).  Zero-fills `out` first.
+ *   md_wgrad_finish : GEMM result [ntap][rows/8][cols_alloc][8] -> dw[row*s_row + col*s_k + (tap0+t)*s_tap] += .
+ *   md_gn_bwd_*     : GroupNorm(+SiLU) backward in three streaming passes (see backward.hip); `sums` zeroed by
+ *                     the caller; dgamma/dbeta accumulate.
+ *   md_channel_sums : out[b][c] += sum_p x (bias / FiLM gradients); md_grad_resample: Upsample backward
+ *                     (mode 0: sum of the 8 children) and zero-stuffing (mode 1).
+ */
+int64_t md_pb16_bytes(int32_t batch, int32_t C, int32_t D, int32_t H, int32_t W, int32_t guard);
+int md_to_pb16(const void* src, void* out, int32_t batch, int32_t C, int32_t D, int32_t H, int32_t W,
+               int32_t guard, int32_t mode, int32_t up, int32_t stuff, void* stream);
+int md_wgrad_finish(const float* g, float* dw, int32_t rows, int32_t cols, int32_t cols_alloc, int32_t ntap,
+                    int32_t tap0, int64_t s_row, int64_t s_k, int64_t s_tap, void* stream);
+int md_gn_bwd_stats(const float* x, const float* dy, const float* params, double* sums, int32_t batch, int32_t C,
+                    int64_t P, int32_t c_total, int32_t c_off, int32_t dy_ctotal, int32_t silu, void* stream);
+int md_gn_bwd_finalize(const double* sums, const float* params, const float* gamma, float* coef, float* dgamma,
+                       float* dbeta, int32_t batch, int32_t c_total, int32_t groups, int64_t P, void* stream);
+int md_gn_bwd_apply(const float* x, const float* dy, const float* params, const float* coef, float* dx, int32_t batch,
+                    int32_t C, int64_t P, int32_t c_total, int32_t c_off, int32_t dy_ctotal, int32_t silu,
+                    int32_t accumulate, void* stream);
+int md_channel_sums(const float* x, float* out, int32_t batch, int32_t C, int64_t P, void* stream);
+int md_grad_resample(const float* in, float* out, int32_t batch, int32_t C, int32_t Dc, int32_t Hc, int32_t Wc,
+                     int32_t mode, int32_t accumulate, void* stream);
 
 /*
  * Marching tetrahedra on a STATIC tet grid (nvdiffrec/lib/geometry/dmtet.py:105-163),

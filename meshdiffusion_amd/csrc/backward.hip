@@ -1,0 +1,345 @@
+// Backward-pass support kernels ("first correct version"): everything that is a contraction
+// re-uses md_gemm_conv (dgrad = conv with flipped/transposed WPK tiles; wgrad = split-K GEMM over positions), so
+// this file only holds the streaming pieces around it.
+//
+// PB16 layout (wgrad operands): bf16 [G + Pp + G][B/8][2][C][8 samples], positions on the zero-padded grid
+// (D+2)(H+2)(W+2) plus G guard positions of zeros on both sides.  The contraction index of a weight gradient is
+// (position, sample); blocking it by 8 SAMPLES (not 8 positions) means any spatial tap shift keeps the 8-blocks
+// intact, so dW[tap] = sum_k dY[k] * A[k + off(tap)] is the plain GEMM with the B pointer moved by off(tap).
+//
+// Reference semantics: torch autograd of lib/diffusion/models/layers.py:646-689 (ResnetBlockDDPM), :573-582 (NIN),
+// :611-643 (Up/Downsample), nn.GroupNorm + nn.SiLU.
+#include "md_common.h"
+
+// ---- F32B / S16B -> PB16 -----------------------------------------------------------------------------------
+// mode 0: src = F32B fp32 [B][C/8][P][8] (split here); mode 1: src = S16B [B][C/8][2][P][8] (planes copied)
+// up: source grid is (D/2,H/2,W/2) and is nearest-upsampled; stuff: source grid is (D/2..) placed at odd fine
+// positions (2o+1), zeros elsewhere (dgrad/wgrad of the stride-2 Downsample conv).
+__global__ void md_to_pb16_kernel(const void* __restrict__ src, uint16_t* __restrict__ out, int B, int C, int D, int H,
+                                  int W, int guard, int mode, int up, int stuff) {
+  const int Dp = D + 2, Hp = H + 2, Wp = W + 2;
+  const int64_t Pp = (int64_t)Dp * Hp * Wp;
+  const int bg_n = B / 8;
+  const int64_t total = Pp * bg_n * C;  // one thread = one (pos, bgroup, c): 8 samples, hi + lo
+  const int Ds = (up || stuff) ? D / 2 : D, Hs = (up || stuff) ? H / 2 : H, Ws = (up || stuff) ? W / 2 : W;
+  const int64_t Ps = (int64_t)Ds * Hs * Ws;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const int bg = (int)((i / C) % bg_n);
+    const int64_t pp = i / ((int64_t)C * bg_n);
+    const int px = (int)(pp % Wp) - 1, py = (int)((pp / Wp) % Hp) - 1, pz = (int)(pp / ((int64_t)Wp * Hp)) - 1;
+    uint32_t hi[8] = {0, 0, 0, 0, 0, 0, 0, 0}, lo[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    bool inb = (px >= 0) & (px < W) & (py >= 0) & (py < H) & (pz >= 0) & (pz < D);
+    int sx = px, sy = py, sz = pz;
+    if (up) { sx >>= 1; sy >>= 1; sz >>= 1; }
+    if (stuff) { inb = inb & (px & 1) & (py & 1) & (pz & 1); sx >>= 1; sy >>= 1; sz >>= 1; }
+    if (inb) {
+      const int64_t sp = ((int64_t)sz * Hs + sy) * Ws + sx;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int b = bg * 8 + k;
+        if (mode == 0) {
+          const float v = ((const float*)src)[(((int64_t)b * (C / 8) + (c >> 3)) * Ps + sp) * 8 + (c & 7)];
+          md_split(v, hi[k], lo[k]);
+        } else {
+          const uint16_t* s = (const uint16_t*)src;
+          const int64_t o = ((((int64_t)b * (C / 8) + (c >> 3)) * 2) * Ps + sp) * 8 + (c & 7);
+          hi[k] = s[o]; lo[k] = s[o + Ps * 8];
+        }
+      }
+    }
+    uint4* o = (uint4*)(out + ((((int64_t)(guard + pp) * bg_n + bg) * 2) * C + c) * 8);
+    o[0] = make_uint4(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16), hi[4] | (hi[5] << 16), hi[6] | (hi[7] << 16));
+    o[C] = make_uint4(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16), lo[4] | (lo[5] << 16), lo[6] | (lo[7] << 16));
+  }
+}
+
+extern "C" int64_t md_pb16_bytes(int32_t batch, int32_t C, int32_t D, int32_t H, int32_t W, int32_t guard) {
+  if (batch <= 0 || (batch % 8) || C <= 0 || D <= 0 || H <= 0 || W <= 0 || guard < 0) return MD_ERR_BAD_ARG;
+  return ((int64_t)(D + 2) * (H + 2) * (W + 2) + 2 * (int64_t)guard) * (batch / 8) * 2 * C * 8 * 2;
+}
+
+extern "C" int md_to_pb16(const void* src, void* out, int32_t batch, int32_t C, int32_t D, int32_t H, int32_t W,
+                          int32_t guard, int32_t mode, int32_t up, int32_t stuff, void* stream) {
+  if (!src || !out || md_pb16_bytes(batch, C, D, H, W, guard) < 0 || (C % 8) || mode < 0 || mode > 1) return MD_ERR_BAD_ARG;
+  if ((up || stuff) && ((D | H | W) & 1)) return MD_ERR_BAD_ARG;
+  hipError_t e = hipMemsetAsync(out, 0, (size_t)md_pb16_bytes(batch, C, D, H, W, guard), (hipStream_t)stream);
+  if (e != hipSuccess) return (int)e;
+  const int64_t total = (int64_t)(D + 2) * (H + 2) * (W + 2) * (batch / 8) * C;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 8192) blocks = 8192;
+  MD_HIP_CLEAR_ERROR();
+  hipLaunchKernelGGL(md_to_pb16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, (uint16_t*)out,
+                     batch, C, D, H, W, guard, mode, up, stuff);
+  MD_HIP_CHECK_LAUNCH();
+  return MD_OK;
+}
+
+// ---- wgrad finish: GEMM result [ntap][rows/8][cols][8] (F32B per tap) -> weight gradient, accumulated ---------
+//   dw[(row*s_row + col*s_k + tap*s_tap)] += g   (same stride convention as md_pack_weights)
+__global__ void md_wgrad_finish_kernel(const float* __restrict__ g, float* __restrict__ dw, int rows, int cols,
+                                       int cols_alloc, int ntap, int tap0, int64_t s_row, int64_t s_k, int64_t s_tap) {
+  const int64_t total = (int64_t)ntap * rows * cols;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int col = (int)(i % cols);
+    const int row = (int)((i / cols) % rows);
+    const int t = (int)(i / ((int64_t)cols * rows));
+    const int rows8 = (rows + 7) / 8;
+    const float v = g[(((int64_t)t * rows8 + (row >> 3)) * cols_alloc + col) * 8 + (row & 7)];
+    dw[row * s_row + col * s_k + (tap0 + t) * s_tap] += v;
+  }
+}
+
+extern "C" int md_wgrad_finish(const float* g, float* dw, int32_t rows, int32_t cols, int32_t cols_alloc, int32_t ntap,
+                               int32_t tap0, int64_t s_row, int64_t s_k, int64_t s_tap, void* stream) {
+  if (!g || !dw || rows <= 0 || cols <= 0 || cols_alloc < cols || ntap <= 0) return MD_ERR_BAD_ARG;
+  const int64_t total = (int64_t)ntap * rows * cols;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  MD_HIP_CLEAR_ERROR();
+  hipLaunchKernelGGL(md_wgrad_finish_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g, dw, rows, cols,
+                     cols_alloc, ntap, tap0, s_row, s_k, s_tap);
+  MD_HIP_CHECK_LAUNCH();
+  return MD_OK;
+}
+
+// ---- GroupNorm (+SiLU) backward -----------------------------------------------------------------------------------
+// forward: z = (x - mu) * a + beta, a = rstd*gamma; y = silu ? z*sigmoid(z) : z.   params float4 = (mu, a, beta, rstd).
+// pass 1 (stats):    S1[b,c] = sum_p dz, S2[b,c] = sum_p dz * xhat      (dz = dy * silu'(z), xhat = (x-mu)*rstd)
+// pass 2 (finalize): per (b, group): G1 = sum_c gamma_c S1, G2 = sum_c gamma_c S2;
+//                    coef[b,c] = (rstd*gamma_c, rstd*G1/n, rstd*G2/n, 0); dgamma[c] += S2[b,c]; dbeta[c] += S1[b,c]
+// pass 3 (apply):    dx = k1*dz - k2 - xhat*k3   (+= into dx when accumulate)
+static constexpr int GB_BLOCK = 256, GB_ITEMS = 16, GB_CHUNK = GB_BLOCK * GB_ITEMS / 2;
+
+__device__ __forceinline__ float md_silu_grad(float z) {
+  const float s = 1.0f / (1.0f + expf(-z));
+  return s * (1.0f + z * (1.0f - s));
+}
+
+__global__ __launch_bounds__(GB_BLOCK) void md_gn_bwd_stats_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                   const float* __restrict__ params, double* __restrict__ sums,
+                                                                   int C, int64_t P, int c_total, int c_off, int dy_ctotal,
+                                                                   int silu) {
+  const int cg = blockIdx.y, b = blockIdx.z;
+  const int tid = threadIdx.x, half = tid & 1;
+  const int64_t p0 = (int64_t)blockIdx.x * GB_CHUNK;
+  const f32x4* xp = (const f32x4*)(x + (((int64_t)b * (C / 8) + cg) * P) * 8);
+  const f32x4* dp = (const f32x4*)(dy + (((int64_t)b * (dy_ctotal / 8) + (c_off / 8) + cg) * P) * 8);
+  float mu[4], a[4], bt[4], r[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const f32x4 pr = *(const f32x4*)(params + ((int64_t)b * c_total + c_off + cg * 8 + half * 4 + e) * 4);
+    mu[e] = pr[0]; a[e] = pr[1]; bt[e] = pr[2]; r[e] = pr[3];
+  }
+  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < GB_ITEMS; ++i) {
+    const int64_t pos = p0 + ((tid + i * GB_BLOCK) >> 1);
+    if (pos < P) {
+      const f32x4 xv = xp[pos * 2 + half], dv = dp[pos * 2 + half];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float xc = xv[e] - mu[e];
+        const float z = xc * a[e] + bt[e];
+        const float dz = silu ? dv[e] * md_silu_grad(z) : dv[e];
+        s1[e] += dz;
+        s2[e] += dz * (xc * r[e]);
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+#pragma unroll
+    for (int o = 32; o > 1; o >>= 1) { s1[e] += __shfl_xor(s1[e], o, 64); s2[e] += __shfl_xor(s2[e], o, 64); }
+  }
+  __shared__ float red[GB_BLOCK / 64][2][8];
+  const int lane = tid & 63, wid = tid >> 6;
+  if (lane < 2) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { red[wid][lane][e] = s1[e]; red[wid][lane][4 + e] = s2[e]; }
+  }
+  __syncthreads();
+  if (tid < 16) {
+    const int hh = (tid >> 2) & 1, e = tid & 3, which = tid >> 3;
+    double acc = 0.0;
+    for (int w = 0; w < GB_BLOCK / 64; ++w) acc += (double)red[w][hh][which * 4 + e];
+    atomicAdd(&sums[((int64_t)b * c_total + c_off + cg * 8 + hh * 4 + e) * 2 + which], acc);
+  }
+}
+
+__global__ void md_gn_bwd_finalize_kernel(const double* __restrict__ sums, const float* __restrict__ params,
+                                          const float* __restrict__ gamma, float* __restrict__ coef,
+                                          float* __restrict__ dgamma, float* __restrict__ dbeta, int c_total, int groups,
+                                          int64_t P) {
+  const int b = blockIdx.x / groups, g = blockIdx.x % groups;
+  const int cpg = c_total / groups;
+  const int lane = threadIdx.x;
+  double g1 = 0.0, g2 = 0.0;
+  for (int c = lane; c < cpg; c += 64) {
+    const int ch = g * cpg + c;
+    const int64_t o = ((int64_t)b * c_total + ch) * 2;
+    g1 += (double)gamma[ch] * sums[o];
+    g2 += (double)gamma[ch] * sums[o + 1];
+    if (dbeta) atomicAdd(&dbeta[ch], (float)sums[o]);
+    if (dgamma) atomicAdd(&dgamma[ch], (float)sums[o + 1]);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { g1 += __shfl_xor(g1, o, 64); g2 += __shfl_xor(g2, o, 64); }
+  const double n = (double)cpg * (double)P;
+  for (int c = lane; c < cpg; c += 64) {
+    const int ch = g * cpg + c;
+    const float r = params[((int64_t)b * c_total + ch) * 4 + 3];
+    f32x4 o4 = {r * gamma[ch], (float)((double)r * g1 / n), (float)((double)r * g2 / n), 0.f};
+    *(f32x4*)(coef + ((int64_t)b * c_total + ch) * 4) = o4;
+  }
+}
+
+__global__ __launch_bounds__(GB_BLOCK) void md_gn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                   const float* __restrict__ params, const float* __restrict__ coef,
+                                                                   float* __restrict__ dx, int C, int64_t P, int c_total,
+                                                                   int c_off, int dy_ctotal, int silu, int accumulate) {
+  const int cg = blockIdx.y, b = blockIdx.z;
+  const int tid = threadIdx.x, half = tid & 1;
+  const int64_t p0 = (int64_t)blockIdx.x * GB_CHUNK;
+  const int64_t xo = (((int64_t)b * (C / 8) + cg) * P) * 8;
+  const f32x4* xp = (const f32x4*)(x + xo);
+  f32x4* op = (f32x4*)(dx + xo);
+  const f32x4* dp = (const f32x4*)(dy + (((int64_t)b * (dy_ctotal / 8) + (c_off / 8) + cg) * P) * 8);
+  float mu[4], a[4], bt[4], r[4], k1[4], k2[4], k3[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int64_t ci = ((int64_t)b * c_total + c_off + cg * 8 + half * 4 + e) * 4;
+    const f32x4 pr = *(const f32x4*)(params + ci), cf = *(const f32x4*)(coef + ci);
+    mu[e] = pr[0]; a[e] = pr[1]; bt[e] = pr[2]; r[e] = pr[3]; k1[e] = cf[0]; k2[e] = cf[1]; k3[e] = cf[2];
+  }
+#pragma unroll
+  for (int i = 0; i < GB_ITEMS; ++i) {
+    const int64_t pos = p0 + ((tid + i * GB_BLOCK) >> 1);
+    if (pos < P) {
+      const f32x4 xv = xp[pos * 2 + half], dv = dp[pos * 2 + half];
+      f32x4 o = {0.f, 0.f, 0.f, 0.f};
+      if (accumulate) o = op[pos * 2 + half];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float xc = xv[e] - mu[e];
+        const float z = xc * a[e] + bt[e];
+        const float dz = silu ? dv[e] * md_silu_grad(z) : dv[e];
+        o[e] += k1[e] * dz - k2[e] - (xc * r[e]) * k3[e];
+      }
+      op[pos * 2 + half] = o;
+    }
+  }
+}
+
+extern "C" int md_gn_bwd_stats(const float* x, const float* dy, const float* params, double* sums, int32_t batch, int32_t C,
+                               int64_t P, int32_t c_total, int32_t c_off, int32_t dy_ctotal, int32_t silu, void* stream) {
+  if (!x || !dy || !params || !sums || batch <= 0 || C <= 0 || (C % 8) || (c_off % 8) || c_off + C > c_total) return MD_ERR_BAD_ARG;
+  dim3 grid((unsigned)((P + GB_CHUNK - 1) / GB_CHUNK), (unsigned)(C / 8), (unsigned)batch);
+  MD_HIP_CLEAR_ERROR();
+  hipLaunchKernelGGL(md_gn_bwd_stats_kernel, grid, dim3(GB_BLOCK), 0, (hipStream_t)stream, x, dy, params, sums, C, P, c_total,
+                     c_off, dy_ctotal, silu);
+  MD_HIP_CHECK_LAUNCH();
+  return MD_OK;
+}
+
+extern "C" int md_gn_bwd_finalize(const double* sums, const float* params, const float* gamma, float* coef, float* dgamma,
+                                  float* dbeta, int32_t batch, int32_t c_total, int32_t groups, int64_t P, void* stream) {
+  if (!sums || !params || !gamma || !coef || batch <= 0 || groups <= 0 || (c_total % groups)) return MD_ERR_BAD_ARG;
+  MD_HIP_CLEAR_ERROR();
+  hipLaunchKernelGGL(md_gn_bwd_finalize_kernel, dim3((unsigned)(batch * groups)), dim3(64), 0, (hipStream_t)stream, sums, params,
+                     gamma, coef, dgamma, dbeta, c_total, groups, P);
+  MD_HIP_CHECK_LAUNCH();
+  return MD_OK;
+}
+
+extern "C" int md_gn_bwd_apply(const float* x, const float* dy, const float* params, const float* coef, float* dx, int32_t batch,
+                               int32_t C, int64_t P, int32_t c_total, int32_t c_off, int32_t dy_ctotal, int32_t silu,
+                               int32_t accumulate, void* stream) {
+  if (!x || !dy || !params || !coef || !dx || batch <= 0 || C <= 0 || (C % 8) || (c_off % 8) || c_off + C > c_total) return MD_ERR_BAD_ARG;
+  dim3 grid((unsigned)((P + GB_CHUNK - 1) / GB_CHUNK), (unsigned)(C / 8), (unsigned)batch);
+  MD_HIP_CLEAR_ERROR();
+  hipLaunchKernelGGL(md_gn_bwd_apply_kernel, grid, dim3(GB_BLOCK), 0, (hipStream_t)stream, x, dy, params, coef, dx, C, P, c_total,
+                     c_off, dy_ctotal, silu, accumulate);
+  MD_HIP_CHECK_LAUNCH();
+  return MD_OK;
+}
+
+// ---- per-(b, channel) sums of an F32B tensor (bias / FiLM gradients): out[b][c] (+)= sum_p x ----------------------
+__global__ __launch_bounds__(256) void md_channel_sums_kernel(const float* __restrict__ x, float* __restrict__ out, int C, int64_t P) {
+  const int cg = blockIdx.y, b = blockIdx.z;
+  const int tid = threadIdx.x, half = tid & 1;
+  const int64_t p0 = (int64_t)blockIdx.x * GB_CHUNK;
+  const f32x4* xp = (const f32x4*)(x + (((int64_t)b * (C / 8) + cg) * P) * 8);
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < GB_ITEMS; ++i) {
+    const int64_t pos = p0 + ((tid + i * 256) >> 1);
+    if (pos < P) { const f32x4 v = xp[pos * 2 + half]; s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3]; }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+#pragma unroll
+    for (int o = 32; o > 1; o >>= 1) s[e] += __shfl_xor(s[e], o, 64);
+  if ((tid & 63) < 2) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) atomicAdd(&out[(int64_t)b * C + cg * 8 + (tid & 1) * 4 + e], s[e]);
+  }
+}
+
+extern "C" int md_channel_sums(const float* x, float* out, int32_t batch, int32_t C, int64_t P, void* stream) {
+  if (!x || !out || batch <= 0 || C <= 0 || (C % 8) || P <= 0) return MD_ERR_BAD_ARG;
+  dim3 grid((unsigned)((P + GB_CHUNK - 1) / GB_CHUNK), (unsigned)(C / 8), (unsigned)batch);
+  MD_HIP_CLEAR_ERROR();
+  hipLaunchKernelGGL(md_channel_sums_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, out, C, P);
+  MD_HIP_CHECK_LAUNCH();
+  return MD_OK;
+}
+
+// ---- F32B resampling of gradients: mode 0: out[coarse] (+)= sum of the 8 fine children (Upsample backward);
+//      mode 1: out[fine 2o+1] = in[coarse o], zeros elsewhere (zero-stuffing for the stride-2 conv's dgrad) -------------
+__global__ void md_grad_resample_kernel(const float* __restrict__ in, float* __restrict__ out, int CG, int Dc, int Hc, int Wc,
+                                        int mode, int accumulate) {
+  const int64_t Pc = (int64_t)Dc * Hc * Wc, Pf = Pc * 8;
+  const int Hf = 2 * Hc, Wf = 2 * Wc;
+  const int64_t total = (mode == 0 ? Pc : Pf) * CG * 2;  // float4 items per batch
+  const int b = blockIdx.y;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int half = (int)(i & 1);
+    const int64_t pq = (i >> 1) % (mode == 0 ? Pc : Pf);
+    const int cg = (int)((i >> 1) / (mode == 0 ? Pc : Pf));
+    if (mode == 0) {
+      const int x = (int)(pq % Wc), y = (int)((pq / Wc) % Hc), z = (int)(pq / ((int64_t)Wc * Hc));
+      f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int64_t pf = ((int64_t)(2 * z + (k >> 2)) * Hf + (2 * y + ((k >> 1) & 1))) * Wf + (2 * x + (k & 1));
+        const f32x4 v = *(const f32x4*)(in + ((((int64_t)b * CG + cg) * Pf + pf) * 8 + half * 4));
+        s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
+      }
+      f32x4* o = (f32x4*)(out + ((((int64_t)b * CG + cg) * Pc + pq) * 8 + half * 4));
+      if (accumulate) { const f32x4 p = *o; s[0] += p[0]; s[1] += p[1]; s[2] += p[2]; s[3] += p[3]; }
+      *o = s;
+    } else {
+      const int x = (int)(pq % Wf), y = (int)((pq / Wf) % Hf), z = (int)(pq / ((int64_t)Wf * Hf));
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if ((x & 1) && (y & 1) && (z & 1)) {
+        const int64_t pc = ((int64_t)(z >> 1) * Hc + (y >> 1)) * Wc + (x >> 1);
+        v = *(const f32x4*)(in + ((((int64_t)b * CG + cg) * Pc + pc) * 8 + half * 4));
+      }
+      *(f32x4*)(out + ((((int64_t)b * CG + cg) * Pf + pq) * 8 + half * 4)) = v;
+    }
+  }
+}
+
+extern "C" int md_grad_resample(const float* in, float* out, int32_t batch, int32_t C, int32_t Dc, int32_t Hc, int32_t Wc,
+                                int32_t mode, int32_t accumulate, void* stream) {
+  if (!in || !out || batch <= 0 || C <= 0 || (C % 8) || Dc <= 0 || Hc <= 0 || Wc <= 0 || mode < 0 || mode > 1) return MD_ERR_BAD_ARG;
+  const int64_t total = (int64_t)Dc * Hc * Wc * (mode == 0 ? 1 : 8) * (C / 8) * 2;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  MD_HIP_CLEAR_ERROR();
+  hipLaunchKernelGGL(md_grad_resample_kernel, dim3((unsigned)blocks, (unsigned)batch), dim3(256), 0, (hipStream_t)stream, in, out,
+                     C / 8, Dc, Hc, Wc, mode, accumulate);
+  MD_HIP_CHECK_LAUNCH();
+  return MD_OK;
+}

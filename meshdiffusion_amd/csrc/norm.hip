@@ -49,7 +49,7 @@ __global__ __launch_bounds__(GN_BLOCK) void md_gn_stats_kernel(const float* __re
   }
 }
 
-// params: float4 [B][c_total] = (mean, rstd*gamma, beta, 0)
+// params: float4 [B][c_total] = (mean, rstd*gamma, beta, rstd)
 __global__ void md_gn_finalize_kernel(const double* __restrict__ sums, const float* __restrict__ gamma,
                                       const float* __restrict__ beta, float* __restrict__ params,
                                       int c_total, int groups, int64_t P, float eps) {
@@ -71,7 +71,7 @@ __global__ void md_gn_finalize_kernel(const double* __restrict__ sums, const flo
   const float rstd = (float)(1.0 / sqrt(var + (double)eps));
   for (int c = lane; c < cpg; c += 64) {
     const int ch = g * cpg + c;
-    f32x4 o4 = {(float)mean, rstd * gamma[ch], beta[ch], 0.f};
+    f32x4 o4 = {(float)mean, rstd * gamma[ch], beta[ch], rstd};  // [3] = rstd: used by the backward pass
     *(f32x4*)(params + ((int64_t)b * c_total + ch) * 4) = o4;
   }
 }

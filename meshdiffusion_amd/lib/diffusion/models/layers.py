@@ -236,11 +236,18 @@ class Upsample(HipLayer):
         self.Conv_0 = ddpm_conv3x3(channels, channels)
         self.with_conv = with_conv
 
-    def forward_blocked(self, x, Cc, B, P):
+    def forward_blocked(self, x, Cc, B, P, tape=None):
         s_out = 2 * _spatial_edge(P)
         pw = conv3_packed(self, "w", self.Conv_0, ops.conv_cfg_for(s_out))
         act = ops.gn_apply([(x, Cc)], None, B, P, norm=False, silu=False, fp16=pw.prec == ops.PREC_FP16X2)
+        if tape is not None:
+            assert pw.prec == ops.PREC_BF16X3
+            tape.append(dict(layer=self, act=act, B=B, S_out=s_out))
         return run_conv3(pw, act, B, s_out, bias=self.Conv_0.bias, ups=1)
+
+    def backward_blocked(self, sv, dy):
+        from . import backward as bw
+        return bw.conv3_backward(self, "w", self.Conv_0, dy, sv["act"], sv["B"], sv["S_out"], ups=1)
 
     def forward(self, x):
         parts, B, P, spatial = _parts_of(x)
@@ -255,11 +262,17 @@ class Downsample(HipLayer):
         self.Conv_0 = ddpm_conv3x3(channels, channels, stride=2, padding=0)
         self.with_conv = with_conv
 
-    def forward_blocked(self, x, Cc, B, P):
+    def forward_blocked(self, x, Cc, B, P, tape=None):
         s_out = _spatial_edge(P) // 2
         act = ops.gn_apply([(x, Cc)], None, B, P, norm=False, silu=False)
         pw = conv3_packed(self, "w", self.Conv_0, ops.conv_cfg_for(s_out, stride=2))
+        if tape is not None:
+            tape.append(dict(layer=self, act=act, B=B, S_out=s_out))
         return run_conv3(pw, act, B, s_out, bias=self.Conv_0.bias)
+
+    def backward_blocked(self, sv, dy):
+        from . import backward as bw
+        return bw.conv3_backward(self, "w", self.Conv_0, dy, sv["act"], sv["B"], sv["S_out"], stride=2)
 
     def forward(self, x):
         parts, B, P, spatial = _parts_of(x)
@@ -295,11 +308,12 @@ class ResnetBlockDDPM(HipLayer):
                                 lambda: (self.Conv_0.bias.detach() + self.Dense_0.bias.detach()).contiguous())
         return self.Conv_0.bias
 
-    def forward_blocked(self, parts, B, P, temb=None, bias0=None, bias0_stride=None):
+    def forward_blocked(self, parts, B, P, temb=None, bias0=None, bias0_stride=None, tape=None):
         """bias0 (optional): precomputed Conv_0.bias + Dense_0(SiLU(temb)) rows [B, out_ch] with row stride
-        `bias0_stride` floats (the U-Net computes all blocks' FiLM biases in one launch)."""
+        `bias0_stride` floats (the U-Net computes all blocks' FiLM biases in one launch).
+        tape (optional list): receives what `backward_blocked` needs (training)."""
         if self.training and self.Dropout_0.p > 0:
-            raise NotImplementedError("training-mode dropout/backward is not implemented on the HIP path yet")
+            raise NotImplementedError("dropout > 0 is not implemented on the HIP path yet (use dropout = 0)")
         S = _spatial_edge(P)
         cin = sum(c for _, c in parts)
         assert cin == self.in_ch
@@ -327,7 +341,40 @@ class ResnetBlockDDPM(HipLayer):
         else:
             assert len(parts) == 1
             res = parts[0][0]
+        if tape is not None:
+            assert not f16, "the backward pass uses the bf16x3 operand format"
+            tape.append(dict(layer=self, parts=parts, prm0=prm, a0=a0, h=h, prm1=prm1, a1=a1, xs=xs, B=B, P=P, S=S,
+                             temb=temb))
         return run_conv3(pw1, a1, B, S, bias=self.Conv_1.bias, residual=res)
+
+    def backward_blocked(self, sv, dy):
+        """dy: F32B [B][out_ch][P].  Returns ([grad per input part], dbias0 [B, out_ch]); accumulates .grad of
+        Conv_0/Conv_1/GroupNorm_0/GroupNorm_1/NIN_0 (Dense_0 is handled by the caller from dbias0)."""
+        from . import backward as bw
+        B, P, S, parts = sv["B"], sv["P"], sv["S"], sv["parts"]
+        d_a1 = bw.conv3_backward(self, "w1", self.Conv_1, dy, sv["a1"], B, S)
+        d_h = bw.gn_backward([(sv["h"], self.out_ch)], d_a1, sv["prm1"], self.GroupNorm_1, B, P, silu=True)[0]
+        del d_a1
+        dbias0 = bw.channel_sums(d_h, B, self.out_ch, P)
+        d_a0 = bw.conv3_backward(self, "w0", self.Conv_0, d_h, sv["a0"], B, S)
+        bw._grad_of(self.Conv_0.bias).sub_(dbias0.sum(0))   # conv3_backward added it; FiLM caller re-adds once
+        del d_h
+        if self.in_ch != self.out_ch:
+            d_xcat = bw.nin_backward(self.NIN_0, dy, sv["xs"], B, P, S)
+            dparts = bw.gn_backward(parts, d_a0, sv["prm0"], self.GroupNorm_0, B, P, silu=True)
+            off, outs = 0, []
+            for (t, c), g in zip(parts, dparts):
+                sl = d_xcat.view(B, self.in_ch // 8, P, 8)[:, off // 8:(off + c) // 8]
+                if len(parts) == 1:
+                    g.add_(d_xcat)
+                else:
+                    g.add_(sl)
+                outs.append(g)
+                off += c
+            return outs, dbias0
+        d_x = dy.clone()
+        bw.gn_backward(parts, d_a0, sv["prm0"], self.GroupNorm_0, B, P, silu=True, d_into=d_x)
+        return [d_x], dbias0
 
     def forward(self, x, temb=None):
         parts, B, P, spatial = _parts_of(x)
