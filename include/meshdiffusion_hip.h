@@ -261,6 +261,11 @@ int md_gn_bwd_apply(const float* x, const float* dy, const float* params, const 
                     int32_t C, int64_t P, int32_t c_total, int32_t c_off, int32_t dy_ctotal, int32_t silu,
                     int32_t accumulate, void* stream);
 int md_channel_sums(const float* x, float* out, int32_t batch, int32_t C, int64_t P, void* stream);
+/* S16B blocked transpose: in [B][R/8][2][Cn][8] -> out [B][Cn/8][2][R][8] (attention backward operands). */
+int md_s16b_transpose(const void* in, void* out, int32_t batch, int32_t R, int32_t Cn, void* stream);
+/* softmax-over-keys backward: ds = split(alpha * P * (dP - sum_keys P*dP)); layouts as md_softmax_keys. */
+int md_softmax_keys_bwd(const void* p, const float* dp, void* ds, int32_t batch, int32_t n_keys, int32_t n_q,
+                        float alpha, void* stream);
 int md_grad_resample(const float* in, float* out, int32_t batch, int32_t C, int32_t Dc, int32_t Hc, int32_t Wc,
                      int32_t mode, int32_t accumulate, void* stream);
 

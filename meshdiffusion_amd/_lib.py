@@ -74,6 +74,8 @@ SIGNATURES = {
     "md_gn_bwd_finalize": (C.c_int, [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I64, _P]),
     "md_gn_bwd_apply": (C.c_int, [_P, _P, _P, _P, _P, _I32, _I32, _I64, _I32, _I32, _I32, _I32, _I32, _P]),
     "md_channel_sums": (C.c_int, [_P, _P, _I32, _I32, _I64, _P]),
+    "md_s16b_transpose": (C.c_int, [_P, _P, _I32, _I32, _I32, _P]),
+    "md_softmax_keys_bwd": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _F, _P]),
     "md_grad_resample": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P]),
     "md_marching_tets_workspace_bytes": (_I64, [_I32, _I32]),
     "md_marching_tets": (C.c_int, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _I64, _P]),

@@ -343,3 +343,93 @@ extern "C" int md_grad_resample(const float* in, float* out, int32_t batch, int3
   MD_HIP_CHECK_LAUNCH();
   return MD_OK;
 }
+
+// ---- S16B blocked transpose: in [B][R/8][2][Cn][8r] -> out [B][Cn/8][2][R][8c]  (swap which index is 8-blocked) ------
+__global__ void md_s16b_transpose_kernel(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, int R, int Cn) {
+  const int b = blockIdx.y;
+  const int64_t total = (int64_t)(R / 8) * (Cn / 8) * 2;  // one thread = one 8x8 block of one plane
+  const uint16_t* ib = in + (int64_t)b * R * Cn * 2;
+  uint16_t* ob = out + (int64_t)b * R * Cn * 2;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int part = (int)(i & 1);
+    const int cb = (int)((i >> 1) % (Cn / 8));
+    const int rb = (int)((i >> 1) / (Cn / 8));
+    uint16_t blk[8][8];  // [c][r]
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const uint4 v = *(const uint4*)(ib + ((((int64_t)rb * 2 + part) * Cn) + cb * 8 + c) * 8);
+      const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { blk[c][2 * k] = (uint16_t)(w[k] & 0xffff); blk[c][2 * k + 1] = (uint16_t)(w[k] >> 16); }
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      uint32_t w[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) w[k] = (uint32_t)blk[2 * k][r] | ((uint32_t)blk[2 * k + 1][r] << 16);
+      *(uint4*)(ob + ((((int64_t)cb * 2 + part) * R) + rb * 8 + r) * 8) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+  }
+}
+
+extern "C" int md_s16b_transpose(const void* in, void* out, int32_t batch, int32_t R, int32_t Cn, void* stream) {
+  if (!in || !out || batch <= 0 || R <= 0 || Cn <= 0 || (R % 8) || (Cn % 8)) return MD_ERR_BAD_ARG;
+  const int64_t total = (int64_t)(R / 8) * (Cn / 8) * 2;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  MD_HIP_CLEAR_ERROR();
+  hipLaunchKernelGGL(md_s16b_transpose_kernel, dim3((unsigned)blocks, (unsigned)batch), dim3(256), 0, (hipStream_t)stream,
+                     (const uint16_t*)in, (uint16_t*)out, R, Cn);
+  MD_HIP_CHECK_LAUNCH();
+  return MD_OK;
+}
+
+// ---- softmax-over-keys backward: dS[key][q] = alpha * P[key][q] * (dP[key][q] - sum_key' P[key'][q] dP[key'][q]) ------
+// p: S16B [B][NK/8][2][NQ][8] (hi+lo = P), dp: fp32 [B][NK/8][NQ][8]; ds: S16B like p (split of dS).
+__global__ __launch_bounds__(256) void md_softmax_keys_bwd_kernel(const uint16_t* __restrict__ p, const float* __restrict__ dp,
+                                                                  uint16_t* __restrict__ ds, int nk, int nq, float alpha) {
+  const int b = blockIdx.y;
+  const int tid = threadIdx.x, half = tid & 1, ql = (tid >> 1) & 31, ks = tid >> 6;
+  const int q = blockIdx.x * 32 + ql;
+  const int nkb = nk / 8;
+  const int64_t plane = (int64_t)nq * 8;
+  const uint16_t* pb = p + (int64_t)b * nkb * 2 * plane;
+  uint16_t* ob = ds + (int64_t)b * nkb * 2 * plane;
+  const f32x4* dpp = (const f32x4*)(dp + (int64_t)b * nk * nq);
+  float dot = 0.f;
+  for (int kb = ks; kb < nkb; kb += 4) {
+    const uint16_t* ph = pb + ((int64_t)kb * 2) * plane + (int64_t)q * 8 + half * 4;
+    const uint2 h2 = *(const uint2*)ph, l2 = *(const uint2*)(ph + plane);
+    const f32x4 dv = dpp[((int64_t)kb * nq + q) * 2 + half];
+    const float pv[4] = {md_bf2f(h2.x & 0xffff) + md_bf2f(l2.x & 0xffff), md_bf2f(h2.x >> 16) + md_bf2f(l2.x >> 16),
+                         md_bf2f(h2.y & 0xffff) + md_bf2f(l2.y & 0xffff), md_bf2f(h2.y >> 16) + md_bf2f(l2.y >> 16)};
+    dot += pv[0] * dv[0] + pv[1] * dv[1] + pv[2] * dv[2] + pv[3] * dv[3];
+  }
+  dot += __shfl_xor(dot, 1, 64);
+  __shared__ float sd[4][32];
+  if (half == 0) sd[ks][ql] = dot;
+  __syncthreads();
+  const float tot = sd[0][ql] + sd[1][ql] + sd[2][ql] + sd[3][ql];
+  for (int kb = ks; kb < nkb; kb += 4) {
+    const int64_t o = ((int64_t)kb * 2) * plane + (int64_t)q * 8 + half * 4;
+    const uint2 h2 = *(const uint2*)(pb + o), l2 = *(const uint2*)(pb + o + plane);
+    const f32x4 dv = dpp[((int64_t)kb * nq + q) * 2 + half];
+    const float pv[4] = {md_bf2f(h2.x & 0xffff) + md_bf2f(l2.x & 0xffff), md_bf2f(h2.x >> 16) + md_bf2f(l2.x >> 16),
+                         md_bf2f(h2.y & 0xffff) + md_bf2f(l2.y & 0xffff), md_bf2f(h2.y >> 16) + md_bf2f(l2.y >> 16)};
+    uint32_t hi[4], lo[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) md_split(alpha * pv[e] * (dv[e] - tot), hi[e], lo[e]);
+    *(uint2*)(ob + o) = make_uint2(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16));
+    *(uint2*)(ob + o + plane) = make_uint2(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16));
+  }
+}
+
+extern "C" int md_softmax_keys_bwd(const void* p, const float* dp, void* ds, int32_t batch, int32_t n_keys, int32_t n_q,
+                                   float alpha, void* stream) {
+  if (!p || !dp || !ds || batch <= 0 || n_keys <= 0 || (n_keys % 8) || n_q <= 0 || (n_q % 32)) return MD_ERR_BAD_ARG;
+  MD_HIP_CLEAR_ERROR();
+  hipLaunchKernelGGL(md_softmax_keys_bwd_kernel, dim3((unsigned)(n_q / 32), (unsigned)batch), dim3(256), 0, (hipStream_t)stream,
+                     (const uint16_t*)p, dp, (uint16_t*)ds, n_keys, n_q, alpha);
+  MD_HIP_CHECK_LAUNCH();
+  return MD_OK;
+}

@@ -2,11 +2,11 @@
 lib/diffusion/losses.py (`get_optimizer` :26-35, `optimization_manager` :38-52, `get_ddpm_loss_fn` :54-85,
 `get_step_fn` :87-141).
 
-On the HIP path today: the forward noising, the masked loss (and its gradient w.r.t. eps_hat), the global
-grad-norm, and the fused clip + Adam + EMA update are HIP kernels (csrc/train.hip); the evaluation branch of
-`get_step_fn` (loss under EMA weights, losses.py:130-136) runs end to end.  The training branch needs the
-U-Net backward kernels, which are not built yet: it raises NotImplementedError when the model is called in
-training mode.
+On the HIP path: forward noising, the masked loss and its gradient w.r.t. eps_hat, the U-Net forward AND
+backward (models/backward.py), the global grad-norm and the fused clip + Adam + EMA update.  `loss.backward()`
+works because the U-Net and the loss are each one opaque autograd node whose backward is the HIP code; the
+reference's `optimize_fn` (torch.optim.Adam + clip_grad_norm_) can then be used unchanged, or `FusedAdamEMA`.
+Current limits of the training path: dropout must be 0, per-GPU batch a multiple of 8, ddpm_res64 only.
 """
 import ctypes as C
 
@@ -77,15 +77,32 @@ def get_ddpm_loss_fn(vpsde, train, mask=None, loss_type="l2"):
         noise = torch.randn_like(batch)
         mask_flat = mask.reshape(-1).to(batch.device, torch.float32).contiguous() if mask is not None else None
         perturbed = ddpm_perturb(vpsde, batch, labels, noise, mask_flat)
-        score = model_fn(perturbed, labels)     # raises in training mode until the backward kernels exist
-        sums, _ = masked_sq_err(score, noise, mask_flat)
-        per_sample = (sums / float(batch[0].numel())).to(torch.float32)   # mean over (C, D, H, W)
-        loss = per_sample.mean()
+        score = model_fn(perturbed, labels)
+        norm = 1.0
         if mask is not None:
-            loss = loss / mask.sum().to(loss.device) * float(np.prod(mask.size()))
-        return loss
+            norm = float(np.prod(mask.size())) / float(mask.sum())
+        return _MaskedDDPMLoss.apply(score, noise, mask_flat, norm)
 
     return loss_fn
+
+
+class _MaskedDDPMLoss(torch.autograd.Function):
+    """loss = mean_b( mean_{c,p}( (score-noise)^2 * mask ) ) * norm, with norm = mask.numel()/mask.sum()
+    (losses.py:68-78).  Forward and the gradient w.r.t. `score` come from one md_masked_sq_err launch."""
+
+    @staticmethod
+    def forward(ctx, score, noise, mask_flat, norm):
+        B = score.shape[0]
+        per = float(score[0].numel())
+        want = score.requires_grad
+        sums, grad = masked_sq_err(score.detach(), noise, mask_flat, want_grad=want, gscale=norm / (B * per))
+        ctx.grad = grad
+        loss = (sums / per).to(torch.float32).mean() * norm
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        return (ctx.grad * g if ctx.grad is not None else None), None, None, None
 
 
 def get_step_fn(sde, train, optimize_fn=None, mask=None, loss_type="l2"):
@@ -97,7 +114,7 @@ def get_step_fn(sde, train, optimize_fn=None, mask=None, loss_type="l2"):
             optimizer = state["optimizer"]
             if clear_grad:
                 optimizer.zero_grad()
-            loss = loss_fn(model, batch)      # NotImplementedError: no HIP backward yet
+            loss = loss_fn(model, batch)
             loss.backward()
             if update_param:
                 optimize_fn(optimizer, model.parameters(), step=state["step"])

@@ -52,8 +52,9 @@ def to_pb16(src, B, C, S, mode, up=0, stuff=0):
     return out
 
 
-def wgrad(dy_pb, act_pb, B, co, ci, S, taps, dw, s_row, s_k, s_tap):
-    """dw[co][ci][tap] += sum_{pos,b} dy[co][pos,b] * act[ci][pos + off(tap), b]   (taps = 27 or 1)."""
+def wgrad(dy_pb, act_pb, B, co, ci, S, taps, dw, s_row, s_k, s_tap, a_ch=None):
+    """dw[co][ci][tap] += sum_{pos,b} dy[co][pos,b] * act[ci][pos + off(tap), b]   (taps = 27 or 1).
+    a_ch: channel count of the dy PB16 tensor when it was padded beyond `co`."""
     lib = _lib.load()
     g = _guard(S)
     Sp = S + 2
@@ -61,14 +62,15 @@ def wgrad(dy_pb, act_pb, B, co, ci, S, taps, dw, s_row, s_k, s_tap):
     kpos = ((Pp + 3) // 4) * 4
     bg = B // 8
     kdim = kpos * bg * 8
-    a_pos = bg * 2 * co * 8          # bf16 elements per position of the A (dy) operand
+    a_ch = co if a_ch is None else a_ch
+    a_pos = bg * 2 * a_ch * 8        # bf16 elements per position of the A (dy) operand
     b_pos = bg * 2 * ci * 8
     cfg = ops.CFG_G1_128_LOW
     assert ci % 64 == 0, "wgrad needs the activation channel count to be a multiple of 64 (pad with zeros)"
     rows8 = ((co + 7) // 8) * 8
     tiles = (ci // 64) * ((co + 127) // 128)
     ksplit = 1
-    while tiles * 3 * ksplit < 1024 and ksplit < 256:
+    while tiles * 3 * ksplit < 1024 and ksplit < 256 and ksplit * 2 <= kdim // 32:
         ksplit *= 2
     a_base = dy_pb[g * a_pos:]
     groups = [(dz, dyy) for dz in range(3) for dyy in range(3)] if taps == 27 else [(1, 1)]
@@ -78,7 +80,7 @@ def wgrad(dy_pb, act_pb, B, co, ci, S, taps, dw, s_row, s_k, s_tap):
         b_base = act_pb[(g + off) * b_pos:]
         out = torch.empty((nb, rows8 // 8, ci, 8), dtype=torch.float32, device=dy_pb.device)
         ops.gemm_conv(cfg=cfg, a=a_base, b=b_base, out=out, batch=nb, rows=co, rows_alloc=rows8, kdim=kdim,
-                      dims=(1, 1, ci), a_src=ops.A_S16B, a_rows=co, a_bstride=0, b_bstride=b_pos, ksplit=ksplit)
+                      dims=(1, 1, ci), a_src=ops.A_S16B, a_rows=a_ch, a_bstride=0, b_bstride=b_pos, ksplit=ksplit)
         tap0 = (dz * 3 + dyy) * 3 if taps == 27 else 0
         check(lib.md_wgrad_finish(_ptr(out), _ptr(dw), co, ci, ci, nb, tap0, s_row, s_k, s_tap, _stream()),
               "md_wgrad_finish")
@@ -161,23 +163,24 @@ def conv3_backward(layer, name, conv, dy, act_s16, B, S_out, ups=0, stride=1, ne
     co, ci = conv.weight.shape[0], conv.weight.shape[1]
     P = S_out ** 3
     dev = dy.device
+    co_t = dy.shape[1] * 8            # channels of the dy tensor (co rounded up to 8)
     # bias
-    _grad_of(conv.bias).add_(channel_sums(dy, B, co, P).sum(0))
+    _grad_of(conv.bias).add_(channel_sums(dy, B, co_t, P).sum(0)[:co])
     # weight gradient
     S_fine = S_out * stride
     if stride == 2:
-        dy_pb = to_pb16(dy, B, co, S_fine, 0, stuff=1)
+        dy_pb = to_pb16(dy, B, co_t, S_fine, 0, stuff=1)
     else:
-        dy_pb = to_pb16(dy, B, co, S_out, 0)
+        dy_pb = to_pb16(dy, B, co_t, S_out, 0)
     ci_pad = act_channels if act_channels is not None else ci
     act_pb = to_pb16(act_s16, B, ci_pad, S_fine, 1, up=ups)
     dw = _grad_of(conv.weight)
     if ci_pad != ci:      # stem: the operand was zero padded to 64 channels; accumulate into a padded scratch
         scratch = torch.zeros((co, ci_pad, 27), dtype=torch.float32, device=dev)
-        wgrad(dy_pb, act_pb, B, co, ci_pad, S_fine, 27, scratch, ci_pad * 27, 27, 1)
+        wgrad(dy_pb, act_pb, B, co, ci_pad, S_fine, 27, scratch, ci_pad * 27, 27, 1, a_ch=co_t)
         dw.add_(scratch[:, :ci].reshape(dw.shape))
     else:
-        wgrad(dy_pb, act_pb, B, co, ci, S_fine, 27, dw, ci * 27, 27, 1)
+        wgrad(dy_pb, act_pb, B, co, ci, S_fine, 27, dw, ci * 27, 27, 1, a_ch=co_t)
     del dy_pb, act_pb
     if not need_dx:
         return None
@@ -186,7 +189,7 @@ def conv3_backward(layer, name, conv, dy, act_s16, B, S_out, ups=0, stride=1, ne
         dyz = resample(dy, B, co, S_out, 1)                       # fine grid, dy at odd positions
         cfg = ops.conv_cfg_for(S_fine)
         pw = dgrad_weight(layer, name, conv, cfg)
-        return layers.run_conv3(pw, split_f32b(dyz, B, co, S_fine ** 3), B, S_fine)
+        return layers.run_conv3(pw, split_f32b(dyz, B, co_t, S_fine ** 3), B, S_fine)
     cfg = ops.conv_cfg_for(S_out)
     if cfg == ops.CFG_C3_128_FAST and co % 32 != 0:
         cfg = ops.CFG_C3_128_K16 if co <= 16 else cfg
@@ -197,17 +200,44 @@ def conv3_backward(layer, name, conv, dy, act_s16, B, S_out, ups=0, stride=1, ne
         dy16 = torch.zeros((B, 2, P, 8), dtype=torch.float32, device=dev)
         dy16[:, :dy.shape[1]] = dy
         dyc, co_k = dy16, 16
-    dx = layers.run_conv3(pw, split_f32b(dyc, B, co_k, P), B, S_out)
+    dx = layers.run_conv3(pw, split_f32b(dyc, B, co_k if cfg == ops.CFG_C3_128_K16 else co_t, P), B, S_out)
     if ups:
         dx = resample(dx, B, ci, S_out // 2, 0)
     return dx
 
 
-def nin_backward(nin, dy, xs_s16, B, P, S, need_dx=True):
+def s16b_transpose(t, B, R, Cn):
+    """S16B [B][R/8][2][Cn][8] -> [B][Cn/8][2][R][8]."""
+    lib = _lib.load()
+    out = torch.empty((B, Cn // 8, 2, R, 8), dtype=torch.bfloat16, device=t.device)
+    check(lib.md_s16b_transpose(_ptr(t), _ptr(out), B, R, Cn, _stream()), "md_s16b_transpose")
+    return out
+
+
+def bgemm(a_s16, a_rows, b_s16, cols, kdim, B, out_rows_alloc=None, alpha=1.0):
+    """Batched out[i][j] = alpha * sum_k A[i][k] B[j][k] with both operands S16B ([K/8][2][rows|cols][8] per batch)."""
+    cfg = ops.gemm_cfg_for(cols, a_rows)
+    ra = out_rows_alloc if out_rows_alloc is not None else ((a_rows + 7) // 8) * 8
+    out = torch.empty((B, ra // 8, cols, 8), dtype=torch.float32, device=a_s16.device)
+    ops.gemm_conv(cfg=cfg, a=a_s16, b=b_s16, out=out, batch=B, rows=a_rows, rows_alloc=ra, kdim=kdim, dims=(1, 1, cols),
+                  a_src=ops.A_S16B, a_rows=a_rows, a_bstride=(kdim // 8) * 2 * a_rows * 8,
+                  b_bstride=(kdim // 8) * 2 * cols * 8, alpha=alpha)
+    return out
+
+
+def softmax_keys_bwd(p_s16, dp, B, nk, nq, alpha):
+    lib = _lib.load()
+    ds = torch.empty_like(p_s16)
+    check(lib.md_softmax_keys_bwd(_ptr(p_s16), _ptr(dp), _ptr(ds), B, nk, nq, float(alpha), _stream()), "md_softmax_keys_bwd")
+    return ds
+
+
+def nin_backward(nin, dy, xs_s16, B, P, S, need_dx=True, with_bias=True):
     """Backward of y[co] = sum_ci x[ci] W[ci][co] + b.  xs_s16: S16B of the forward input."""
     from . import layers
     ci, co = nin.W.shape
-    _grad_of(nin.b).add_(channel_sums(dy, B, co, P).sum(0))
+    if with_bias:
+        _grad_of(nin.b).add_(channel_sums(dy, B, co, P).sum(0))
     dy_pb = to_pb16(dy, B, co, S, 0)
     x_pb = to_pb16(xs_s16, B, ci, S, 1)
     wgrad(dy_pb, x_pb, B, co, ci, S, 1, _grad_of(nin.W), 1, co, 0)
@@ -217,3 +247,54 @@ def nin_backward(nin, dy, xs_s16, B, P, S, need_dx=True):
     cfg = ops.gemm_cfg_for(P, ci)
     pw = nin._cached(f"dgrad{cfg}", [nin.W], lambda: ops.PackedWeight(nin.W, "rows", cfg, nin.W.device))
     return layers.run_gemm(pw, split_f32b(dy, B, co, P), B, P)
+
+
+def attn_backward(blk, sv, dy):
+    """Backward of AttnBlock.forward_blocked (single head, keys blocked by 8; see layers.AttnBlock)."""
+    from . import layers
+    B, P, S, Cc = sv["B"], sv["P"], sv["S"], blk.channels
+    x, prm, hN, qk, vT, pr, o = sv["x"], sv["prm"], sv["hN"], sv["qk"], sv["vT"], sv["pr"], sv["o"]
+    alpha = ops.attn_scale(Cc)
+    # y = NIN_3(o) + x
+    d_o = nin_backward(blk.NIN_3, dy, o, B, P, S)                               # F32B [C][P]
+    _grad_of(blk.NIN_2.b).add_(channel_sums(d_o, B, Cc, P).sum(0))              # o = V P + b_v
+    d_o16 = split_f32b(d_o, B, Cc, P)                                           # [C/8][2][q][8c]
+    v_cb = s16b_transpose(vT, B, P, Cc)                                         # [C/8][2][key][8c]
+    dP = bgemm(v_cb, P, d_o16, P, Cc, B)                                        # [key/8][q][8]
+    dS = softmax_keys_bwd(pr, dP, B, P, P, alpha)                               # S16B [key/8][2][q][8key]
+    del dP
+    d_o_q = s16b_transpose(d_o16, B, Cc, P)                                     # [q/8][2][c][8q]
+    pr_q = s16b_transpose(pr, B, P, P)                                          # [q/8][2][key][8q]
+    dV = bgemm(d_o_q, Cc, pr_q, P, P, B)                                        # F32B [c/8][key][8]
+    del pr_q, d_o_q
+    q16 = qk[:, :Cc // 8].contiguous()
+    k16 = qk[:, Cc // 8:].contiguous()
+    kT = s16b_transpose(k16, B, Cc, P)                                          # [key/8][2][c][8key]
+    dq = bgemm(kT, Cc, dS, P, P, B)                                             # [c/8][q][8]
+    qT = s16b_transpose(q16, B, Cc, P)                                          # [q/8][2][c][8q]
+    dS_q = s16b_transpose(dS, B, P, P)                                          # [q/8][2][key][8q]
+    dk = bgemm(qT, Cc, dS_q, P, P, B)                                           # [c/8][key][8]
+    del dS, dS_q, kT, qT
+    dqk = torch.cat([dq, dk], dim=1).contiguous()                               # F32B [2C][P]
+    # q|k = NIN_0|NIN_1 (h)
+    wqk = torch.cat([blk.NIN_0.W.detach(), blk.NIN_1.W.detach()], dim=1).contiguous()   # [C][2C]
+    bsum = channel_sums(dqk, B, 2 * Cc, P).sum(0)
+    _grad_of(blk.NIN_0.b).add_(bsum[:Cc]); _grad_of(blk.NIN_1.b).add_(bsum[Cc:])
+    dw = torch.zeros_like(wqk)
+    dqk_pb = to_pb16(dqk, B, 2 * Cc, S, 0)
+    h_pb = to_pb16(hN, B, Cc, S, 1)
+    wgrad(dqk_pb, h_pb, B, 2 * Cc, Cc, S, 1, dw, 1, 2 * Cc, 0)
+    _grad_of(blk.NIN_0.W).add_(dw[:, :Cc]); _grad_of(blk.NIN_1.W).add_(dw[:, Cc:])
+    del dqk_pb
+    cfg = ops.gemm_cfg_for(P, Cc)
+    pw = ops.PackedWeight(wqk, "rows", cfg, wqk.device)
+    d_h = layers.run_gemm(pw, split_f32b(dqk, B, 2 * Cc, P), B, P)
+    # v = NIN_2(h) (bias handled above)
+    dv_pb = to_pb16(dV, B, Cc, S, 0)
+    wgrad(dv_pb, h_pb, B, Cc, Cc, S, 1, _grad_of(blk.NIN_2.W), 1, Cc, 0)
+    del dv_pb, h_pb
+    pw2 = blk.NIN_2._cached(f"dgrad{cfg}", [blk.NIN_2.W], lambda: ops.PackedWeight(blk.NIN_2.W, "rows", cfg, blk.NIN_2.W.device))
+    d_h.add_(layers.run_gemm(pw2, split_f32b(dV, B, Cc, P), B, P))
+    dx = dy.clone()
+    gn_backward([(x, Cc)], d_h, prm, blk.GroupNorm_0, B, P, silu=False, d_into=dx)
+    return dx

@@ -142,6 +142,174 @@ class DDPMUNet3D(layers.HipLayer):
 
         return self._cached("film", ps, build)
 
+    # ---- training (first correct version; KSIZE 3 / bf16x3 / dropout 0 / batch % 8 == 0) --------------
+    def _autograd_anchor(self):
+        a = self.__dict__.get("_md_anchor")
+        if a is None or a.device != self.mask.device:
+            a = torch.zeros((), device=self.mask.device, requires_grad=True)
+            self.__dict__["_md_anchor"] = a
+        return a
+
+    def forward_train(self, x, labels):
+        """Forward pass that records what `backward` needs.  Returns (eps_hat NCDHW, ctx)."""
+        if self.KSIZE != 3:
+            raise NotImplementedError("training of ddpm_res128 (5x5x5 stem/head) is not implemented yet")
+        ops.set_precision("bf16x3")
+        mods = self.all_modules
+        B, R = x.shape[0], self.img_size
+        if B % 8:
+            raise NotImplementedError("the HIP backward needs a per-GPU batch that is a multiple of 8")
+        P = R ** 3
+        i = 0
+        emb = layers.get_timestep_embedding(labels, self.nf)
+        t1 = ops.linear(emb, mods[0].weight, mods[0].bias); i += 1
+        temb = ops.linear(t1, mods[1].weight, mods[1].bias, silu_in=True); i += 1
+        stem = mods[i]; i += 1
+        x64 = ops.ncdhw_to_s16b(x if self.centered else 2 * x - 1.0, 64)
+        x16 = x64[:, :2].contiguous()
+        pw = layers.conv3_packed(self, "stem", stem, self._stem_cfg())
+        h = layers.run_conv3(pw, x16, B, R, bias=stem.bias, residual=self._stem_const(), res_bstride=0)
+        fw, fb, foffs, ftot = self._film_table()
+        film = ops.linear(temb, fw, fb, silu_in=True)
+        acts, tape = {}, []
+        nid = [0]
+
+        def new(t, c, p):
+            nid[0] += 1
+            acts[nid[0]] = (t, c, p)
+            return nid[0]
+
+        def res(block, in_ids):
+            parts = [(acts[v][0], acts[v][1]) for v in in_ids]
+            p = acts[in_ids[0]][2]
+            tp = []
+            o = foffs[id(block)]
+            y = block.forward_blocked(parts, B, p, temb, bias0=film.view(-1)[o:], bias0_stride=ftot, tape=tp)
+            out = new(y, block.out_ch, p)
+            tape.append(("res", block, tp[0], in_ids, out))
+            return out
+
+        def attn(block, vid):
+            t, c, p = acts[vid]
+            tp = []
+            y = block.forward_blocked(t, B, p, tape=tp)
+            out = new(y, c, p)
+            tape.append(("attn", block, tp[0], [vid], out))
+            return out
+
+        v0 = new(h, self.nf, P)
+        hs = [v0]
+        for lvl in range(self.num_resolutions):
+            for _ in range(self._blocks_at(lvl)):
+                v = res(mods[i], [hs[-1]]); i += 1
+                if self.all_resolutions[lvl] in self.attn_resolutions:
+                    v = attn(mods[i], v); i += 1
+                hs.append(v)
+            if lvl != self.num_resolutions - 1:
+                t, c, p = acts[hs[-1]]
+                tp = []
+                y = mods[i].forward_blocked(t, c, B, p, tape=tp)
+                out = new(y, c, p // 8)
+                tape.append(("down", mods[i], tp[0], [hs[-1]], out)); i += 1
+                hs.append(out)
+        v = hs[-1]
+        v = res(mods[i], [v]); i += 1
+        v = attn(mods[i], v); i += 1
+        v = res(mods[i], [v]); i += 1
+        for lvl in reversed(range(self.num_resolutions)):
+            for _ in range(self._blocks_at(lvl) + 1):
+                v = res(mods[i], [v, hs.pop()]); i += 1
+            if self.all_resolutions[lvl] in self.attn_resolutions:
+                v = attn(mods[i], v); i += 1
+            if lvl != 0:
+                t, c, p = acts[v]
+                tp = []
+                y = mods[i].forward_blocked(t, c, B, p, tape=tp)
+                out = new(y, c, p * 8)
+                tape.append(("up", mods[i], tp[0], [v], out)); i += 1
+                v = out
+        assert not hs
+        gn = mods[i]; i += 1
+        hl, c, p = acts[v]
+        prm = ops.gn_params([(hl, c)], gn.weight, gn.bias, B, p, eps=gn.eps, groups=gn.num_groups)
+        a = ops.gn_apply([(hl, c)], prm, B, p, norm=True, silu=True)
+        head = mods[i]
+        out = torch.empty((B, self.out_channels, R, R, R), dtype=torch.float32, device=x.device)
+        pwh = layers.conv3_packed(self, "head", head, self._head_cfg())
+        layers.run_conv3(pwh, a, B, R, bias=head.bias, out=out, out_mode=ops.OUT_NCDHW, rows_alloc=8)
+        ctx = dict(B=B, R=R, P=P, emb=emb, t1=t1, temb=temb, x64=x64, v0=v0, last=v, acts=acts, tape=tape, gn_prm=prm,
+                   a_final=a, foffs=foffs, ftot=ftot, fw=fw)
+        return out, ctx
+
+    def backward(self, ctx, d_eps):
+        """Accumulate d(loss)/d(parameter) into `.grad` for every trainable parameter, given d(loss)/d(eps_hat)."""
+        from . import backward as bw
+        from torch.nn import functional as F
+        mods = self.all_modules
+        B, R, P, acts, tape = ctx["B"], ctx["R"], ctx["P"], ctx["acts"], ctx["tape"]
+        dev = d_eps.device
+        grads = {}
+
+        def acc(vid, g):
+            if vid in grads:
+                grads[vid].add_(g)
+            else:
+                grads[vid] = g
+
+        # head conv + final GroupNorm/SiLU
+        d8 = torch.zeros((B, 8, R, R, R), dtype=torch.float32, device=dev)
+        d8[:, :self.out_channels] = d_eps
+        dy = ops.ncdhw_to_f32b(d8)
+        gn, head = mods[-2], mods[-1]
+        hl, c, p = acts[ctx["last"]]
+        d_a = bw.conv3_backward(self, "head", head, dy, ctx["a_final"], B, R)
+        acc(ctx["last"], bw.gn_backward([(hl, c)], d_a, ctx["gn_prm"], gn, B, p, silu=True)[0])
+        del d_a
+        d_film = torch.zeros((B, ctx["ftot"]), dtype=torch.float32, device=dev)
+        for kind, layer, sv, ins, out in reversed(tape):
+            g = grads.pop(out)
+            if kind == "res":
+                dparts, dbias0 = layer.backward_blocked(sv, g)
+                o = ctx["foffs"][id(layer)]
+                d_film[:, o:o + layer.out_ch] = dbias0
+                for vid, dp in zip(ins, dparts):
+                    acc(vid, dp)
+            else:
+                acc(ins[0], layer.backward_blocked(sv, g))
+            del g
+        # stem: h0 = conv(x) + pos_layer(coords) + mask_layer(mask) (+ biases)
+        g0 = grads.pop(ctx["v0"])
+        stem = mods[2]
+        bw.conv3_backward(self, "stem", stem, g0, ctx["x64"], B, R, need_dx=False, act_channels=64)
+        # (each conv3_backward call also adds sum(g0) to its conv's bias: all three biases get the same sum)
+        m64 = ops.ncdhw_to_s16b(self.mask.detach().expand(B, -1, -1, -1, -1).contiguous(), 64)
+        bw.conv3_backward(self, "mask_layer", self.mask_layer, g0, m64, B, R, need_dx=False, act_channels=64)
+        if self.USE_COORDS:
+            c64 = ops.ncdhw_to_s16b(self.coords.detach().expand(B, -1, -1, -1, -1).contiguous(), 64)
+            bw.conv3_backward(self, "pos_layer", self.pos_layer, g0, c64, B, R, need_dx=False, act_channels=64)
+        del g0
+        # FiLM table + timestep MLP (tiny [B,512] algebra: torch ops on the device)
+        temb, t1, emb = ctx["temb"], ctx["t1"], ctx["emb"]
+        s2 = F.silu(temb)
+        d_fw = d_film.t() @ s2
+        d_fb = d_film.sum(0)
+        for blk, o in ((m, ctx["foffs"][id(m)]) for m in mods if isinstance(m, ResnetBlockDDPM)):
+            bw._grad_of(blk.Dense_0.weight).add_(d_fw[o:o + blk.out_ch])
+            bw._grad_of(blk.Dense_0.bias).add_(d_fb[o:o + blk.out_ch])
+            bw._grad_of(blk.Conv_0.bias).add_(d_fb[o:o + blk.out_ch])
+
+        def dsilu(z):
+            sg = torch.sigmoid(z)
+            return sg * (1 + z * (1 - sg))
+
+        d_temb = (d_film @ ctx["fw"]) * dsilu(temb)
+        bw._grad_of(mods[1].weight).add_(d_temb.t() @ F.silu(t1))
+        bw._grad_of(mods[1].bias).add_(d_temb.sum(0))
+        d_t1 = (d_temb @ mods[1].weight.detach()) * dsilu(t1)
+        bw._grad_of(mods[0].weight).add_(d_t1.t() @ emb)
+        bw._grad_of(mods[0].bias).add_(d_t1.sum(0))
+        ops.bump_param_epoch()   # nothing cached depends on grads, but keep caches honest if an optimizer steps next
+
     def _stem_cfg(self):
         return ops.CFG_C3_128_K16 if self.KSIZE == 3 else ops.CFG_C5_128_K16
 
@@ -153,8 +321,9 @@ class DDPMUNet3D(layers.HipLayer):
         if not x.is_cuda:
             raise RuntimeError(f"{type(self).__name__} (meshdiffusion_amd) runs on the GPU only: no CPU fallback")
         if torch.is_grad_enabled() and self.training:
-            raise NotImplementedError("autograd/backward through the HIP U-Net is not implemented yet; "
-                                      "call under torch.no_grad() in eval mode")
+            # training: the HIP forward records a tape and the HIP backward accumulates parameter .grad; torch
+            # autograd only sees one opaque node (so `loss.backward()` of the reference's step_fn works)
+            return _UNetTrainFn.apply(x, labels, self, self._autograd_anchor())
         if self.hip_precision is not None:
             ops.set_precision(self.hip_precision)
         mods = self.all_modules
@@ -225,3 +394,22 @@ class DDPMUNet3D(layers.HipLayer):
 class DDPMRes64(DDPMUNet3D):
     """lib/diffusion/models/ddpm_res64.py: 3x3x3 stem/head, `coords` positional input."""
     KSIZE, USE_COORDS, LEVEL0_BLOCKS = 3, True, None
+
+
+class _UNetTrainFn(torch.autograd.Function):
+    """One opaque autograd node around the HIP forward/backward.  Parameter gradients are accumulated straight
+    into `.grad` by `DDPMUNet3D.backward`; the `anchor` input only makes autograd schedule this node."""
+
+    @staticmethod
+    def forward(ctx, x, labels, model, anchor):
+        with torch.no_grad():
+            out, tape_ctx = model.forward_train(x, labels)
+        ctx.model, ctx.tape_ctx = model, tape_ctx
+        return out
+
+    @staticmethod
+    def backward(ctx, d_eps):
+        with torch.no_grad():
+            ctx.model.backward(ctx.tape_ctx, d_eps.contiguous())
+        ctx.tape_ctx = None
+        return None, None, None, None

@@ -192,7 +192,7 @@ class AttnBlock(HipLayer):
     def _wv_s16(self):
         return self._cached("wv", [self.NIN_2.W], lambda: ops.pack_s16b_from_matrix(self.NIN_2.W, self.NIN_2.W.device))
 
-    def forward_blocked(self, x, B, P):
+    def forward_blocked(self, x, B, P, tape=None):
         Cc = self.channels
         dev = x.device
         gn = self.GroupNorm_0
@@ -221,7 +221,13 @@ class AttnBlock(HipLayer):
         ops.gemm_conv(cfg=cfg_o, a=vT, b=pr, out=o, batch=B, rows=Cc, rows_alloc=Cc, kdim=P, dims=(1, 1, P),
                       a_src=ops.A_S16B, a_rows=Cc, a_bstride=(P // 8) * 2 * Cc * 8, bias=self.NIN_2.b,
                       out_mode=ops.OUT_S16B)
+        if tape is not None:
+            tape.append(dict(layer=self, x=x, prm=params, hN=h, qk=qk, vT=vT, pr=pr, o=o, B=B, P=P, S=_spatial_edge(P)))
         return self.NIN_3.forward_s16(o, B, P, residual=x)
+
+    def backward_blocked(self, sv, dy):
+        from . import backward as bw
+        return bw.attn_backward(self, sv, dy)
 
     def forward(self, x):
         parts, B, P, spatial = _parts_of(x)

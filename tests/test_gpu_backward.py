@@ -96,3 +96,31 @@ def test_up_down_nin_backward(hip_lib):
         dx = bw.nin_backward(nin, _f32b(ops, dy), xs16, B, P, S)
     assert rel_l2(ops.f32b_to_ncdhw(dx, (S, S, S)).cpu(), xr.grad) < TOL
     assert rel_l2(nin.W.grad.cpu(), Wr.grad) < TOL and rel_l2(nin.b.grad.cpu(), br.grad) < TOL
+
+
+@pytest.mark.parametrize("Cc,S", [(64, 8), (64, 4)])
+def test_attn_block_backward(hip_lib, Cc, S):
+    from meshdiffusion_amd import hip_ops as ops
+    from meshdiffusion_amd.lib.diffusion.models import layers
+    from oracle import unet_oracle as uo
+    B = 8
+    blk = layers.AttnBlock(channels=Cc)
+    sd = _load(blk, 4)
+    blk = blk.cuda().train()
+    x, dy = _randn((B, Cc, S, S, S), 5), _randn((B, Cc, S, S, S), 6)
+    sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    xr = x.clone().requires_grad_(True)
+    uo.attn_block(sdr, xr).backward(dy)
+    tape = []
+    with torch.no_grad():
+        blk.forward_blocked(_f32b(ops, x), B, S ** 3, tape=tape)
+        dx = blk.backward_blocked(tape[0], _f32b(ops, dy))
+    assert rel_l2(ops.f32b_to_ncdhw(dx, (S, S, S)).cpu(), xr.grad) < TOL
+    assert rel_l2(ops.f32b_to_ncdhw(dx, (S, S, S)).cpu() - dy, xr.grad - dy) < 5e-4    # the attention branch itself
+    params = dict(blk.named_parameters())
+    for n in ["NIN_0.W", "NIN_0.b", "NIN_1.W", "NIN_2.W", "NIN_2.b", "NIN_3.W", "NIN_3.b",
+              "GroupNorm_0.weight", "GroupNorm_0.bias"]:
+        assert rel_l2(params[n].grad.cpu(), sdr[n].grad) < 5e-4, n
+    # the key bias cannot change a softmax over keys: its exact gradient is 0 and both sides hold only round-off
+    scale = float(sdr["NIN_0.b"].grad.abs().max())
+    assert float(params["NIN_1.b"].grad.abs().max()) < 1e-2 * scale + 1e-4
