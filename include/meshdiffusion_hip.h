@@ -249,8 +249,8 @@ int md_adam_ema_step(float* p, const float* g, float* m, float* v, float* ema, i
  *                     (mode 0: sum of the 8 children) and zero-stuffing (mode 1).
  */
 int64_t md_pb16_bytes(int32_t batch, int32_t C, int32_t D, int32_t H, int32_t W, int32_t guard);
-int md_to_pb16(const void* src, void* out, int32_t batch, int32_t C, int32_t D, int32_t H, int32_t W,
-               int32_t guard, int32_t mode, int32_t up, int32_t stuff, void* stream);
+int md_to_pb16(const void* src, void* out, int32_t batch, int32_t C, int32_t c_src, int32_t D, int32_t H, int32_t W,
+               int32_t guard, int32_t mode, int32_t up, int32_t stuff, void* stream);  /* channels >= c_src are zero */
 int md_wgrad_finish(const float* g, float* dw, int32_t rows, int32_t cols, int32_t cols_alloc, int32_t ntap,
                     int32_t tap0, int64_t s_row, int64_t s_k, int64_t s_tap, void* stream);
 int md_gn_bwd_stats(const float* x, const float* dy, const float* params, double* sums, int32_t batch, int32_t C,

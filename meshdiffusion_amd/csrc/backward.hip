@@ -15,8 +15,8 @@
 // mode 0: src = F32B fp32 [B][C/8][P][8] (split here); mode 1: src = S16B [B][C/8][2][P][8] (planes copied)
 // up: source grid is (D/2,H/2,W/2) and is nearest-upsampled; stuff: source grid is (D/2..) placed at odd fine
 // positions (2o+1), zeros elsewhere (dgrad/wgrad of the stride-2 Downsample conv).
-__global__ void md_to_pb16_kernel(const void* __restrict__ src, uint16_t* __restrict__ out, int B, int C, int D, int H,
-                                  int W, int guard, int mode, int up, int stuff) {
+__global__ void md_to_pb16_kernel(const void* __restrict__ src, uint16_t* __restrict__ out, int B, int C, int Cs, int D,
+                                  int H, int W, int guard, int mode, int up, int stuff) {
   const int Dp = D + 2, Hp = H + 2, Wp = W + 2;
   const int64_t Pp = (int64_t)Dp * Hp * Wp;
   const int bg_n = B / 8;
@@ -29,7 +29,7 @@ __global__ void md_to_pb16_kernel(const void* __restrict__ src, uint16_t* __rest
     const int64_t pp = i / ((int64_t)C * bg_n);
     const int px = (int)(pp % Wp) - 1, py = (int)((pp / Wp) % Hp) - 1, pz = (int)(pp / ((int64_t)Wp * Hp)) - 1;
     uint32_t hi[8] = {0, 0, 0, 0, 0, 0, 0, 0}, lo[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    bool inb = (px >= 0) & (px < W) & (py >= 0) & (py < H) & (pz >= 0) & (pz < D);
+    bool inb = (px >= 0) & (px < W) & (py >= 0) & (py < H) & (pz >= 0) & (pz < D) & (c < Cs);
     int sx = px, sy = py, sz = pz;
     if (up) { sx >>= 1; sy >>= 1; sz >>= 1; }
     if (stuff) { inb = inb & (px & 1) & (py & 1) & (pz & 1); sx >>= 1; sy >>= 1; sz >>= 1; }
@@ -39,11 +39,11 @@ __global__ void md_to_pb16_kernel(const void* __restrict__ src, uint16_t* __rest
       for (int k = 0; k < 8; ++k) {
         const int b = bg * 8 + k;
         if (mode == 0) {
-          const float v = ((const float*)src)[(((int64_t)b * (C / 8) + (c >> 3)) * Ps + sp) * 8 + (c & 7)];
+          const float v = ((const float*)src)[(((int64_t)b * (Cs / 8) + (c >> 3)) * Ps + sp) * 8 + (c & 7)];
           md_split(v, hi[k], lo[k]);
         } else {
           const uint16_t* s = (const uint16_t*)src;
-          const int64_t o = ((((int64_t)b * (C / 8) + (c >> 3)) * 2) * Ps + sp) * 8 + (c & 7);
+          const int64_t o = ((((int64_t)b * (Cs / 8) + (c >> 3)) * 2) * Ps + sp) * 8 + (c & 7);
           hi[k] = s[o]; lo[k] = s[o + Ps * 8];
         }
       }
@@ -59,9 +59,11 @@ extern "C" int64_t md_pb16_bytes(int32_t batch, int32_t C, int32_t D, int32_t H,
   return ((int64_t)(D + 2) * (H + 2) * (W + 2) + 2 * (int64_t)guard) * (batch / 8) * 2 * C * 8 * 2;
 }
 
-extern "C" int md_to_pb16(const void* src, void* out, int32_t batch, int32_t C, int32_t D, int32_t H, int32_t W,
-                          int32_t guard, int32_t mode, int32_t up, int32_t stuff, void* stream) {
-  if (!src || !out || md_pb16_bytes(batch, C, D, H, W, guard) < 0 || (C % 8) || mode < 0 || mode > 1) return MD_ERR_BAD_ARG;
+extern "C" int md_to_pb16(const void* src, void* out, int32_t batch, int32_t C, int32_t c_src, int32_t D, int32_t H,
+                          int32_t W, int32_t guard, int32_t mode, int32_t up, int32_t stuff, void* stream) {
+  if (!src || !out || md_pb16_bytes(batch, C, D, H, W, guard) < 0 || (C % 8) || (c_src % 8) || c_src <= 0 || c_src > C ||
+      mode < 0 || mode > 1)
+    return MD_ERR_BAD_ARG;
   if ((up || stuff) && ((D | H | W) & 1)) return MD_ERR_BAD_ARG;
   hipError_t e = hipMemsetAsync(out, 0, (size_t)md_pb16_bytes(batch, C, D, H, W, guard), (hipStream_t)stream);
   if (e != hipSuccess) return (int)e;
@@ -70,7 +72,7 @@ extern "C" int md_to_pb16(const void* src, void* out, int32_t batch, int32_t C, 
   if (blocks > 8192) blocks = 8192;
   MD_HIP_CLEAR_ERROR();
   hipLaunchKernelGGL(md_to_pb16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, (uint16_t*)out,
-                     batch, C, D, H, W, guard, mode, up, stuff);
+                     batch, C, c_src, D, H, W, guard, mode, up, stuff);
   MD_HIP_CHECK_LAUNCH();
   return MD_OK;
 }

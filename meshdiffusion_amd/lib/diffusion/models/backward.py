@@ -39,8 +39,9 @@ def _guard(S):
     return ((g + 3) // 4) * 4
 
 
-def to_pb16(src, B, C, S, mode, up=0, stuff=0):
-    """src: F32B (mode 0) or S16B (mode 1) on an S^3 grid (or (S/2)^3 when up/stuff) -> PB16 on the padded S^3 grid."""
+def to_pb16(src, B, C, S, mode, up=0, stuff=0, c_src=None):
+    """src: F32B (mode 0) or S16B (mode 1) on an S^3 grid (or (S/2)^3 when up/stuff) -> PB16 on the padded S^3 grid.
+    c_src: channels actually present in `src` (the PB16 tensor is zero for channels c_src..C-1)."""
     lib = _lib.load()
     g = _guard(S)
     nbytes = lib.md_pb16_bytes(B, C, S, S, S, g)
@@ -48,7 +49,8 @@ def to_pb16(src, B, C, S, mode, up=0, stuff=0):
         raise _lib.MeshDiffusionHipError("md_pb16_bytes failed (batch must be a multiple of 8)")
     out = torch.empty(nbytes // 2 + 4 * 2 * C * 8 * (B // 8), dtype=torch.bfloat16, device=src.device)
     out[nbytes // 2:].zero_()      # tail so that K rounded up to 4 positions stays in bounds
-    check(lib.md_to_pb16(_ptr(src), _ptr(out), B, C, S, S, S, g, mode, up, stuff, _stream()), "md_to_pb16")
+    check(lib.md_to_pb16(_ptr(src), _ptr(out), B, C, C if c_src is None else c_src, S, S, S, g, mode, up, stuff,
+                         _stream()), "md_to_pb16")
     return out
 
 
@@ -172,10 +174,11 @@ def conv3_backward(layer, name, conv, dy, act_s16, B, S_out, ups=0, stride=1, ne
         dy_pb = to_pb16(dy, B, co_t, S_fine, 0, stuff=1)
     else:
         dy_pb = to_pb16(dy, B, co_t, S_out, 0)
-    ci_pad = act_channels if act_channels is not None else ci
-    act_pb = to_pb16(act_s16, B, ci_pad, S_fine, 1, up=ups)
+    c_src = act_channels if act_channels is not None else ci      # channels of the S16B operand tensor
+    ci_pad = ((c_src + 63) // 64) * 64
+    act_pb = to_pb16(act_s16, B, ci_pad, S_fine, 1, up=ups, c_src=c_src)
     dw = _grad_of(conv.weight)
-    if ci_pad != ci:      # stem: the operand was zero padded to 64 channels; accumulate into a padded scratch
+    if ci_pad != ci:      # operand zero padded to a multiple of 64 channels: accumulate into a padded scratch
         scratch = torch.zeros((co, ci_pad, 27), dtype=torch.float32, device=dev)
         wgrad(dy_pb, act_pb, B, co, ci_pad, S_fine, 27, scratch, ci_pad * 27, 27, 1, a_ch=co_t)
         dw.add_(scratch[:, :ci].reshape(dw.shape))
@@ -232,6 +235,18 @@ def softmax_keys_bwd(p_s16, dp, B, nk, nq, alpha):
     return ds
 
 
+def wgrad_nin(dy_pb, xs_s16, B, co, ci, S, dw):
+    """dw[ci][co] += sum x[ci] dy[co] with the activation channels padded to a multiple of 64 when needed."""
+    ci_pad = ((ci + 63) // 64) * 64
+    x_pb = to_pb16(xs_s16, B, ci_pad, S, 1, c_src=ci)
+    if ci_pad == ci:
+        wgrad(dy_pb, x_pb, B, co, ci, S, 1, dw, 1, co, 0)
+    else:
+        scratch = torch.zeros((ci_pad, co), dtype=torch.float32, device=dw.device)
+        wgrad(dy_pb, x_pb, B, co, ci_pad, S, 1, scratch, 1, co, 0)
+        dw.add_(scratch[:ci])
+
+
 def nin_backward(nin, dy, xs_s16, B, P, S, need_dx=True, with_bias=True):
     """Backward of y[co] = sum_ci x[ci] W[ci][co] + b.  xs_s16: S16B of the forward input."""
     from . import layers
@@ -239,9 +254,8 @@ def nin_backward(nin, dy, xs_s16, B, P, S, need_dx=True, with_bias=True):
     if with_bias:
         _grad_of(nin.b).add_(channel_sums(dy, B, co, P).sum(0))
     dy_pb = to_pb16(dy, B, co, S, 0)
-    x_pb = to_pb16(xs_s16, B, ci, S, 1)
-    wgrad(dy_pb, x_pb, B, co, ci, S, 1, _grad_of(nin.W), 1, co, 0)
-    del dy_pb, x_pb
+    wgrad_nin(dy_pb, xs_s16, B, co, ci, S, _grad_of(nin.W))
+    del dy_pb
     if not need_dx:
         return None
     cfg = ops.gemm_cfg_for(P, ci)
@@ -282,8 +296,7 @@ def attn_backward(blk, sv, dy):
     _grad_of(blk.NIN_0.b).add_(bsum[:Cc]); _grad_of(blk.NIN_1.b).add_(bsum[Cc:])
     dw = torch.zeros_like(wqk)
     dqk_pb = to_pb16(dqk, B, 2 * Cc, S, 0)
-    h_pb = to_pb16(hN, B, Cc, S, 1)
-    wgrad(dqk_pb, h_pb, B, 2 * Cc, Cc, S, 1, dw, 1, 2 * Cc, 0)
+    wgrad_nin(dqk_pb, hN, B, 2 * Cc, Cc, S, dw)
     _grad_of(blk.NIN_0.W).add_(dw[:, :Cc]); _grad_of(blk.NIN_1.W).add_(dw[:, Cc:])
     del dqk_pb
     cfg = ops.gemm_cfg_for(P, Cc)
@@ -291,8 +304,8 @@ def attn_backward(blk, sv, dy):
     d_h = layers.run_gemm(pw, split_f32b(dqk, B, 2 * Cc, P), B, P)
     # v = NIN_2(h) (bias handled above)
     dv_pb = to_pb16(dV, B, Cc, S, 0)
-    wgrad(dv_pb, h_pb, B, Cc, Cc, S, 1, _grad_of(blk.NIN_2.W), 1, Cc, 0)
-    del dv_pb, h_pb
+    wgrad_nin(dv_pb, hN, B, Cc, Cc, S, _grad_of(blk.NIN_2.W))
+    del dv_pb
     pw2 = blk.NIN_2._cached(f"dgrad{cfg}", [blk.NIN_2.W], lambda: ops.PackedWeight(blk.NIN_2.W, "rows", cfg, blk.NIN_2.W.device))
     d_h.add_(layers.run_gemm(pw2, split_f32b(dV, B, Cc, P), B, P))
     dx = dy.clone()

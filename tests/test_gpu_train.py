@@ -99,6 +99,7 @@ def test_whole_unet_backward_and_train_step_vs_oracle_autograd(hip_lib):
     from oracle import unet_oracle as uo
     cfg = synth.small_config(); cfg.device = torch.device("cuda")
     cfg.optim.warmup = 2
+    cfg.optim.grad_clip = -1.0        # keep p.grad unscaled so it can be compared with autograd's gradient
     model = mutils.create_model(cfg)
     R, B = cfg.data.image_size, 8
     sd = synth.sensitised_state_dict(model.module.state_dict(), seed=1234, grid_mask=synth.synthetic_grid_mask(R))
@@ -112,7 +113,8 @@ def test_whole_unet_backward_and_train_step_vs_oracle_autograd(hip_lib):
     batch = (synth.synthetic_inputs(B, 4, R, seed=8) * mask.cpu()).cuda()
     state = dict(model=model, ema=ema, optimizer=opt, step=1)
     torch.manual_seed(321)
-    loss = float(step_fn(state, batch)["loss"])
+    w_before = {n: p.detach().cpu().clone() for n, p in model.module.named_parameters()}
+    loss = float(step_fn(state, batch)["loss"].detach())
     grads = {n: p.grad.detach().cpu().clone() for n, p in model.module.named_parameters() if p.grad is not None}
     # ---- reference: autograd through the oracle, same labels/noise stream ----
     torch.manual_seed(321)
@@ -139,3 +141,6 @@ def test_whole_unet_backward_and_train_step_vs_oracle_autograd(hip_lib):
     print("worst per-tensor error relative to the global grad norm:", worst)
     assert worst[1] < 5e-4
     assert set(grads) == {n for n, v in sdr.items() if v.grad is not None}
+    # the optimizer really stepped (reference optimize_fn: warm-up lr 2e-5 * 1/2, Adam) and the EMA moved
+    moved = [n for n, p in model.module.named_parameters() if p.requires_grad and not torch.equal(p.detach().cpu(), w_before[n])]
+    assert len(moved) == len(grads) and state["step"] == 2 and ema.num_updates == 1
