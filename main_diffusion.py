@@ -4,7 +4,7 @@
         --config.eval.eval_dir=out --config.eval.ckpt_path=ckpt.pth [--config.eval.batch_size=8]
 
 `--config` may be a reference-style python config file (get_config()) or one of the built-in
-names `res64` / `res128`.  `--mode=train` is a later SURVEY 8(a) row.
+names `res64` / `res128`.  `--mode=train` runs one rank per GPU under torchrun.
 """
 import sys
 
@@ -50,7 +50,8 @@ def main(argv=None):
     elif mode == "cond_gen":
         evaler.cond_gen(config)
     else:
-        raise SystemExit("--mode=train: the HIP backward/optimizer path is not built yet (DESIGN.md scope)")
+        from meshdiffusion_amd.lib.diffusion import trainer
+        trainer.train(config)
 
 
 if __name__ == "__main__":

@@ -14,6 +14,7 @@ import numpy as np
 import torch
 import torch.optim as optim
 
+from . import parallel
 from .models import utils as mutils
 from .sde_lib import VPSDE
 from ... import _lib
@@ -117,6 +118,8 @@ def get_step_fn(sde, train, optimize_fn=None, mask=None, loss_type="l2"):
             loss = loss_fn(model, batch)
             loss.backward()
             if update_param:
+                # one process per GPU: the replicas' gradients meet here (no-op for a single process)
+                parallel.allreduce_param_grads_(model.parameters())
                 optimize_fn(optimizer, model.parameters(), step=state["step"])
             state["step"] += 1
             state["ema"].update(model.parameters())

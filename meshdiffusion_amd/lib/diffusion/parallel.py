@@ -77,3 +77,48 @@ def allreduce_grads_(flat_grad):
     dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
     flat_grad.div_(dist.get_world_size())
     return flat_grad
+
+
+def broadcast_params_(params, src=0, cap_bytes=256 << 20):
+    """Start-up only: copy rank `src`'s parameters to every replica (bucketed, <= 256 MB per broadcast)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return
+    for bucket in _buckets([p.data for p in params], cap_bytes):
+        flat = torch._utils._flatten_dense_tensors(bucket)
+        dist.broadcast(flat, src=src)
+        for t, f in zip(bucket, torch._utils._unflatten_dense_tensors(flat, bucket)):
+            t.copy_(f)
+
+
+def _buckets(tensors, cap_bytes=256 << 20):
+    out, cur, size = [], [], 0
+    for t in tensors:
+        n = t.numel() * t.element_size()
+        if cur and size + n > cap_bytes:
+            out.append(cur)
+            cur, size = [], 0
+        cur.append(t)
+        size += n
+    if cur:
+        out.append(cur)
+    return out
+
+
+def allreduce_param_grads_(params, cap_bytes=256 << 20):
+    """Mean of `p.grad` over ranks for separately allocated gradients (the reference-format optimizer path):
+    a few large flattened buckets (<= 256 MB: xGMI rings are per-link bound, so few big messages), launched
+    asynchronously back to back and unpacked once all are in flight.  If the gradients are already views of
+    one flat buffer use `allreduce_grads_` on it instead.  No-op for world size 1."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return
+    world = dist.get_world_size()
+    grads = [p.grad for p in params if p.requires_grad and p.grad is not None]
+    pending = []
+    for bucket in _buckets(grads, cap_bytes):
+        flat = torch._utils._flatten_dense_tensors(bucket)
+        pending.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True), flat, bucket))
+    for work, flat, bucket in pending:
+        work.wait()
+        flat.div_(world)
+        for g, f in zip(bucket, torch._utils._unflatten_dense_tensors(flat, bucket)):
+            g.copy_(f)

@@ -10,6 +10,7 @@ outputs are stored):
   unet_res64.npz     reference DDPMRes64 (res64, B=1) eps_hat: ::4 subsample + statistics
   sampler_small.npz  unmodified reference pc_sampler, first K iterations, uncond + inpainting
   sampler_res64.npz  BASELINE config #1: res64, B=1, first 10 of 1000 ancestral steps
+  dataset.npz        reference ShapeNetDMTetDataset items (augmentation on/off) for seeded on-disk grids
   dmtet.npz          reference DMTet.__call__ on the shipped 64-grid: counts, hashes, samples
   64_tets_cropped.npz  the tet-grid DATA asset (vertices/indices), copied verbatim
 Every reference result is also compared with the oracle restatement (assert), which is the pin
@@ -287,15 +288,55 @@ def gen_dmtet():
     np.savez_compressed(os.path.join(GOLD, "dmtet.npz"), **out)
 
 
+def dataset_inputs(tmp, R=8):
+    """Three seeded grids on disk (two at r=R, one smaller than the model grid), a path list and an id
+    filter, in the reference's on-disk format (data/tets_to_3dgrid.py:49).  Shared with the CPU test."""
+    import json
+    g = torch.Generator().manual_seed(99)
+    paths = []
+    for i, r in enumerate((R, R // 2, R, R)):
+        grid = torch.randn((4, r, r, r), generator=g)
+        grid[0, :, 1::2] = 0.0                      # exact zeros exercise the sign(0) -> +1 rule
+        grid[1:, :, :, ::3] = 0.0                   # empty cells exercise the non-empty test of the augmentation
+        path = os.path.join(tmp, f"grid_{i:05d}.pt")
+        torch.save(grid, path)
+        paths.append(path)
+    meta, keep = os.path.join(tmp, "meta.json"), os.path.join(tmp, "keep.json")
+    json.dump(paths, open(meta, "w"))
+    json.dump([0, 1, 3], open(keep, "w"))
+    mask = (torch.rand((1, 1, R, R, R), generator=g) < 0.6).float()
+    return meta, keep, mask
+
+
+def gen_dataset():
+    """Reference ShapeNetDMTetDataset items (lib/dataset/shapenet_dmtet_dataset.py) under a fixed global seed."""
+    import tempfile
+    sys.path.insert(0, REF)
+    from lib.dataset.shapenet_dmtet_dataset import ShapeNetDMTetDataset as RefDS
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        meta, keep, mask = dataset_inputs(tmp)
+        for tag, kw in (("aug_norm", dict(aug=True, normalize_sdf=True, filter_meta_path=keep)),
+                        ("plain", dict(aug=False, normalize_sdf=False, filter_meta_path=None))):
+            ds = RefDS(meta, grid_mask=mask, extension="pt", **kw)
+            out[f"{tag}_len"] = np.int64(len(ds))
+            torch.manual_seed(4321)
+            for i in range(len(ds)):
+                out[f"{tag}_{i}"] = ds[i].numpy()
+    np.savez_compressed(os.path.join(GOLD, "dataset.npz"), **out)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-res64", action="store_true")
-    ap.add_argument("--only", choices=["unet", "dmtet"], default=None)
+    ap.add_argument("--only", choices=["unet", "dmtet", "dataset"], default=None)
     a = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(os.cpu_count())
     if a.only in (None, "dmtet"):
         gen_dmtet()
+    if a.only in (None, "dataset"):
+        gen_dataset()
     if a.only in (None, "unet"):
         gen_unet_and_sampler(a.skip_res64)
     print("golden fixtures written to", GOLD)

@@ -94,6 +94,52 @@ def test_grad_allreduce_equals_large_batch_gradient_gloo():
     assert torch.allclose(res[0], full, atol=1e-6) and torch.equal(res[0], res[1])
 
 
+def _replica_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from meshdiffusion_amd.lib.diffusion import parallel
+    parallel.init_distributed(backend="gloo")
+    torch.manual_seed(10 + rank)                                   # replicas start DIFFERENT on purpose
+    net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 3))
+    parallel.broadcast_params_(net.parameters(), cap_bytes=64)     # tiny cap: several buckets
+    start = [p.detach().clone() for p in net.parameters()]
+    g = torch.Generator().manual_seed(3)
+    x, y = torch.randn((8, 6), generator=g), torch.randn((8, 3), generator=g)
+    sl = slice(rank * 4, rank * 4 + 4)
+    ((net(x[sl]) - y[sl]) ** 2).mean().backward()
+    parallel.allreduce_param_grads_(net.parameters(), cap_bytes=64)
+    q.put((rank, start, [p.grad.clone() for p in net.parameters()]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_replica_broadcast_and_bucketed_grad_allreduce_gloo():
+    """trainer.py's exchange: start-up broadcast makes the replicas identical; the bucketed mean of per-rank
+    gradients equals the gradient of the global batch (training.batch_size = sum of the shards)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_replica_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(2):
+        rank, start, grads = q.get(timeout=120)
+        res[rank] = (start, grads)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    torch.manual_seed(10)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 3))
+    g = torch.Generator().manual_seed(3)
+    x, y = torch.randn((8, 6), generator=g), torch.randn((8, 3), generator=g)
+    ((net(x) - y) ** 2).mean().backward()
+    for k, p in enumerate(net.parameters()):
+        assert torch.equal(res[0][0][k], p.detach()) and torch.equal(res[1][0][k], p.detach())
+        assert torch.allclose(res[0][1][k], p.grad, atol=1e-6) and torch.equal(res[0][1][k], res[1][1][k])
+
+
 def test_bench_multi_process_control_flow_dry_run():
     """bench.py under torch.distributed.run with 2 ranks: rendezvous on 127.0.0.1, barrier, MAX over ranks,
     exactly one JSON line from rank 0 (the GPU work itself is covered by the -m gpu suite and `bench.py`)."""
