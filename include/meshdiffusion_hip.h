@@ -38,7 +38,7 @@ extern "C" {
 #define MD_ERR_UNSUPPORTED (-2)
 #define MD_ERR_NO_DEVICE (-3)
 
-#define MD_ABI_VERSION 1
+#define MD_ABI_VERSION 2
 
 /* ---- tile configurations of md_gemm_conv (compile-time instantiations) ---- */
 enum {
@@ -151,6 +151,10 @@ int64_t md_packed_weight_bytes(int32_t rows, int32_t kdim, int32_t taps, int32_t
  *               the raw x from the same read (ResnetBlock: GN path and NIN shortcut share one pass).
  *               `silu` is a bit field: 1 = apply SiLU, 4 = MD_PREC_FP16X2 output (plane 0 = fp16(y),
  *               plane 1 not written), 2 = debug: round y to fp16 before the bf16 split.
+ *               drop_p > 0 (training, nn.Dropout of ResnetBlockDDPM, layers.py:682): after SiLU, y is zeroed with
+ *               probability drop_p and scaled by 1/(1-drop_p) otherwise.  The mask is a counter-based hash of
+ *               (drop_seed, b, channel quad, position) -- md_gn_bwd_stats/apply regenerate it from the same
+ *               (drop_p, drop_seed); md_dropout_scale writes it out as an F32B tensor of {0, 1/(1-p)} (tests).
  */
 int md_gn_stats(const float* x, double* sums, int32_t batch, int32_t C, int64_t P,
                 int32_t c_total, int32_t c_off, void* stream);
@@ -159,7 +163,9 @@ int md_gn_finalize(const double* sums, const float* gamma, const float* beta,
                    int64_t P, float eps, void* stream);
 int md_gn_apply(const float* x, const float* params, void* out, void* out_raw, int32_t batch,
                 int32_t C, int64_t P, int32_t c_total, int32_t c_off, int32_t norm,
-                int32_t silu, void* stream);
+                int32_t silu, float drop_p, uint64_t drop_seed, void* stream);
+int md_dropout_scale(float* out, int32_t batch, int32_t C, int64_t P, int32_t c_total, int32_t c_off,
+                     float drop_p, uint64_t drop_seed, void* stream);
 int md_zero(void* p, int64_t bytes, void* stream);
 
 /*
@@ -243,8 +249,8 @@ int md_adam_ema_step(float* p, const float* g, float* m, float* v, float* ema, i
  *   md_to_pb16      : F32B (mode 0) / S16B (mode 1) -> PB16; up=1 nearest-upsamples a (D/2)^3 source, stuff=1
  *                     places it at odd fine positions (stride-2 conv backward).  Zero-fills `out` first.
  *   md_wgrad_finish : GEMM result [ntap][rows/8][cols_alloc][8] -> dw[row*s_row + col*s_k + (tap0+t)*s_tap] += .
- *   md_gn_bwd_*     : GroupNorm(+SiLU) backward in three streaming passes (see backward.hip); `sums` zeroed by
- *                     the caller; dgamma/dbeta accumulate.
+ *   md_gn_bwd_*     : GroupNorm(+SiLU)(+dropout) backward in three streaming passes (see backward.hip); `sums`
+ *                     zeroed by the caller; dgamma/dbeta accumulate; (drop_p, drop_seed) as given to md_gn_apply.
  *   md_channel_sums : out[b][c] += sum_p x (bias / FiLM gradients); md_grad_resample: Upsample backward
  *                     (mode 0: sum of the 8 children) and zero-stuffing (mode 1).
  */
@@ -254,12 +260,13 @@ int md_to_pb16(const void* src, void* out, int32_t batch, int32_t C, int32_t c_s
 int md_wgrad_finish(const float* g, float* dw, int32_t rows, int32_t cols, int32_t cols_alloc, int32_t ntap,
                     int32_t tap0, int64_t s_row, int64_t s_k, int64_t s_tap, void* stream);
 int md_gn_bwd_stats(const float* x, const float* dy, const float* params, double* sums, int32_t batch, int32_t C,
-                    int64_t P, int32_t c_total, int32_t c_off, int32_t dy_ctotal, int32_t silu, void* stream);
+                    int64_t P, int32_t c_total, int32_t c_off, int32_t dy_ctotal, int32_t silu, float drop_p,
+                    uint64_t drop_seed, void* stream);
 int md_gn_bwd_finalize(const double* sums, const float* params, const float* gamma, float* coef, float* dgamma,
                        float* dbeta, int32_t batch, int32_t c_total, int32_t groups, int64_t P, void* stream);
 int md_gn_bwd_apply(const float* x, const float* dy, const float* params, const float* coef, float* dx, int32_t batch,
                     int32_t C, int64_t P, int32_t c_total, int32_t c_off, int32_t dy_ctotal, int32_t silu,
-                    int32_t accumulate, void* stream);
+                    int32_t accumulate, float drop_p, uint64_t drop_seed, void* stream);
 int md_channel_sums(const float* x, float* out, int32_t batch, int32_t C, int64_t P, void* stream);
 /* S16B blocked transpose: in [B][R/8][2][Cn][8] -> out [B][Cn/8][2][R][8] (attention backward operands). */
 int md_s16b_transpose(const void* in, void* out, int32_t batch, int32_t R, int32_t Cn, void* stream);

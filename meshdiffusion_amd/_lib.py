@@ -38,7 +38,7 @@ class MdGemmConvArgs(C.Structure):
     ]
 
 
-_P, _I32, _I64, _F = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+_P, _I32, _I64, _F, _U64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint64
 
 # name -> (restype, argtypes); exactly the entry points of include/meshdiffusion_hip.h
 SIGNATURES = {
@@ -51,7 +51,8 @@ SIGNATURES = {
     "md_packed_weight_bytes": (_I64, [_I32, _I32, _I32, _I32, _I32]),
     "md_gn_stats": (C.c_int, [_P, _P, _I32, _I32, _I64, _I32, _I32, _P]),
     "md_gn_finalize": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _I64, _F, _P]),
-    "md_gn_apply": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I64, _I32, _I32, _I32, _I32, _P]),
+    "md_gn_apply": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I64, _I32, _I32, _I32, _I32, _F, _U64, _P]),
+    "md_dropout_scale": (C.c_int, [_P, _I32, _I32, _I64, _I32, _I32, _F, _U64, _P]),
     "md_zero": (C.c_int, [_P, _I64, _P]),
     "md_timestep_embedding": (C.c_int, [_P, _P, _I32, _I32, _P]),
     "md_linear": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _P]),
@@ -70,9 +71,9 @@ SIGNATURES = {
     "md_pb16_bytes": (_I64, [_I32, _I32, _I32, _I32, _I32, _I32]),
     "md_to_pb16": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P]),
     "md_wgrad_finish": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _I32, _I64, _I64, _I64, _P]),
-    "md_gn_bwd_stats": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I64, _I32, _I32, _I32, _I32, _P]),
+    "md_gn_bwd_stats": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I64, _I32, _I32, _I32, _I32, _F, _U64, _P]),
     "md_gn_bwd_finalize": (C.c_int, [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I64, _P]),
-    "md_gn_bwd_apply": (C.c_int, [_P, _P, _P, _P, _P, _I32, _I32, _I64, _I32, _I32, _I32, _I32, _I32, _P]),
+    "md_gn_bwd_apply": (C.c_int, [_P, _P, _P, _P, _P, _I32, _I32, _I64, _I32, _I32, _I32, _I32, _I32, _F, _U64, _P]),
     "md_channel_sums": (C.c_int, [_P, _P, _I32, _I32, _I64, _P]),
     "md_s16b_transpose": (C.c_int, [_P, _P, _I32, _I32, _I32, _P]),
     "md_softmax_keys_bwd": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _F, _P]),
@@ -108,7 +109,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.md_abi_version() != 1:
+    if lib.md_abi_version() != 2:
         raise MeshDiffusionHipError("ABI version mismatch")
     for cfg, (nt, kc) in CFG_NT_KC.items():
         v = [C.c_int32() for _ in range(6)]

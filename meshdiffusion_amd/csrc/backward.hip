@@ -121,7 +121,7 @@ __device__ __forceinline__ float md_silu_grad(float z) {
 __global__ __launch_bounds__(GB_BLOCK) void md_gn_bwd_stats_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                                    const float* __restrict__ params, double* __restrict__ sums,
                                                                    int C, int64_t P, int c_total, int c_off, int dy_ctotal,
-                                                                   int silu) {
+                                                                   int silu, uint32_t thr16, float drop_scale, uint64_t seed) {
   const int cg = blockIdx.y, b = blockIdx.z;
   const int tid = threadIdx.x, half = tid & 1;
   const int64_t p0 = (int64_t)blockIdx.x * GB_CHUNK;
@@ -138,7 +138,13 @@ __global__ __launch_bounds__(GB_BLOCK) void md_gn_bwd_stats_kernel(const float* 
   for (int i = 0; i < GB_ITEMS; ++i) {
     const int64_t pos = p0 + ((tid + i * GB_BLOCK) >> 1);
     if (pos < P) {
-      const f32x4 xv = xp[pos * 2 + half], dv = dp[pos * 2 + half];
+      const f32x4 xv = xp[pos * 2 + half];
+      f32x4 dv = dp[pos * 2 + half];
+      if (thr16) {  // the forward dropped / rescaled y after SiLU: the same mask gates dy
+        const uint64_t bits = md_drop_bits(seed, (uint64_t)(((int64_t)b * c_total + c_off + cg * 8 + half * 4) >> 2) * (uint64_t)P + (uint64_t)pos);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dv[e] = md_drop_keep(bits, e, thr16) ? dv[e] * drop_scale : 0.f;
+      }
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const float xc = xv[e] - mu[e];
@@ -199,7 +205,8 @@ __global__ void md_gn_bwd_finalize_kernel(const double* __restrict__ sums, const
 __global__ __launch_bounds__(GB_BLOCK) void md_gn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                                    const float* __restrict__ params, const float* __restrict__ coef,
                                                                    float* __restrict__ dx, int C, int64_t P, int c_total,
-                                                                   int c_off, int dy_ctotal, int silu, int accumulate) {
+                                                                   int c_off, int dy_ctotal, int silu, int accumulate,
+                                                                   uint32_t thr16, float drop_scale, uint64_t seed) {
   const int cg = blockIdx.y, b = blockIdx.z;
   const int tid = threadIdx.x, half = tid & 1;
   const int64_t p0 = (int64_t)blockIdx.x * GB_CHUNK;
@@ -218,7 +225,13 @@ __global__ __launch_bounds__(GB_BLOCK) void md_gn_bwd_apply_kernel(const float* 
   for (int i = 0; i < GB_ITEMS; ++i) {
     const int64_t pos = p0 + ((tid + i * GB_BLOCK) >> 1);
     if (pos < P) {
-      const f32x4 xv = xp[pos * 2 + half], dv = dp[pos * 2 + half];
+      const f32x4 xv = xp[pos * 2 + half];
+      f32x4 dv = dp[pos * 2 + half];
+      if (thr16) {
+        const uint64_t bits = md_drop_bits(seed, (uint64_t)(((int64_t)b * c_total + c_off + cg * 8 + half * 4) >> 2) * (uint64_t)P + (uint64_t)pos);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dv[e] = md_drop_keep(bits, e, thr16) ? dv[e] * drop_scale : 0.f;
+      }
       f32x4 o = {0.f, 0.f, 0.f, 0.f};
       if (accumulate) o = op[pos * 2 + half];
 #pragma unroll
@@ -234,12 +247,14 @@ __global__ __launch_bounds__(GB_BLOCK) void md_gn_bwd_apply_kernel(const float* 
 }
 
 extern "C" int md_gn_bwd_stats(const float* x, const float* dy, const float* params, double* sums, int32_t batch, int32_t C,
-                               int64_t P, int32_t c_total, int32_t c_off, int32_t dy_ctotal, int32_t silu, void* stream) {
+                               int64_t P, int32_t c_total, int32_t c_off, int32_t dy_ctotal, int32_t silu, float drop_p,
+                               uint64_t drop_seed, void* stream) {
+  if (!(drop_p >= 0.f && drop_p < 1.f)) return MD_ERR_BAD_ARG;
   if (!x || !dy || !params || !sums || batch <= 0 || C <= 0 || (C % 8) || (c_off % 8) || c_off + C > c_total) return MD_ERR_BAD_ARG;
   dim3 grid((unsigned)((P + GB_CHUNK - 1) / GB_CHUNK), (unsigned)(C / 8), (unsigned)batch);
   MD_HIP_CLEAR_ERROR();
   hipLaunchKernelGGL(md_gn_bwd_stats_kernel, grid, dim3(GB_BLOCK), 0, (hipStream_t)stream, x, dy, params, sums, C, P, c_total,
-                     c_off, dy_ctotal, silu);
+                     c_off, dy_ctotal, silu, md_drop_thr16(drop_p), 1.0f / (1.0f - drop_p), (uint64_t)drop_seed);
   MD_HIP_CHECK_LAUNCH();
   return MD_OK;
 }
@@ -256,12 +271,13 @@ extern "C" int md_gn_bwd_finalize(const double* sums, const float* params, const
 
 extern "C" int md_gn_bwd_apply(const float* x, const float* dy, const float* params, const float* coef, float* dx, int32_t batch,
                                int32_t C, int64_t P, int32_t c_total, int32_t c_off, int32_t dy_ctotal, int32_t silu,
-                               int32_t accumulate, void* stream) {
+                               int32_t accumulate, float drop_p, uint64_t drop_seed, void* stream) {
+  if (!(drop_p >= 0.f && drop_p < 1.f)) return MD_ERR_BAD_ARG;
   if (!x || !dy || !params || !coef || !dx || batch <= 0 || C <= 0 || (C % 8) || (c_off % 8) || c_off + C > c_total) return MD_ERR_BAD_ARG;
   dim3 grid((unsigned)((P + GB_CHUNK - 1) / GB_CHUNK), (unsigned)(C / 8), (unsigned)batch);
   MD_HIP_CLEAR_ERROR();
   hipLaunchKernelGGL(md_gn_bwd_apply_kernel, grid, dim3(GB_BLOCK), 0, (hipStream_t)stream, x, dy, params, coef, dx, C, P, c_total,
-                     c_off, dy_ctotal, silu, accumulate);
+                     c_off, dy_ctotal, silu, accumulate, md_drop_thr16(drop_p), 1.0f / (1.0f - drop_p), (uint64_t)drop_seed);
   MD_HIP_CHECK_LAUNCH();
   return MD_OK;
 }

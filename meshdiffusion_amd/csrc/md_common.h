@@ -45,6 +45,24 @@ __device__ __forceinline__ void md_split_f16(float x, uint32_t& hi, uint32_t& lo
   lo = md_f2h(x - md_h2f(hi));
 }
 
+// Counter-based dropout mask (training).  One 64-bit hash per 4 consecutive channels of one position gives four
+// 16-bit uniforms; element e is kept when its field >= thr16 = round(p * 65536).  `q` = ((b * c_total + first channel
+// of the quad) / 4) * P + pos identifies the quad, so the forward, the backward and md_dropout_scale regenerate the
+// same mask from (seed, p) alone -- no mask tensor is stored.
+__device__ __forceinline__ uint64_t md_drop_bits(uint64_t seed, uint64_t q) {
+  uint64_t z = seed + (q + 1) * 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+__device__ __forceinline__ bool md_drop_keep(uint64_t bits, int e, uint32_t thr16) {
+  return (uint32_t)((bits >> (16 * e)) & 0xFFFFu) >= thr16;
+}
+static inline uint32_t md_drop_thr16(float p) {
+  const float t = p * 65536.0f + 0.5f;
+  return t <= 0.f ? 0u : (t >= 65535.f ? 65535u : (uint32_t)t);
+}
+
 __device__ __forceinline__ float md_silu(float x) { return x / (1.0f + expf(-x)); }
 
 __device__ __forceinline__ float md_wave_sum(float v) {

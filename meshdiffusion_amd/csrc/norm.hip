@@ -82,7 +82,8 @@ __global__ __launch_bounds__(GN_BLOCK) void md_gn_apply_kernel(const float* __re
                                                                uint16_t* __restrict__ out,
                                                                uint16_t* __restrict__ out_raw, int C,
                                                                int64_t P, int c_total, int c_off,
-                                                               int norm, int silu) {
+                                                               int norm, int silu, uint32_t thr16,
+                                                               float drop_scale, uint64_t seed) {
   const int cg = blockIdx.y, b = blockIdx.z;
   const int tid = threadIdx.x, half = tid & 1;
   const int64_t p0 = (int64_t)blockIdx.x * GN_CHUNK;
@@ -106,6 +107,8 @@ __global__ __launch_bounds__(GN_BLOCK) void md_gn_apply_kernel(const float* __re
     if (pos < P) {
       const f32x4 v = xp[pos * 2 + half];
       uint32_t hi[4], lo[4];
+      uint64_t bits = 0;
+      if (thr16) bits = md_drop_bits(seed, (uint64_t)(((int64_t)b * c_total + c_off + cg * 8 + half * 4) >> 2) * (uint64_t)P + (uint64_t)pos);
       if (rhi) {  // second output: bf16 split of the raw input (operand of the NIN shortcut), same read
 #pragma unroll
         for (int e = 0; e < 4; ++e) md_split(v[e], hi[e], lo[e]);
@@ -118,6 +121,7 @@ __global__ __launch_bounds__(GN_BLOCK) void md_gn_apply_kernel(const float* __re
         float y = v[e];
         if (norm) y = (y - mean[e]) * a[e] + bt[e];
         if (silu & 1) y = md_silu(y);
+        if (thr16) y = md_drop_keep(bits, e, thr16) ? y * drop_scale : 0.f;   // nn.Dropout (layers.py:682)
         // experiment hook (tools/longrun_parity.py --act-fp16): round the operand to fp16 first, which is
         // what a weights-split-only fp16 scheme (2 MFMAs per product) would feed the matrix cores
         if (silu & 2) y = __half2float(__float2half_rn(y));
@@ -156,14 +160,16 @@ extern "C" int md_gn_finalize(const double* sums, const float* gamma, const floa
 
 extern "C" int md_gn_apply(const float* x, const float* params, void* out, void* out_raw, int32_t batch,
                            int32_t C, int64_t P, int32_t c_total, int32_t c_off, int32_t norm, int32_t silu,
-                           void* stream) {
+                           float drop_p, uint64_t drop_seed, void* stream) {
+  if (!(drop_p >= 0.f && drop_p < 1.f)) return MD_ERR_BAD_ARG;
   if (!x || !out || (norm && !params) || batch <= 0 || C <= 0 || (C % 8) || (c_off % 8) ||
       (c_total % 8) || c_off + C > c_total || P <= 0)
     return MD_ERR_BAD_ARG;
   dim3 grid((unsigned)((P + GN_CHUNK - 1) / GN_CHUNK), (unsigned)(C / 8), (unsigned)batch);
   MD_HIP_CLEAR_ERROR();
   hipLaunchKernelGGL(md_gn_apply_kernel, grid, dim3(GN_BLOCK), 0, (hipStream_t)stream, x, params,
-                     (uint16_t*)out, (uint16_t*)out_raw, C, P, c_total, c_off, norm, silu);
+                     (uint16_t*)out, (uint16_t*)out_raw, C, P, c_total, c_off, norm, silu, md_drop_thr16(drop_p),
+                     1.0f / (1.0f - drop_p), (uint64_t)drop_seed);
   MD_HIP_CHECK_LAUNCH();
   return MD_OK;
 }
@@ -172,4 +178,32 @@ extern "C" int md_zero(void* p, int64_t bytes, void* stream) {
   if (!p || bytes < 0) return MD_ERR_BAD_ARG;
   hipError_t e = hipMemsetAsync(p, 0, (size_t)bytes, (hipStream_t)stream);
   return e == hipSuccess ? MD_OK : (int)e;
+}
+
+// keep/(1-p) factors of the dropout mask as an F32B tensor [B][C/8][P][8] (tests build the reference's explicit mask
+// from it; the training path itself never materialises the mask).
+__global__ __launch_bounds__(256) void md_dropout_scale_kernel(float* __restrict__ out, int C, int64_t P, int c_total,
+                                                               int c_off, uint32_t thr16, float scale, uint64_t seed) {
+  const int cg = blockIdx.y, b = blockIdx.z;
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t pos = t >> 1;
+  const int half = (int)(t & 1);
+  if (pos >= P) return;
+  const uint64_t bits = md_drop_bits(seed, (uint64_t)(((int64_t)b * c_total + c_off + cg * 8 + half * 4) >> 2) * (uint64_t)P + (uint64_t)pos);
+  f32x4 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) o[e] = (!thr16 || md_drop_keep(bits, e, thr16)) ? scale : 0.f;
+  *(f32x4*)(out + ((((int64_t)b * (C / 8) + cg) * P + pos) * 8 + half * 4)) = o;
+}
+
+extern "C" int md_dropout_scale(float* out, int32_t batch, int32_t C, int64_t P, int32_t c_total, int32_t c_off,
+                                float drop_p, uint64_t drop_seed, void* stream) {
+  if (!out || batch <= 0 || C <= 0 || (C % 8) || (c_off % 8) || c_off + C > c_total || P <= 0 || !(drop_p >= 0.f && drop_p < 1.f))
+    return MD_ERR_BAD_ARG;
+  dim3 grid((unsigned)((P * 2 + 255) / 256), (unsigned)(C / 8), (unsigned)batch);
+  MD_HIP_CLEAR_ERROR();
+  hipLaunchKernelGGL(md_dropout_scale_kernel, grid, dim3(256), 0, (hipStream_t)stream, out, C, P, c_total, c_off,
+                     md_drop_thr16(drop_p), 1.0f / (1.0f - drop_p), (uint64_t)drop_seed);
+  MD_HIP_CHECK_LAUNCH();
+  return MD_OK;
 }

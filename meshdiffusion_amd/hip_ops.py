@@ -179,9 +179,24 @@ def gn_params(parts, gamma, beta, B, P, eps=1e-6, groups=32):
     return params
 
 
-def gn_apply(parts, params, B, P, norm=True, silu=True, out=None, fp16=False, want_raw=False):
+def next_dropout_seed():
+    """A fresh 62-bit mask seed from torch's global CPU generator (so `torch.manual_seed` pins the masks)."""
+    return int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+
+
+def dropout_scale(B, C, P, p, seed, device):
+    """The mask md_gn_apply applies for (p, seed) as an F32B tensor of {0, 1/(1-p)} (parity tests)."""
+    lib = _lib.load()
+    out = f32b_empty(B, C, P, device)
+    check(lib.md_dropout_scale(_ptr(out), B, C, P, C, 0, float(p), int(seed), _stream()), "md_dropout_scale")
+    return out
+
+
+def gn_apply(parts, params, B, P, norm=True, silu=True, out=None, fp16=False, want_raw=False, drop=None):
     """fp16=True: MD_PREC_FP16X2 operand format (plane 0 = fp16(y), plane 1 untouched).
-    want_raw=True: also return the bf16 split of the raw input (one read, two writes)."""
+    want_raw=True: also return the bf16 split of the raw input (one read, two writes).
+    drop=(p, seed): training dropout after the activation (mask regenerated from the seed in the backward)."""
+    dp, dseed = (float(drop[0]), int(drop[1])) if drop else (0.0, 0)
     lib = _lib.load()
     dev = parts[0][0].device
     ctot = sum(c for _, c in parts)
@@ -191,7 +206,8 @@ def gn_apply(parts, params, B, P, norm=True, silu=True, out=None, fp16=False, wa
     off = 0
     for t, c in parts:
         check(lib.md_gn_apply(_ptr(t), _ptr(params) if norm else None, _ptr(out), _ptr(raw), B, c, P, ctot, off,
-                              1 if norm else 0, (1 if silu else 0) | DEBUG_ACT_FP16 | (4 if fp16 else 0), _stream()),
+                              1 if norm else 0, (1 if silu else 0) | DEBUG_ACT_FP16 | (4 if fp16 else 0), dp, dseed,
+                              _stream()),
               "md_gn_apply")
         off += c
     return (out, raw) if want_raw else out

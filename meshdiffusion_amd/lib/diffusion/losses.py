@@ -6,7 +6,8 @@ On the HIP path: forward noising, the masked loss and its gradient w.r.t. eps_ha
 backward (models/backward.py), the global grad-norm and the fused clip + Adam + EMA update.  `loss.backward()`
 works because the U-Net and the loss are each one opaque autograd node whose backward is the HIP code; the
 reference's `optimize_fn` (torch.optim.Adam + clip_grad_norm_) can then be used unchanged, or `FusedAdamEMA`.
-Current limits of the training path: dropout must be 0, per-GPU batch a multiple of 8, ddpm_res64 only.
+Dropout (ResnetBlockDDPM, p = config.model.dropout) runs inside the GroupNorm+SiLU kernel from a counter-based
+mask that the backward regenerates.  Current limits: per-GPU batch a multiple of 8, ddpm_res64 only.
 """
 import ctypes as C
 

@@ -111,17 +111,19 @@ def resample(t, B, C, Sc, mode, accumulate_into=None):
 # ---------------------------------------------------------------------------------------------------------
 # GroupNorm (+SiLU) backward over concatenated parts
 # ---------------------------------------------------------------------------------------------------------
-def gn_backward(parts, dy, params, gn, B, P, silu, d_into=None):
+def gn_backward(parts, dy, params, gn, B, P, silu, d_into=None, drop=None):
     """parts: forward inputs [(F32B, C)]; dy: F32B [B][Ctot][P]; returns one F32B [B][Ctot][P] gradient
-    (written into / accumulated onto `d_into` when given) and accumulates gn.weight/.bias grads."""
+    (written into / accumulated onto `d_into` when given) and accumulates gn.weight/.bias grads.
+    drop=(p, seed): the forward applied dropout after the activation (same mask regenerated here)."""
     lib = _lib.load()
+    dp, dseed = (float(drop[0]), int(drop[1])) if drop else (0.0, 0)
     dev = dy.device
     ctot = sum(c for _, c in parts)
     sums = torch.zeros((B, ctot, 2), dtype=torch.float64, device=dev)
     off = 0
     for t, c in parts:
         check(lib.md_gn_bwd_stats(_ptr(t), _ptr(dy), _ptr(params), _ptr(sums), B, c, P, ctot, off, ctot, 1 if silu else 0,
-                                  _stream()), "md_gn_bwd_stats")
+                                  dp, dseed, _stream()), "md_gn_bwd_stats")
         off += c
     coef = torch.empty((B, ctot, 4), dtype=torch.float32, device=dev)
     check(lib.md_gn_bwd_finalize(_ptr(sums), _ptr(params), _ptr(gn.weight), _ptr(coef), _ptr(_grad_of(gn.weight)),
@@ -135,11 +137,11 @@ def gn_backward(parts, dy, params, gn, B, P, silu, d_into=None):
         dx_view = dxcat.view(B, ctot // 8, P, 8)[:, off // 8:(off + c) // 8]
         if len(parts) == 1:
             check(lib.md_gn_bwd_apply(_ptr(t), _ptr(dy), _ptr(params), _ptr(coef), _ptr(dxcat), B, c, P, ctot, 0, ctot,
-                                      1 if silu else 0, 1 if acc else 0, _stream()), "md_gn_bwd_apply")
+                                      1 if silu else 0, 1 if acc else 0, dp, dseed, _stream()), "md_gn_bwd_apply")
         else:
             tmp = dx_view.contiguous() if acc else ops.f32b_empty(B, c, P, dev)
             check(lib.md_gn_bwd_apply(_ptr(t), _ptr(dy), _ptr(params), _ptr(coef), _ptr(tmp), B, c, P, ctot, off, ctot,
-                                      1 if silu else 0, 1 if acc else 0, _stream()), "md_gn_bwd_apply")
+                                      1 if silu else 0, 1 if acc else 0, dp, dseed, _stream()), "md_gn_bwd_apply")
             outs.append(tmp)
         off += c
     if len(parts) == 1:

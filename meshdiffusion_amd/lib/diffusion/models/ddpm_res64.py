@@ -142,7 +142,7 @@ class DDPMUNet3D(layers.HipLayer):
 
         return self._cached("film", ps, build)
 
-    # ---- training (first correct version; KSIZE 3 / bf16x3 / dropout 0 / batch % 8 == 0) --------------
+    # ---- training (first correct version; KSIZE 3 / bf16x3 / batch % 8 == 0) --------------
     def _autograd_anchor(self):
         a = self.__dict__.get("_md_anchor")
         if a is None or a.device != self.mask.device:

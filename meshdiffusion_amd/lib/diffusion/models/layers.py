@@ -318,8 +318,7 @@ class ResnetBlockDDPM(HipLayer):
         """bias0 (optional): precomputed Conv_0.bias + Dense_0(SiLU(temb)) rows [B, out_ch] with row stride
         `bias0_stride` floats (the U-Net computes all blocks' FiLM biases in one launch).
         tape (optional list): receives what `backward_blocked` needs (training)."""
-        if self.training and self.Dropout_0.p > 0:
-            raise NotImplementedError("dropout > 0 is not implemented on the HIP path yet (use dropout = 0)")
+        drop = (self.Dropout_0.p, ops.next_dropout_seed()) if self.training and self.Dropout_0.p > 0 else None
         S = _spatial_edge(P)
         cin = sum(c for _, c in parts)
         assert cin == self.in_ch
@@ -341,7 +340,7 @@ class ResnetBlockDDPM(HipLayer):
         else:
             h = run_conv3(pw0, a0, B, S, bias=self.Conv_0.bias)
         prm1 = ops.gn_params([(h, self.out_ch)], g1.weight, g1.bias, B, P, eps=g1.eps, groups=g1.num_groups)
-        a1 = ops.gn_apply([(h, self.out_ch)], prm1, B, P, norm=True, silu=True, fp16=f16)
+        a1 = ops.gn_apply([(h, self.out_ch)], prm1, B, P, norm=True, silu=True, fp16=f16, drop=drop)
         if need_nin:
             res = self.NIN_0.forward_s16(xs, B, P)
         else:
@@ -350,7 +349,7 @@ class ResnetBlockDDPM(HipLayer):
         if tape is not None:
             assert not f16, "the backward pass uses the bf16x3 operand format"
             tape.append(dict(layer=self, parts=parts, prm0=prm, a0=a0, h=h, prm1=prm1, a1=a1, xs=xs, B=B, P=P, S=S,
-                             temb=temb))
+                             temb=temb, drop=drop))
         return run_conv3(pw1, a1, B, S, bias=self.Conv_1.bias, residual=res)
 
     def backward_blocked(self, sv, dy):
@@ -359,7 +358,8 @@ class ResnetBlockDDPM(HipLayer):
         from . import backward as bw
         B, P, S, parts = sv["B"], sv["P"], sv["S"], sv["parts"]
         d_a1 = bw.conv3_backward(self, "w1", self.Conv_1, dy, sv["a1"], B, S)
-        d_h = bw.gn_backward([(sv["h"], self.out_ch)], d_a1, sv["prm1"], self.GroupNorm_1, B, P, silu=True)[0]
+        d_h = bw.gn_backward([(sv["h"], self.out_ch)], d_a1, sv["prm1"], self.GroupNorm_1, B, P, silu=True,
+                             drop=sv.get("drop"))[0]
         del d_a1
         dbias0 = bw.channel_sums(d_h, B, self.out_ch, P)
         d_a0 = bw.conv3_backward(self, "w0", self.Conv_0, d_h, sv["a0"], B, S)

@@ -52,12 +52,15 @@ class _SD:
         return _SD(self.sd, self.prefix + p)
 
 
-def resnet_block(p, x, temb):
-    """layers.py:672-689 (eval mode: dropout is the identity)."""
+def resnet_block(p, x, temb, drop=None):
+    """layers.py:672-689.  Eval mode (drop=None): dropout is the identity.  Training: `drop` is the explicit
+    {0, 1/(1-p)} factor tensor nn.Dropout would have multiplied by (layers.py:682), supplied by the test."""
     h = F.silu(group_norm(x, p["GroupNorm_0.weight"], p["GroupNorm_0.bias"]))
     h = F.conv3d(h, p["Conv_0.weight"], p["Conv_0.bias"], padding=1)
     h = h + F.linear(F.silu(temb), p["Dense_0.weight"], p["Dense_0.bias"])[:, :, None, None, None]
     h = F.silu(group_norm(h, p["GroupNorm_1.weight"], p["GroupNorm_1.bias"]))
+    if drop is not None:
+        h = h * drop
     h = F.conv3d(h, p["Conv_1.weight"], p["Conv_1.bias"], padding=1)
     if "NIN_0.W" in p:
         x = nin(x, p["NIN_0.W"], p["NIN_0.b"])

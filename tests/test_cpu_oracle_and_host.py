@@ -105,7 +105,7 @@ def test_c_abi_exports_every_declared_symbol(hip_lib):
     raw = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared:
         assert hasattr(raw, name), name
-    assert hip_lib.md_abi_version() == 1
+    assert hip_lib.md_abi_version() == 2
     info = _lib.cfg_info(_lib.CFG_C3_128)
     assert info["taps"] == 27 and info["lds_bytes"] <= 160 * 1024 and info["threads"] == 512
     nm = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout

@@ -61,6 +61,55 @@ def test_resnet_block_backward(hip_lib, cin_parts, cout, S):
     assert rel_l2(dbias0.sum(0).cpu(), d_film_ref) < TOL
 
 
+def test_resnet_block_dropout_forward_backward(hip_lib):
+    """Training-mode dropout (layers.py:682): the HIP path regenerates its mask from (p, seed); the oracle gets
+    the same mask explicitly (md_dropout_scale), so outputs and every gradient must agree as without dropout.
+    Also: keep rate ~ 1-p, masks differ between seeds / blocks and repeat for the same torch seed."""
+    from meshdiffusion_amd import hip_ops as ops
+    from meshdiffusion_amd.lib.diffusion.models import layers
+    from oracle import unet_oracle as uo
+    B, cin, cout, S, p = 8, 128, 64, 8, 0.3
+    P = S ** 3
+    blk = layers.ResnetBlockDDPM(act=torch.nn.SiLU(), in_ch=cin, out_ch=cout, temb_dim=128, dropout=p)
+    sd = _load(blk, 3)
+    blk = blk.cuda().train()
+    x, temb, dy = _randn((B, cin, S, S, S), 10), _randn((B, 128), 2), _randn((B, cout, S, S, S), 4)
+    parts = [(_f32b(ops, x), cin)]
+    tape = []
+    torch.manual_seed(77)
+    with torch.no_grad():
+        y = blk.forward_blocked(parts, B, P, temb.cuda(), tape=tape)
+        dparts, _ = blk.backward_blocked(tape[0], _f32b(ops, dy))
+    pd, seed = tape[0]["drop"]
+    assert pd == p
+    scale = ops.f32b_to_ncdhw(ops.dropout_scale(B, cout, P, p, seed, x.cuda().device), (S, S, S)).cpu()
+    vals = torch.unique(scale)
+    assert vals.numel() == 2 and vals[0] == 0 and abs(float(vals[1]) - 1 / (1 - p)) < 1e-6
+    keep = float((scale > 0).double().mean())
+    assert abs(keep - (1 - p)) < 4 * (p * (1 - p) / scale.numel()) ** 0.5 + 1e-4
+    per_channel = (scale > 0).double().mean(dim=(0, 2, 3, 4))
+    assert float((per_channel - (1 - p)).abs().max()) < 0.05           # no dead / always-on channel lanes
+    sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    xr, tr = x.clone().requires_grad_(True), temb.clone().requires_grad_(True)
+    y_ref = uo.resnet_block(sdr, xr, tr, drop=scale)
+    y_ref.backward(dy)
+    assert rel_l2(ops.f32b_to_ncdhw(y, (S, S, S)).cpu(), y_ref.detach()) < 1e-4
+    assert rel_l2(ops.f32b_to_ncdhw(dparts[0], (S, S, S)).cpu(), xr.grad) < TOL
+    params = dict(blk.named_parameters())
+    for n in ["Conv_0.weight", "Conv_1.weight", "GroupNorm_0.weight", "GroupNorm_1.weight", "GroupNorm_1.bias", "NIN_0.W"]:
+        assert rel_l2(params[n].grad.cpu(), sdr[n].grad) < TOL, n
+    # eval mode: identity; same torch seed: same mask; next call: another mask
+    tape2, tape3 = [], []
+    torch.manual_seed(77)
+    with torch.no_grad():
+        y2 = blk.forward_blocked(parts, B, P, temb.cuda(), tape=tape2)
+        y3 = blk.forward_blocked(parts, B, P, temb.cuda(), tape=tape3)
+        y_eval = blk.eval().forward_blocked(parts, B, P, temb.cuda())
+    assert torch.equal(y2, y) and tape2[0]["drop"] == tape[0]["drop"] and tape3[0]["drop"][1] != seed
+    assert not torch.equal(y3, y)
+    assert rel_l2(ops.f32b_to_ncdhw(y_eval, (S, S, S)).cpu(), uo.resnet_block(sd, x, temb)) < 1e-4
+
+
 def test_up_down_nin_backward(hip_lib):
     from meshdiffusion_amd import hip_ops as ops
     from meshdiffusion_amd.lib.diffusion.models import backward as bw, layers

@@ -1,5 +1,5 @@
 """BASELINE config #3 on the GPUs that are visible: res64 training step (forward + loss + backward + gradient
-all-reduce + fused clip/Adam/EMA), batch 8 per GPU, dropout 0.  One process per GPU:
+all-reduce + fused clip/Adam/EMA), batch 8 per GPU, dropout as configured (0.1).  One process per GPU:
 
     python tools/train_step_bench.py --steps 2 --warmup 1
     python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 tools/train_step_bench.py
@@ -33,7 +33,6 @@ def main():
     dev = torch.device("cuda", local)
     cfg = synth.small_config() if a.small else get_config_res64()
     cfg.device = dev
-    cfg.model.dropout = 0.0
     R = cfg.data.image_size
     model = mutils.create_model(cfg)
     sd = synth.sensitised_state_dict(model.module.state_dict(), seed=1234, grid_mask=synth.synthetic_grid_mask(R))
@@ -86,7 +85,7 @@ def main():
         print(json.dumps({"metric": "res64 training step (fwd+bwd+Adam/EMA), samples/s", "value": round(world * a.batch * a.steps / w, 3),
                           "n_gpus": world, "batch_per_gpu": a.batch, "steps": a.steps, "s_per_step": round(w / a.steps, 3),
                           "losses": [round(v, 5) for v in ls], "peak_hbm_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
-                          "last_step_split_ms": {k: round(v, 1) for k, v in split.items()}, "dropout": 0.0,
+                          "last_step_split_ms": {k: round(v, 1) for k, v in split.items()}, "dropout": cfg.model.dropout,
                           "model": "small" if a.small else "ddpm_res64"}))
     if world > 1:
         torch.distributed.destroy_process_group()
