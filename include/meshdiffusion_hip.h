@@ -259,6 +259,20 @@ int md_to_pb16(const void* src, void* out, int32_t batch, int32_t C, int32_t c_s
                int32_t guard, int32_t mode, int32_t up, int32_t stuff, void* stream);  /* channels >= c_src are zero */
 int md_wgrad_finish(const float* g, float* dw, int32_t rows, int32_t cols, int32_t cols_alloc, int32_t ntap,
                     int32_t tap0, int64_t s_row, int64_t s_k, int64_t s_tap, void* stream);
+/*
+ * md_wgrad: dw[row*s_row + col*s_k + tap*s_tap] += sum_{position, sample} dY[row][pos] * A[col][pos + off(tap)]
+ * for the 27 taps of a 3x3x3 convolution (tap = (dz*3+dy)*3+dx, off = ((dz-1)(D+2) + dy-1)(D+2) + dx-1) or the
+ * single tap of a 1x1x1 layer (taps = 1) -- autograd of nn.Conv3d (layers.py:118-124) / NIN (layers.py:573-582).
+ * dy_pb / act_pb: PB16 tensors from md_to_pb16 with a_ch / b_ch channels (multiples of 8) on the same cubic grid
+ * and `guard` >= (D+2)^2 + (D+2) + 9; rows <= a_ch, cols <= b_ch are the valid co / ci.  bf16x3 MFMA, fp32
+ * accumulate; the contraction is split into `ksplit` position ranges whose partial sums live in `workspace`
+ * (md_wgrad_workspace_bytes) and are reduced in a fixed order, so results are run-to-run identical.
+ */
+void md_wgrad_set_debug(int32_t flags);   /* profiling ablations only (tools/bench_wgrad.py); 0 = normal */
+int64_t md_wgrad_workspace_bytes(int32_t rows, int32_t cols, int32_t taps, int32_t ksplit);
+int md_wgrad(const void* dy_pb, const void* act_pb, float* dw, void* workspace, int64_t workspace_bytes, int32_t batch,
+             int32_t a_ch, int32_t b_ch, int32_t rows, int32_t cols, int32_t D, int32_t H, int32_t W, int32_t guard,
+             int32_t taps, int32_t ksplit, int64_t s_row, int64_t s_k, int64_t s_tap, void* stream);
 int md_gn_bwd_stats(const float* x, const float* dy, const float* params, double* sums, int32_t batch, int32_t C,
                     int64_t P, int32_t c_total, int32_t c_off, int32_t dy_ctotal, int32_t silu, float drop_p,
                     uint64_t drop_seed, void* stream);

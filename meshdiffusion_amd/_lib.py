@@ -71,6 +71,10 @@ SIGNATURES = {
     "md_pb16_bytes": (_I64, [_I32, _I32, _I32, _I32, _I32, _I32]),
     "md_to_pb16": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P]),
     "md_wgrad_finish": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _I32, _I64, _I64, _I64, _P]),
+    "md_wgrad_set_debug": (None, [_I32]),
+    "md_wgrad_workspace_bytes": (_I64, [_I32, _I32, _I32, _I32]),
+    "md_wgrad": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I64, _I64,
+                           _I64, _P]),
     "md_gn_bwd_stats": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I64, _I32, _I32, _I32, _I32, _F, _U64, _P]),
     "md_gn_bwd_finalize": (C.c_int, [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I64, _P]),
     "md_gn_bwd_apply": (C.c_int, [_P, _P, _P, _P, _P, _I32, _I32, _I64, _I32, _I32, _I32, _I32, _I32, _F, _U64, _P]),

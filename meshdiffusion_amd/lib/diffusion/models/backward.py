@@ -2,8 +2,8 @@
 
 Every contraction re-uses md_gemm_conv:
   * dgrad of a conv / NIN  = the forward kernels on WPK tiles packed from the flipped + transposed weight;
-  * wgrad                  = split-K GEMM over (position, sample) on PB16 operands (csrc/backward.hip), one
-                             B-pointer offset per tap, the three dx taps of a (dz, dy) row batched per launch;
+  * wgrad                  = md_wgrad (csrc/wgrad.hip): a dedicated MFMA kernel contracting over (position, sample)
+                             on PB16 operands, 128 co x 128 ci x 3 dx taps per workgroup, deterministic split-K;
 GroupNorm/SiLU backward, bias sums and gradient resampling are streaming kernels.  Glue that is not on the
 FLOP/byte path (slicing a concatenated gradient, adding two gradients, the [B,512] timestep-MLP algebra) uses
 torch tensor ops on the device.
@@ -18,6 +18,7 @@ from .... import hip_ops as ops
 from ....hip_ops import _ptr, _stream, check
 
 GUARD_EXTRA = 8
+WGRAD_BLOCKS = 256     # one 512-thread wgrad workgroup per CU
 
 
 def _grad_of(p):
@@ -54,38 +55,20 @@ def to_pb16(src, B, C, S, mode, up=0, stuff=0, c_src=None):
     return out
 
 
-def wgrad(dy_pb, act_pb, B, co, ci, S, taps, dw, s_row, s_k, s_tap, a_ch=None):
-    """dw[co][ci][tap] += sum_{pos,b} dy[co][pos,b] * act[ci][pos + off(tap), b]   (taps = 27 or 1).
-    a_ch: channel count of the dy PB16 tensor when it was padded beyond `co`."""
+def wgrad(dy_pb, act_pb, B, co, ci, S, taps, dw, s_row, s_k, s_tap, a_ch=None, b_ch=None):
+    """dw[co*s_row + ci*s_k + tap*s_tap] += sum_{pos,b} dy[co][pos,b] * act[ci][pos + off(tap), b]  (taps = 27 or 1)
+    -- md_wgrad (csrc/wgrad.hip).  a_ch / b_ch: channel counts of the two PB16 tensors when they exceed co / ci."""
     lib = _lib.load()
     g = _guard(S)
-    Sp = S + 2
-    Pp = Sp ** 3
-    kpos = ((Pp + 3) // 4) * 4
-    bg = B // 8
-    kdim = kpos * bg * 8
     a_ch = co if a_ch is None else a_ch
-    a_pos = bg * 2 * a_ch * 8        # bf16 elements per position of the A (dy) operand
-    b_pos = bg * 2 * ci * 8
-    cfg = ops.CFG_G1_128_LOW
-    assert ci % 64 == 0, "wgrad needs the activation channel count to be a multiple of 64 (pad with zeros)"
-    rows8 = ((co + 7) // 8) * 8
-    tiles = (ci // 64) * ((co + 127) // 128)
-    ksplit = 1
-    while tiles * 3 * ksplit < 1024 and ksplit < 256 and ksplit * 2 <= kdim // 32:
-        ksplit *= 2
-    a_base = dy_pb[g * a_pos:]
-    groups = [(dz, dyy) for dz in range(3) for dyy in range(3)] if taps == 27 else [(1, 1)]
-    nb = 3 if taps == 27 else 1
-    for dz, dyy in groups:
-        off = ((dz - 1) * Sp + (dyy - 1)) * Sp + (-1 if taps == 27 else 0)
-        b_base = act_pb[(g + off) * b_pos:]
-        out = torch.empty((nb, rows8 // 8, ci, 8), dtype=torch.float32, device=dy_pb.device)
-        ops.gemm_conv(cfg=cfg, a=a_base, b=b_base, out=out, batch=nb, rows=co, rows_alloc=rows8, kdim=kdim,
-                      dims=(1, 1, ci), a_src=ops.A_S16B, a_rows=a_ch, a_bstride=0, b_bstride=b_pos, ksplit=ksplit)
-        tap0 = (dz * 3 + dyy) * 3 if taps == 27 else 0
-        check(lib.md_wgrad_finish(_ptr(out), _ptr(dw), co, ci, ci, nb, tap0, s_row, s_k, s_tap, _stream()),
-              "md_wgrad_finish")
+    b_ch = ci if b_ch is None else b_ch
+    stages = (B // 8) * S * S * ((S + 7) // 8)
+    units = ((co + 127) // 128) * ((ci + 127) // 128) * (9 if taps == 27 else 1)
+    ksplit = max(1, min(WGRAD_BLOCKS // units, stages // 4))
+    nbytes = lib.md_wgrad_workspace_bytes(co, ci, taps, ksplit)
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=dy_pb.device)
+    check(lib.md_wgrad(_ptr(dy_pb), _ptr(act_pb), _ptr(dw), _ptr(ws), nbytes, B, a_ch, b_ch, co, ci, S, S, S, g, taps,
+                       ksplit, s_row, s_k, s_tap, _stream()), "md_wgrad")
 
 
 def channel_sums(t, B, C, P):
@@ -177,15 +160,8 @@ def conv3_backward(layer, name, conv, dy, act_s16, B, S_out, ups=0, stride=1, ne
     else:
         dy_pb = to_pb16(dy, B, co_t, S_out, 0)
     c_src = act_channels if act_channels is not None else ci      # channels of the S16B operand tensor
-    ci_pad = ((c_src + 63) // 64) * 64
-    act_pb = to_pb16(act_s16, B, ci_pad, S_fine, 1, up=ups, c_src=c_src)
-    dw = _grad_of(conv.weight)
-    if ci_pad != ci:      # operand zero padded to a multiple of 64 channels: accumulate into a padded scratch
-        scratch = torch.zeros((co, ci_pad, 27), dtype=torch.float32, device=dev)
-        wgrad(dy_pb, act_pb, B, co, ci_pad, S_fine, 27, scratch, ci_pad * 27, 27, 1, a_ch=co_t)
-        dw.add_(scratch[:, :ci].reshape(dw.shape))
-    else:
-        wgrad(dy_pb, act_pb, B, co, ci, S_fine, 27, dw, ci * 27, 27, 1, a_ch=co_t)
+    act_pb = to_pb16(act_s16, B, c_src, S_fine, 1, up=ups)
+    wgrad(dy_pb, act_pb, B, co, ci, S_fine, 27, _grad_of(conv.weight), ci * 27, 27, 1, a_ch=co_t, b_ch=c_src)
     del dy_pb, act_pb
     if not need_dx:
         return None
@@ -238,15 +214,9 @@ def softmax_keys_bwd(p_s16, dp, B, nk, nq, alpha):
 
 
 def wgrad_nin(dy_pb, xs_s16, B, co, ci, S, dw):
-    """dw[ci][co] += sum x[ci] dy[co] with the activation channels padded to a multiple of 64 when needed."""
-    ci_pad = ((ci + 63) // 64) * 64
-    x_pb = to_pb16(xs_s16, B, ci_pad, S, 1, c_src=ci)
-    if ci_pad == ci:
-        wgrad(dy_pb, x_pb, B, co, ci, S, 1, dw, 1, co, 0)
-    else:
-        scratch = torch.zeros((ci_pad, co), dtype=torch.float32, device=dw.device)
-        wgrad(dy_pb, x_pb, B, co, ci_pad, S, 1, scratch, 1, co, 0)
-        dw.add_(scratch[:ci])
+    """dw[ci][co] += sum x[ci] dy[co]."""
+    x_pb = to_pb16(xs_s16, B, ci, S, 1)
+    wgrad(dy_pb, x_pb, B, co, ci, S, 1, dw, 1, co, 0)
 
 
 def nin_backward(nin, dy, xs_s16, B, P, S, need_dx=True, with_bias=True):
