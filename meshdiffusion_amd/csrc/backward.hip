@@ -19,7 +19,7 @@ __global__ void md_to_pb16_kernel(const void* __restrict__ src, uint16_t* __rest
                                   int H, int W, int guard, int mode, int up, int stuff) {
   const int Dp = D + 2, Hp = H + 2, Wp = W + 2;
   const int64_t Pp = (int64_t)Dp * Hp * Wp;
-  const int bg_n = B / 8;
+  const int bg_n = (B + 7) / 8;   // a partial last block of 8 samples is zero filled
   const int64_t total = Pp * bg_n * C;  // one thread = one (pos, bgroup, c): 8 samples, hi + lo
   const int Ds = (up || stuff) ? D / 2 : D, Hs = (up || stuff) ? H / 2 : H, Ws = (up || stuff) ? W / 2 : W;
   const int64_t Ps = (int64_t)Ds * Hs * Ws;
@@ -38,6 +38,7 @@ __global__ void md_to_pb16_kernel(const void* __restrict__ src, uint16_t* __rest
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         const int b = bg * 8 + k;
+        if (b >= B) break;
         if (mode == 0) {
           const float v = ((const float*)src)[(((int64_t)b * (Cs / 8) + (c >> 3)) * Ps + sp) * 8 + (c & 7)];
           md_split(v, hi[k], lo[k]);
@@ -55,8 +56,8 @@ __global__ void md_to_pb16_kernel(const void* __restrict__ src, uint16_t* __rest
 }
 
 extern "C" int64_t md_pb16_bytes(int32_t batch, int32_t C, int32_t D, int32_t H, int32_t W, int32_t guard) {
-  if (batch <= 0 || (batch % 8) || C <= 0 || D <= 0 || H <= 0 || W <= 0 || guard < 0) return MD_ERR_BAD_ARG;
-  return ((int64_t)(D + 2) * (H + 2) * (W + 2) + 2 * (int64_t)guard) * (batch / 8) * 2 * C * 8 * 2;
+  if (batch <= 0 || C <= 0 || D <= 0 || H <= 0 || W <= 0 || guard < 0) return MD_ERR_BAD_ARG;
+  return ((int64_t)(D + 2) * (H + 2) * (W + 2) + 2 * (int64_t)guard) * ((batch + 7) / 8) * 2 * C * 8 * 2;
 }
 
 extern "C" int md_to_pb16(const void* src, void* out, int32_t batch, int32_t C, int32_t c_src, int32_t D, int32_t H,
@@ -65,9 +66,16 @@ extern "C" int md_to_pb16(const void* src, void* out, int32_t batch, int32_t C, 
       mode < 0 || mode > 1)
     return MD_ERR_BAD_ARG;
   if ((up || stuff) && ((D | H | W) & 1)) return MD_ERR_BAD_ARG;
-  hipError_t e = hipMemsetAsync(out, 0, (size_t)md_pb16_bytes(batch, C, D, H, W, guard), (hipStream_t)stream);
-  if (e != hipSuccess) return (int)e;
-  const int64_t total = (int64_t)(D + 2) * (H + 2) * (W + 2) * (batch / 8) * C;
+  // the kernel writes every position of the padded grid (zeros on the halo); only the two guards need clearing
+  const int64_t pos_bytes = (int64_t)((batch + 7) / 8) * 2 * C * 8 * 2;
+  const int64_t Pp = (int64_t)(D + 2) * (H + 2) * (W + 2);
+  if (guard > 0) {
+    hipError_t e = hipMemsetAsync(out, 0, (size_t)(guard * pos_bytes), (hipStream_t)stream);
+    if (e == hipSuccess)
+      e = hipMemsetAsync((char*)out + (guard + Pp) * pos_bytes, 0, (size_t)(guard * pos_bytes), (hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
+  }
+  const int64_t total = Pp * ((batch + 7) / 8) * C;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 8192) blocks = 8192;
   MD_HIP_CLEAR_ERROR();

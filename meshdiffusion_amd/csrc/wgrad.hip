@@ -247,7 +247,7 @@ extern "C" int md_wgrad(const void* dy_pb, const void* act_pb, float* dw, void* 
                         int32_t batch, int32_t a_ch, int32_t b_ch, int32_t rows, int32_t cols, int32_t D, int32_t H,
                         int32_t W, int32_t guard, int32_t taps, int32_t ksplit, int64_t s_row, int64_t s_k, int64_t s_tap,
                         void* stream) {
-  if (!dy_pb || !act_pb || !dw || !workspace || batch <= 0 || (batch % 8) || a_ch <= 0 || b_ch <= 0 || (a_ch % 8) ||
+  if (!dy_pb || !act_pb || !dw || !workspace || batch <= 0 || a_ch <= 0 || b_ch <= 0 || (a_ch % 8) ||
       (b_ch % 8) || rows <= 0 || rows > a_ch || cols <= 0 || cols > b_ch || D <= 0 || H != D || W != D ||
       (taps != 27 && taps != 1) || ksplit <= 0)
     return MD_ERR_BAD_ARG;
@@ -256,7 +256,7 @@ extern "C" int md_wgrad(const void* dy_pb, const void* act_pb, float* dw, void* 
   if (guard < sp * sp + sp + 1 + WG_STAGE) return MD_ERR_BAD_ARG;
   if (workspace_bytes < md_wgrad_workspace_bytes(rows, cols, taps, ksplit)) return MD_ERR_BAD_ARG;
   WgArgs g;
-  g.bgn = batch / 8;
+  g.bgn = (batch + 7) / 8;
   g.a_ch = a_ch; g.b_ch = b_ch;
   g.dy = (const uint16_t*)dy_pb + (int64_t)guard * g.bgn * 2 * a_ch * 8;
   g.act = (const uint16_t*)act_pb + (int64_t)guard * g.bgn * 2 * b_ch * 8;

@@ -9,7 +9,8 @@ FLOP/byte path (slicing a concatenated gradient, adding two gradients, the [B,51
 torch tensor ops on the device.
 
 Gradients are F32B tensors shaped like the forward activations; parameter gradients accumulate into `.grad`.
-Batch must be a multiple of 8 (the PB16 contraction blocks 8 samples).
+Any batch size works; the wgrad contraction blocks 8 samples per MFMA k-group, so a batch that is not a multiple
+of 8 pays for the zero-filled remainder of its last block (B = 6 costs the wgrad time of B = 8).
 """
 import torch
 
@@ -47,8 +48,8 @@ def to_pb16(src, B, C, S, mode, up=0, stuff=0, c_src=None):
     g = _guard(S)
     nbytes = lib.md_pb16_bytes(B, C, S, S, S, g)
     if nbytes <= 0:
-        raise _lib.MeshDiffusionHipError("md_pb16_bytes failed (batch must be a multiple of 8)")
-    out = torch.empty(nbytes // 2 + 4 * 2 * C * 8 * (B // 8), dtype=torch.bfloat16, device=src.device)
+        raise _lib.MeshDiffusionHipError("md_pb16_bytes failed")
+    out = torch.empty(nbytes // 2 + 4 * 2 * C * 8 * ((B + 7) // 8), dtype=torch.bfloat16, device=src.device)
     out[nbytes // 2:].zero_()      # tail so that K rounded up to 4 positions stays in bounds
     check(lib.md_to_pb16(_ptr(src), _ptr(out), B, C, C if c_src is None else c_src, S, S, S, g, mode, up, stuff,
                          _stream()), "md_to_pb16")
@@ -62,7 +63,7 @@ def wgrad(dy_pb, act_pb, B, co, ci, S, taps, dw, s_row, s_k, s_tap, a_ch=None, b
     g = _guard(S)
     a_ch = co if a_ch is None else a_ch
     b_ch = ci if b_ch is None else b_ch
-    stages = (B // 8) * S * S * ((S + 7) // 8)
+    stages = ((B + 7) // 8) * S * S * ((S + 7) // 8)
     units = ((co + 127) // 128) * ((ci + 127) // 128) * (9 if taps == 27 else 1)
     ksplit = max(1, min(WGRAD_BLOCKS // units, stages // 4))
     nbytes = lib.md_wgrad_workspace_bytes(co, ci, taps, ksplit)
@@ -143,7 +144,8 @@ def dgrad_weight(layer, name, conv, cfg):
     return layer._cached(f"{name}/dgrad{cfg}", [conv.weight], build)
 
 
-def conv3_backward(layer, name, conv, dy, act_s16, B, S_out, ups=0, stride=1, need_dx=True, act_channels=None):
+def conv3_backward(layer, name, conv, dy, act_s16, B, S_out, ups=0, stride=1, need_dx=True, act_channels=None,
+                   bias_sums=None):
     """Backward of y = conv3x3x3(act) (+bias).  dy: F32B [B][co][S_out^3]; act_s16: S16B input operand of the
     forward (coarse grid when ups, fine grid 2*S_out when stride 2).  Returns dx (F32B) or None."""
     from . import layers
@@ -152,7 +154,9 @@ def conv3_backward(layer, name, conv, dy, act_s16, B, S_out, ups=0, stride=1, ne
     dev = dy.device
     co_t = dy.shape[1] * 8            # channels of the dy tensor (co rounded up to 8)
     # bias
-    _grad_of(conv.bias).add_(channel_sums(dy, B, co_t, P).sum(0)[:co])
+    if bias_sums is not False:   # False: the caller owns the bias gradient (ResnetBlock Conv_0: FiLM shares the sums)
+        bs = bias_sums if bias_sums is not None else channel_sums(dy, B, co_t, P)
+        _grad_of(conv.bias).add_(bs.sum(0)[:co])
     # weight gradient
     S_fine = S_out * stride
     if stride == 2:

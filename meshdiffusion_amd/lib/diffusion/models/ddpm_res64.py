@@ -142,7 +142,7 @@ class DDPMUNet3D(layers.HipLayer):
 
         return self._cached("film", ps, build)
 
-    # ---- training (first correct version; KSIZE 3 / bf16x3 / batch % 8 == 0) --------------
+    # ---- training (first correct version; KSIZE 3 / bf16x3) --------------
     def _autograd_anchor(self):
         a = self.__dict__.get("_md_anchor")
         if a is None or a.device != self.mask.device:
@@ -157,8 +157,6 @@ class DDPMUNet3D(layers.HipLayer):
         ops.set_precision("bf16x3")
         mods = self.all_modules
         B, R = x.shape[0], self.img_size
-        if B % 8:
-            raise NotImplementedError("the HIP backward needs a per-GPU batch that is a multiple of 8")
         P = R ** 3
         i = 0
         emb = layers.get_timestep_embedding(labels, self.nf)

@@ -362,8 +362,8 @@ class ResnetBlockDDPM(HipLayer):
                              drop=sv.get("drop"))[0]
         del d_a1
         dbias0 = bw.channel_sums(d_h, B, self.out_ch, P)
-        d_a0 = bw.conv3_backward(self, "w0", self.Conv_0, d_h, sv["a0"], B, S)
-        bw._grad_of(self.Conv_0.bias).sub_(dbias0.sum(0))   # conv3_backward added it; FiLM caller re-adds once
+        # Conv_0.bias gradient = batch sum of dbias0: the FiLM caller adds it once together with Dense_0's
+        d_a0 = bw.conv3_backward(self, "w0", self.Conv_0, d_h, sv["a0"], B, S, bias_sums=False)
         del d_h
         if self.in_ch != self.out_ch:
             d_xcat = bw.nin_backward(self.NIN_0, dy, sv["xs"], B, P, S)

@@ -24,12 +24,15 @@ def _f32b(ops, t):
     return ops.ncdhw_to_f32b(t.cuda())
 
 
-@pytest.mark.parametrize("cin_parts,cout,S", [((64,), 64, 8), ((64, 64), 64, 8), ((128,), 64, 4)])
-def test_resnet_block_backward(hip_lib, cin_parts, cout, S):
+@pytest.mark.parametrize("cin_parts,cout,S,B", [((64,), 64, 8, 8), ((64, 64), 64, 8, 8), ((128,), 64, 4, 8),
+                                                ((64, 64), 64, 8, 6), ((64,), 64, 8, 11)])
+def test_resnet_block_backward(hip_lib, cin_parts, cout, S, B):
+    """B = 6 / 11: per-GPU batches that are not a multiple of the 8-sample wgrad block (reference res64 config:
+    training.batch_size 48 over 8 GPUs = 6 per GPU)."""
     from meshdiffusion_amd import hip_ops as ops
     from meshdiffusion_amd.lib.diffusion.models import layers
     from oracle import unet_oracle as uo
-    B, cin = 8, sum(cin_parts)
+    cin = sum(cin_parts)
     blk = layers.ResnetBlockDDPM(act=torch.nn.SiLU(), in_ch=cin, out_ch=cout, temb_dim=128, dropout=0.0)
     sd = _load(blk, 3)
     blk = blk.cuda().train()
@@ -147,12 +150,11 @@ def test_up_down_nin_backward(hip_lib):
     assert rel_l2(nin.W.grad.cpu(), Wr.grad) < TOL and rel_l2(nin.b.grad.cpu(), br.grad) < TOL
 
 
-@pytest.mark.parametrize("Cc,S", [(64, 8), (64, 4)])
-def test_attn_block_backward(hip_lib, Cc, S):
+@pytest.mark.parametrize("Cc,S,B", [(64, 8, 8), (64, 4, 8), (64, 8, 3)])
+def test_attn_block_backward(hip_lib, Cc, S, B):
     from meshdiffusion_amd import hip_ops as ops
     from meshdiffusion_amd.lib.diffusion.models import layers
     from oracle import unet_oracle as uo
-    B = 8
     blk = layers.AttnBlock(channels=Cc)
     sd = _load(blk, 4)
     blk = blk.cuda().train()
