@@ -254,17 +254,19 @@ int md_adam_ema_step(float* p, const float* g, float* m, float* v, float* ema, i
  *   md_channel_sums : out[b][c] += sum_p x (bias / FiLM gradients); md_grad_resample: Upsample backward
  *                     (mode 0: sum of the 8 children) and zero-stuffing (mode 1).
  */
-int64_t md_pb16_bytes(int32_t batch, int32_t C, int32_t D, int32_t H, int32_t W, int32_t guard);
+int64_t md_pb16_bytes(int32_t batch, int32_t C, int32_t D, int32_t H, int32_t W, int32_t guard, int32_t pad);
 int md_to_pb16(const void* src, void* out, int32_t batch, int32_t C, int32_t c_src, int32_t D, int32_t H, int32_t W,
-               int32_t guard, int32_t mode, int32_t up, int32_t stuff, void* stream);  /* channels >= c_src are zero */
+               int32_t guard, int32_t pad, int32_t mode, int32_t up, int32_t stuff, void* stream);
+               /* channels >= c_src are zero; pad = halo of the grid: 1 (3x3x3, 1x1x1 consumers) or 2 (5x5x5) */
 int md_wgrad_finish(const float* g, float* dw, int32_t rows, int32_t cols, int32_t cols_alloc, int32_t ntap,
                     int32_t tap0, int64_t s_row, int64_t s_k, int64_t s_tap, void* stream);
 /*
  * md_wgrad: dw[row*s_row + col*s_k + tap*s_tap] += sum_{position, sample} dY[row][pos] * A[col][pos + off(tap)]
- * for the 27 taps of a 3x3x3 convolution (tap = (dz*3+dy)*3+dx, off = ((dz-1)(D+2) + dy-1)(D+2) + dx-1) or the
- * single tap of a 1x1x1 layer (taps = 1) -- autograd of nn.Conv3d (layers.py:118-124) / NIN (layers.py:573-582).
- * dy_pb / act_pb: PB16 tensors from md_to_pb16 with a_ch / b_ch channels (multiples of 8) on the same cubic grid
- * and `guard` >= (D+2)^2 + (D+2) + 9; rows <= a_ch, cols <= b_ch are the valid co / ci.  bf16x3 MFMA, fp32
+ * for the taps of a k^3 convolution, taps = k^3 in {27, 125} (tap = (dz*k+dy)*k+dx, positions on the grid padded by
+ * p = k/2), or the single tap of a 1x1x1 layer (taps = 1, p = 1) -- autograd of nn.Conv3d (layers.py:118-124,
+ * ddpm_res128.py:90-92,132) / NIN (layers.py:573-582).
+ * dy_pb / act_pb: PB16 tensors from md_to_pb16 (pad = p) with a_ch / b_ch channels (multiples of 8) on the same cubic
+ * grid and `guard` >= p((D+2p)^2 + (D+2p) + 1) + 10; rows <= a_ch, cols <= b_ch are the valid co / ci.  bf16x3 MFMA, fp32
  * accumulate; the contraction is split into `ksplit` position ranges whose partial sums live in `workspace`
  * (md_wgrad_workspace_bytes) and are reduced in a fixed order, so results are run-to-run identical.
  */

@@ -68,8 +68,8 @@ SIGNATURES = {
     "md_masked_sq_err": (C.c_int, [_P, _P, _P, _P, _P, _F, _I32, _I32, _I64, _P]),
     "md_grad_sqnorm": (C.c_int, [_P, _I64, _P, _P]),
     "md_adam_ema_step": (C.c_int, [_P, _P, _P, _P, _P, _I64, _F, _F, _F, _F, _F, _I32, _F, _P, _F, _P]),
-    "md_pb16_bytes": (_I64, [_I32, _I32, _I32, _I32, _I32, _I32]),
-    "md_to_pb16": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P]),
+    "md_pb16_bytes": (_I64, [_I32, _I32, _I32, _I32, _I32, _I32, _I32]),
+    "md_to_pb16": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P]),
     "md_wgrad_finish": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _I32, _I64, _I64, _I64, _P]),
     "md_wgrad_set_debug": (None, [_I32]),
     "md_wgrad_workspace_bytes": (_I64, [_I32, _I32, _I32, _I32]),

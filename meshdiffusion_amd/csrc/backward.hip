@@ -2,8 +2,8 @@
 // re-uses md_gemm_conv (dgrad = conv with flipped/transposed WPK tiles; wgrad = split-K GEMM over positions), so
 // this file only holds the streaming pieces around it.
 //
-// PB16 layout (wgrad operands): bf16 [G + Pp + G][B/8][2][C][8 samples], positions on the zero-padded grid
-// (D+2)(H+2)(W+2) plus G guard positions of zeros on both sides.  The contraction index of a weight gradient is
+// PB16 layout (wgrad operands): bf16 [G + Pp + G][ceil(B/8)][2][C][8 samples], positions on the zero-padded grid
+// (D+2p)(H+2p)(W+2p) (p = 1 for 3x3x3 / 1x1x1 layers, 2 for 5x5x5) plus G guard positions of zeros on both sides.  The contraction index of a weight gradient is
 // (position, sample); blocking it by 8 SAMPLES (not 8 positions) means any spatial tap shift keeps the 8-blocks
 // intact, so dW[tap] = sum_k dY[k] * A[k + off(tap)] is the plain GEMM with the B pointer moved by off(tap).
 //
@@ -16,8 +16,8 @@
 // up: source grid is (D/2,H/2,W/2) and is nearest-upsampled; stuff: source grid is (D/2..) placed at odd fine
 // positions (2o+1), zeros elsewhere (dgrad/wgrad of the stride-2 Downsample conv).
 __global__ void md_to_pb16_kernel(const void* __restrict__ src, uint16_t* __restrict__ out, int B, int C, int Cs, int D,
-                                  int H, int W, int guard, int mode, int up, int stuff) {
-  const int Dp = D + 2, Hp = H + 2, Wp = W + 2;
+                                  int H, int W, int guard, int mode, int up, int stuff, int pad) {
+  const int Dp = D + 2 * pad, Hp = H + 2 * pad, Wp = W + 2 * pad;
   const int64_t Pp = (int64_t)Dp * Hp * Wp;
   const int bg_n = (B + 7) / 8;   // a partial last block of 8 samples is zero filled
   const int64_t total = Pp * bg_n * C;  // one thread = one (pos, bgroup, c): 8 samples, hi + lo
@@ -27,7 +27,7 @@ __global__ void md_to_pb16_kernel(const void* __restrict__ src, uint16_t* __rest
     const int c = (int)(i % C);
     const int bg = (int)((i / C) % bg_n);
     const int64_t pp = i / ((int64_t)C * bg_n);
-    const int px = (int)(pp % Wp) - 1, py = (int)((pp / Wp) % Hp) - 1, pz = (int)(pp / ((int64_t)Wp * Hp)) - 1;
+    const int px = (int)(pp % Wp) - pad, py = (int)((pp / Wp) % Hp) - pad, pz = (int)(pp / ((int64_t)Wp * Hp)) - pad;
     uint32_t hi[8] = {0, 0, 0, 0, 0, 0, 0, 0}, lo[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     bool inb = (px >= 0) & (px < W) & (py >= 0) & (py < H) & (pz >= 0) & (pz < D) & (c < Cs);
     int sx = px, sy = py, sz = pz;
@@ -55,20 +55,20 @@ __global__ void md_to_pb16_kernel(const void* __restrict__ src, uint16_t* __rest
   }
 }
 
-extern "C" int64_t md_pb16_bytes(int32_t batch, int32_t C, int32_t D, int32_t H, int32_t W, int32_t guard) {
-  if (batch <= 0 || C <= 0 || D <= 0 || H <= 0 || W <= 0 || guard < 0) return MD_ERR_BAD_ARG;
-  return ((int64_t)(D + 2) * (H + 2) * (W + 2) + 2 * (int64_t)guard) * ((batch + 7) / 8) * 2 * C * 8 * 2;
+extern "C" int64_t md_pb16_bytes(int32_t batch, int32_t C, int32_t D, int32_t H, int32_t W, int32_t guard, int32_t pad) {
+  if (batch <= 0 || C <= 0 || D <= 0 || H <= 0 || W <= 0 || guard < 0 || pad < 1 || pad > 2) return MD_ERR_BAD_ARG;
+  return ((int64_t)(D + 2 * pad) * (H + 2 * pad) * (W + 2 * pad) + 2 * (int64_t)guard) * ((batch + 7) / 8) * 2 * C * 8 * 2;
 }
 
 extern "C" int md_to_pb16(const void* src, void* out, int32_t batch, int32_t C, int32_t c_src, int32_t D, int32_t H,
-                          int32_t W, int32_t guard, int32_t mode, int32_t up, int32_t stuff, void* stream) {
-  if (!src || !out || md_pb16_bytes(batch, C, D, H, W, guard) < 0 || (C % 8) || (c_src % 8) || c_src <= 0 || c_src > C ||
+                          int32_t W, int32_t guard, int32_t pad, int32_t mode, int32_t up, int32_t stuff, void* stream) {
+  if (!src || !out || md_pb16_bytes(batch, C, D, H, W, guard, pad) < 0 || (C % 8) || (c_src % 8) || c_src <= 0 || c_src > C ||
       mode < 0 || mode > 1)
     return MD_ERR_BAD_ARG;
   if ((up || stuff) && ((D | H | W) & 1)) return MD_ERR_BAD_ARG;
   // the kernel writes every position of the padded grid (zeros on the halo); only the two guards need clearing
   const int64_t pos_bytes = (int64_t)((batch + 7) / 8) * 2 * C * 8 * 2;
-  const int64_t Pp = (int64_t)(D + 2) * (H + 2) * (W + 2);
+  const int64_t Pp = (int64_t)(D + 2 * pad) * (H + 2 * pad) * (W + 2 * pad);
   if (guard > 0) {
     hipError_t e = hipMemsetAsync(out, 0, (size_t)(guard * pos_bytes), (hipStream_t)stream);
     if (e == hipSuccess)
@@ -80,7 +80,7 @@ extern "C" int md_to_pb16(const void* src, void* out, int32_t batch, int32_t C, 
   if (blocks > 8192) blocks = 8192;
   MD_HIP_CLEAR_ERROR();
   hipLaunchKernelGGL(md_to_pb16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, (uint16_t*)out,
-                     batch, C, c_src, D, H, W, guard, mode, up, stuff);
+                     batch, C, c_src, D, H, W, guard, mode, up, stuff, pad);
   MD_HIP_CHECK_LAUNCH();
   return MD_OK;
 }

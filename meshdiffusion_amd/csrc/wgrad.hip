@@ -33,7 +33,9 @@ struct WgArgs {
   int co_tiles, ci_tiles, ngroups, ksplit;
   int rows, cols;        // valid co / ci (waves whose whole sub-tile lies outside skip their MFMAs)
   int bgn;               // B / 8
-  int S;                 // grid edge; the padded edge is S + 2
+  int S;                 // grid edge; the padded edge is S + 2 pad
+  int pad;               // halo of the PB16 grids: 1 (3x3x3, 1x1x1) or 2 (5x5x5)
+  int ksz;               // 1, 3 or 5
   int spr;               // stages per grid row = ceil(S / 8)
   int debug;             // tools/bench_wgrad.py ablations: 1 = no global loads in the loop, 2 = no MFMAs (results invalid)
 };
@@ -59,7 +61,10 @@ struct WgCursor {
       }
     }
   }
-  __device__ int64_t p0(int S) const { return ((int64_t)(z + 1) * (S + 2) + (y + 1)) * (S + 2) + 1 + seg * WG_STAGE; }
+  __device__ int64_t p0(int S, int pad) const {
+    const int sp = S + 2 * pad;
+    return ((int64_t)(z + pad) * sp + (y + pad)) * sp + pad + seg * WG_STAGE;
+  }
 };
 
 // FULL: every wave's 64 x 32 sub-tile lies inside rows x cols, so the MFMA section carries no predication at all
@@ -82,12 +87,19 @@ __global__ __launch_bounds__(WG_THREADS) void md_wgrad_kernel(const WgArgs g) {
   const int grp = u % g.ngroups;
   const int tci = (u / g.ngroups) % g.ci_tiles, tco = u / (g.ngroups * g.ci_tiles);
   const int co0 = tco * WG_TILE, ci0 = tci * WG_TILE;
-  const int S = g.S, sp = S + 2;
+  const int S = g.S, sp = S + 2 * g.pad;
   const int total = g.bgn * S * S * g.spr;
   const int per = (total + g.ksplit - 1) / g.ksplit;
   const int st0 = min(total, r * per), st1 = min(total, st0 + per);
   int64_t off = 0;
-  if (NTAP == 3) off = ((int64_t)(grp / 3 - 1) * sp + (grp % 3 - 1)) * sp - 1;   // window starts at dx = -1
+  if (NTAP == 3) {
+    if (g.ksz == 3) {          // group = (dz, dy); the window starts at dx = -1
+      off = ((int64_t)(grp / 3 - 1) * sp + (grp % 3 - 1)) * sp - 1;
+    } else {                   // 5x5x5: group = ((dz, dy), h); window h covers dx = -2 + 3h .. -2 + 3h + 2 (dx = +3 is discarded)
+      const int zy = grp >> 1, h = grp & 1;
+      off = ((int64_t)(zy / 5 - 2) * sp + (zy % 5 - 2)) * sp - 2 + 3 * h;
+    }
+  }
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 2, wc = wave & 3, half = lane >> 5, l31 = lane & 31;
@@ -110,7 +122,7 @@ __global__ __launch_bounds__(WG_THREADS) void md_wgrad_kernel(const WgArgs g) {
   WgCursor cur;
   cur.init(st0, S, g.spr);
   auto fetch = [&]() {   // the stage `cur` points at
-    const int64_t p0 = cur.p0(S);
+    const int64_t p0 = cur.p0(S, g.pad);
     const int valid = min(WG_STAGE, S - cur.seg * WG_STAGE);
     const uint16_t* pa = g.dy + (p0 + fpos) * a_pos + ((int64_t)(cur.bg * 2 + fpl) * g.a_ch + co0 + frow) * 8;
     const uint16_t* pb = g.act + (p0 + off + fpos) * b_pos + ((int64_t)(cur.bg * 2 + fpl) * g.b_ch + ci0 + frow) * 8;
@@ -216,16 +228,23 @@ __global__ __launch_bounds__(WG_THREADS) void md_wgrad_kernel(const WgArgs g) {
     }
 }
 
-// dw[row*s_row + col*s_k + tap*s_tap] += sum_r partial[r][grp][t][row][col], tap = grp*NTAP + t
+// dw[row*s_row + col*s_k + tap*s_tap] += sum_r partial[r][slot][row][col]; slot = grp * NTAP + t maps to
+//   ksz 1: tap 0;  ksz 3: tap = slot;  ksz 5: grp = (dz*5+dy)*2 + h, dx = 3h + t (dx = 5 does not exist: skipped)
 __global__ void md_wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int rows, int cols, int RT,
-                                       int CT, int ntaps, int ksplit, int64_t s_row, int64_t s_k, int64_t s_tap) {
-  const int64_t total = (int64_t)ntaps * rows * cols;
-  const int64_t slab = (int64_t)ntaps * RT * CT;
+                                       int CT, int nslots, int ksz, int ksplit, int64_t s_row, int64_t s_k, int64_t s_tap) {
+  const int64_t total = (int64_t)nslots * rows * cols;
+  const int64_t slab = (int64_t)nslots * RT * CT;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int col = (int)(i % cols);
     const int row = (int)((i / cols) % rows);
-    const int tap = (int)(i / ((int64_t)cols * rows));
-    const float* p = partial + ((int64_t)tap * RT + row) * CT + col;
+    const int slot = (int)(i / ((int64_t)cols * rows));
+    int tap = slot;
+    if (ksz == 5) {
+      const int grp = slot / 3, t = slot - grp * 3, dx = 3 * (grp & 1) + t;
+      if (dx >= 5) continue;
+      tap = (grp >> 1) * 5 + dx;
+    }
+    const float* p = partial + ((int64_t)slot * RT + row) * CT + col;
     float s = 0.f;
     for (int r = 0; r < ksplit; ++r) s += p[r * slab];
     dw[row * s_row + col * s_k + tap * s_tap] += s;
@@ -237,10 +256,12 @@ __global__ void md_wgrad_reduce_kernel(const float* __restrict__ partial, float*
 static int md_wgrad_debug = 0;
 extern "C" void md_wgrad_set_debug(int32_t flags) { md_wgrad_debug = flags; }
 
+static int md_wgrad_slots(int taps) { return taps == 1 ? 1 : (taps == 27 ? 27 : (taps == 125 ? 150 : -1)); }
+
 extern "C" int64_t md_wgrad_workspace_bytes(int32_t rows, int32_t cols, int32_t taps, int32_t ksplit) {
-  if (rows <= 0 || cols <= 0 || (taps != 27 && taps != 1) || ksplit <= 0) return MD_ERR_BAD_ARG;
+  if (rows <= 0 || cols <= 0 || md_wgrad_slots(taps) < 0 || ksplit <= 0) return MD_ERR_BAD_ARG;
   const int64_t RT = (rows + WG_TILE - 1) / WG_TILE * WG_TILE, CT = (cols + WG_TILE - 1) / WG_TILE * WG_TILE;
-  return (int64_t)ksplit * taps * RT * CT * 4;
+  return (int64_t)ksplit * md_wgrad_slots(taps) * RT * CT * 4;
 }
 
 extern "C" int md_wgrad(const void* dy_pb, const void* act_pb, float* dw, void* workspace, int64_t workspace_bytes,
@@ -249,11 +270,12 @@ extern "C" int md_wgrad(const void* dy_pb, const void* act_pb, float* dw, void* 
                         void* stream) {
   if (!dy_pb || !act_pb || !dw || !workspace || batch <= 0 || a_ch <= 0 || b_ch <= 0 || (a_ch % 8) ||
       (b_ch % 8) || rows <= 0 || rows > a_ch || cols <= 0 || cols > b_ch || D <= 0 || H != D || W != D ||
-      (taps != 27 && taps != 1) || ksplit <= 0)
+      md_wgrad_slots(taps) < 0 || ksplit <= 0)
     return MD_ERR_BAD_ARG;
-  const int sp = D + 2;
+  const int pad = taps == 125 ? 2 : 1;
+  const int sp = D + 2 * pad;
   // a stage may run up to 7 positions past the end of its row (masked dY, but the A window is read): stay in the guard
-  if (guard < sp * sp + sp + 1 + WG_STAGE) return MD_ERR_BAD_ARG;
+  if (guard < pad * (sp * sp + sp + 1) + WG_STAGE + 2) return MD_ERR_BAD_ARG;
   if (workspace_bytes < md_wgrad_workspace_bytes(rows, cols, taps, ksplit)) return MD_ERR_BAD_ARG;
   WgArgs g;
   g.bgn = (batch + 7) / 8;
@@ -262,7 +284,9 @@ extern "C" int md_wgrad(const void* dy_pb, const void* act_pb, float* dw, void* 
   g.act = (const uint16_t*)act_pb + (int64_t)guard * g.bgn * 2 * b_ch * 8;
   g.partial = (float*)workspace;
   g.co_tiles = (rows + WG_TILE - 1) / WG_TILE; g.ci_tiles = (cols + WG_TILE - 1) / WG_TILE;
-  g.ngroups = taps == 27 ? 9 : 1;
+  g.ngroups = taps == 27 ? 9 : (taps == 125 ? 50 : 1);
+  g.pad = pad;
+  g.ksz = taps == 27 ? 3 : (taps == 125 ? 5 : 1);
   g.ksplit = ksplit;
   g.rows = rows; g.cols = cols;
   g.S = D;
@@ -274,16 +298,17 @@ extern "C" int md_wgrad(const void* dy_pb, const void* act_pb, float* dw, void* 
   MD_HIP_CLEAR_ERROR();
   const bool full = (rows % 64) == 0 && (cols % 32) == 0;
   const dim3 grid((unsigned)blocks), blk(WG_THREADS);
-  if (taps == 27 && full) hipLaunchKernelGGL((md_wgrad_kernel<3, true>), grid, blk, 0, (hipStream_t)stream, g);
-  else if (taps == 27) hipLaunchKernelGGL((md_wgrad_kernel<3, false>), grid, blk, 0, (hipStream_t)stream, g);
+  if (taps != 1 && full) hipLaunchKernelGGL((md_wgrad_kernel<3, true>), grid, blk, 0, (hipStream_t)stream, g);
+  else if (taps != 1) hipLaunchKernelGGL((md_wgrad_kernel<3, false>), grid, blk, 0, (hipStream_t)stream, g);
   else if (full) hipLaunchKernelGGL((md_wgrad_kernel<1, true>), grid, blk, 0, (hipStream_t)stream, g);
   else hipLaunchKernelGGL((md_wgrad_kernel<1, false>), grid, blk, 0, (hipStream_t)stream, g);
   MD_HIP_CHECK_LAUNCH();
-  const int64_t total = (int64_t)taps * rows * cols;
+  const int nslots = md_wgrad_slots(taps);
+  const int64_t total = (int64_t)nslots * rows * cols;
   int rb = (int)((total + 255) / 256);
   if (rb > 4096) rb = 4096;
   hipLaunchKernelGGL(md_wgrad_reduce_kernel, dim3((unsigned)rb), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, dw,
-                     rows, cols, g.co_tiles * WG_TILE, g.ci_tiles * WG_TILE, taps, ksplit, s_row, s_k, s_tap);
+                     rows, cols, g.co_tiles * WG_TILE, g.ci_tiles * WG_TILE, nslots, g.ksz, ksplit, s_row, s_k, s_tap);
   MD_HIP_CHECK_LAUNCH();
   return MD_OK;
 }

@@ -7,7 +7,7 @@ backward (models/backward.py), the global grad-norm and the fused clip + Adam + 
 works because the U-Net and the loss are each one opaque autograd node whose backward is the HIP code; the
 reference's `optimize_fn` (torch.optim.Adam + clip_grad_norm_) can then be used unchanged, or `FusedAdamEMA`.
 Dropout (ResnetBlockDDPM, p = config.model.dropout) runs inside the GroupNorm+SiLU kernel from a counter-based
-mask that the backward regenerates.  Current limit: ddpm_res64 only (any per-GPU batch; the wgrad blocks samples by 8).
+mask that the backward regenerates.  Both architectures and any per-GPU batch (the wgrad blocks samples by 8: a partial block is zero-filled).
 """
 import ctypes as C
 

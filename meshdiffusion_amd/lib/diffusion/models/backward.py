@@ -18,7 +18,7 @@ from .... import _lib
 from .... import hip_ops as ops
 from ....hip_ops import _ptr, _stream, check
 
-GUARD_EXTRA = 8
+GUARD_EXTRA = 12
 WGRAD_BLOCKS = 256     # one 512-thread wgrad workgroup per CU
 
 
@@ -36,35 +36,37 @@ def split_f32b(t, B, C, P, fp16=False):
 # ---------------------------------------------------------------------------------------------------------
 # PB16 operands and the wgrad GEMM
 # ---------------------------------------------------------------------------------------------------------
-def _guard(S):
-    g = (S + 2) * (S + 2) + (S + 2) + 1 + GUARD_EXTRA
+def _guard(S, pad=1):
+    sp = S + 2 * pad
+    g = pad * (sp * sp + sp + 1) + GUARD_EXTRA
     return ((g + 3) // 4) * 4
 
 
-def to_pb16(src, B, C, S, mode, up=0, stuff=0, c_src=None):
+def to_pb16(src, B, C, S, mode, up=0, stuff=0, c_src=None, pad=1):
     """src: F32B (mode 0) or S16B (mode 1) on an S^3 grid (or (S/2)^3 when up/stuff) -> PB16 on the padded S^3 grid.
-    c_src: channels actually present in `src` (the PB16 tensor is zero for channels c_src..C-1)."""
+    c_src: channels actually present in `src` (the PB16 tensor is zero for channels c_src..C-1).
+    pad: halo of the padded grid = kernel size // 2 of the conv whose wgrad consumes it (1 for NIN)."""
     lib = _lib.load()
-    g = _guard(S)
-    nbytes = lib.md_pb16_bytes(B, C, S, S, S, g)
+    g = _guard(S, pad)
+    nbytes = lib.md_pb16_bytes(B, C, S, S, S, g, pad)
     if nbytes <= 0:
         raise _lib.MeshDiffusionHipError("md_pb16_bytes failed")
     out = torch.empty(nbytes // 2 + 4 * 2 * C * 8 * ((B + 7) // 8), dtype=torch.bfloat16, device=src.device)
     out[nbytes // 2:].zero_()      # tail so that K rounded up to 4 positions stays in bounds
-    check(lib.md_to_pb16(_ptr(src), _ptr(out), B, C, C if c_src is None else c_src, S, S, S, g, mode, up, stuff,
+    check(lib.md_to_pb16(_ptr(src), _ptr(out), B, C, C if c_src is None else c_src, S, S, S, g, pad, mode, up, stuff,
                          _stream()), "md_to_pb16")
     return out
 
 
 def wgrad(dy_pb, act_pb, B, co, ci, S, taps, dw, s_row, s_k, s_tap, a_ch=None, b_ch=None):
-    """dw[co*s_row + ci*s_k + tap*s_tap] += sum_{pos,b} dy[co][pos,b] * act[ci][pos + off(tap), b]  (taps = 27 or 1)
+    """dw[co*s_row + ci*s_k + tap*s_tap] += sum_{pos,b} dy[co][pos,b] * act[ci][pos + off(tap), b]  (taps = 125, 27 or 1)
     -- md_wgrad (csrc/wgrad.hip).  a_ch / b_ch: channel counts of the two PB16 tensors when they exceed co / ci."""
     lib = _lib.load()
-    g = _guard(S)
+    g = _guard(S, 2 if taps == 125 else 1)
     a_ch = co if a_ch is None else a_ch
     b_ch = ci if b_ch is None else b_ch
     stages = ((B + 7) // 8) * S * S * ((S + 7) // 8)
-    units = ((co + 127) // 128) * ((ci + 127) // 128) * (9 if taps == 27 else 1)
+    units = ((co + 127) // 128) * ((ci + 127) // 128) * {125: 50, 27: 9, 1: 1}[taps]
     ksplit = max(1, min(WGRAD_BLOCKS // units, stages // 4))
     nbytes = lib.md_wgrad_workspace_bytes(co, ci, taps, ksplit)
     ws = torch.empty(nbytes // 4, dtype=torch.float32, device=dy_pb.device)
@@ -146,10 +148,13 @@ def dgrad_weight(layer, name, conv, cfg):
 
 def conv3_backward(layer, name, conv, dy, act_s16, B, S_out, ups=0, stride=1, need_dx=True, act_channels=None,
                    bias_sums=None):
-    """Backward of y = conv3x3x3(act) (+bias).  dy: F32B [B][co][S_out^3]; act_s16: S16B input operand of the
-    forward (coarse grid when ups, fine grid 2*S_out when stride 2).  Returns dx (F32B) or None."""
+    """Backward of y = conv k^3 (act) (+bias), k = 3 (any layer) or 5 (stem / head of ddpm_res128, stride 1).
+    dy: F32B [B][co][S_out^3]; act_s16: S16B input operand of the forward (coarse grid when ups, fine grid 2*S_out
+    when stride 2).  Returns dx (F32B) or None."""
     from . import layers
-    co, ci = conv.weight.shape[0], conv.weight.shape[1]
+    co, ci, ksz = conv.weight.shape[0], conv.weight.shape[1], conv.weight.shape[-1]
+    taps, pad = ksz ** 3, ksz // 2
+    assert ksz == 3 or (ksz == 5 and stride == 1 and not ups)
     P = S_out ** 3
     dev = dy.device
     co_t = dy.shape[1] * 8            # channels of the dy tensor (co rounded up to 8)
@@ -162,10 +167,10 @@ def conv3_backward(layer, name, conv, dy, act_s16, B, S_out, ups=0, stride=1, ne
     if stride == 2:
         dy_pb = to_pb16(dy, B, co_t, S_fine, 0, stuff=1)
     else:
-        dy_pb = to_pb16(dy, B, co_t, S_out, 0)
+        dy_pb = to_pb16(dy, B, co_t, S_out, 0, pad=pad)
     c_src = act_channels if act_channels is not None else ci      # channels of the S16B operand tensor
-    act_pb = to_pb16(act_s16, B, c_src, S_fine, 1, up=ups)
-    wgrad(dy_pb, act_pb, B, co, ci, S_fine, 27, _grad_of(conv.weight), ci * 27, 27, 1, a_ch=co_t, b_ch=c_src)
+    act_pb = to_pb16(act_s16, B, c_src, S_fine, 1, up=ups, pad=pad)
+    wgrad(dy_pb, act_pb, B, co, ci, S_fine, taps, _grad_of(conv.weight), ci * taps, taps, 1, a_ch=co_t, b_ch=c_src)
     del dy_pb, act_pb
     if not need_dx:
         return None
@@ -176,16 +181,20 @@ def conv3_backward(layer, name, conv, dy, act_s16, B, S_out, ups=0, stride=1, ne
         pw = dgrad_weight(layer, name, conv, cfg)
         return layers.run_conv3(pw, split_f32b(dyz, B, co_t, S_fine ** 3), B, S_fine)
     cfg = ops.conv_cfg_for(S_out)
-    if cfg == ops.CFG_C3_128_FAST and co % 32 != 0:
-        cfg = ops.CFG_C3_128_K16 if co <= 16 else cfg
+    k16 = ops.CFG_C3_128_K16 if ksz == 3 else ops.CFG_C5_128_K16
+    if ksz == 5:
+        assert co <= 16, "5x5x5 data gradients are only needed for the 4-channel head"
+        cfg = k16
+    elif cfg == ops.CFG_C3_128_FAST and co % 32 != 0:
+        cfg = k16 if co <= 16 else cfg
     pw = dgrad_weight(layer, name, conv, cfg)
     dyc = dy
     co_k = co
-    if cfg == ops.CFG_C3_128_K16:          # head: dy has 4 (padded to 8) channels -> K padded to 16
+    if cfg == k16:                         # head: dy has 4 (padded to 8) channels -> K padded to 16
         dy16 = torch.zeros((B, 2, P, 8), dtype=torch.float32, device=dev)
         dy16[:, :dy.shape[1]] = dy
         dyc, co_k = dy16, 16
-    dx = layers.run_conv3(pw, split_f32b(dyc, B, co_k if cfg == ops.CFG_C3_128_K16 else co_t, P), B, S_out)
+    dx = layers.run_conv3(pw, split_f32b(dyc, B, co_k if cfg == k16 else co_t, P), B, S_out)
     if ups:
         dx = resample(dx, B, ci, S_out // 2, 0)
     return dx

@@ -142,7 +142,7 @@ class DDPMUNet3D(layers.HipLayer):
 
         return self._cached("film", ps, build)
 
-    # ---- training (first correct version; KSIZE 3 / bf16x3) --------------
+    # ---- training (bf16x3 operands; both architectures) --------------
     def _autograd_anchor(self):
         a = self.__dict__.get("_md_anchor")
         if a is None or a.device != self.mask.device:
@@ -152,8 +152,6 @@ class DDPMUNet3D(layers.HipLayer):
 
     def forward_train(self, x, labels):
         """Forward pass that records what `backward` needs.  Returns (eps_hat NCDHW, ctx)."""
-        if self.KSIZE != 3:
-            raise NotImplementedError("training of ddpm_res128 (5x5x5 stem/head) is not implemented yet")
         ops.set_precision("bf16x3")
         mods = self.all_modules
         B, R = x.shape[0], self.img_size
@@ -163,8 +161,7 @@ class DDPMUNet3D(layers.HipLayer):
         t1 = ops.linear(emb, mods[0].weight, mods[0].bias); i += 1
         temb = ops.linear(t1, mods[1].weight, mods[1].bias, silu_in=True); i += 1
         stem = mods[i]; i += 1
-        x64 = ops.ncdhw_to_s16b(x if self.centered else 2 * x - 1.0, 64)
-        x16 = x64[:, :2].contiguous()
+        x16 = ops.ncdhw_to_s16b(x if self.centered else 2 * x - 1.0, 16)
         pw = layers.conv3_packed(self, "stem", stem, self._stem_cfg())
         h = layers.run_conv3(pw, x16, B, R, bias=stem.bias, residual=self._stem_const(), res_bstride=0)
         fw, fb, foffs, ftot = self._film_table()
@@ -235,7 +232,7 @@ class DDPMUNet3D(layers.HipLayer):
         out = torch.empty((B, self.out_channels, R, R, R), dtype=torch.float32, device=x.device)
         pwh = layers.conv3_packed(self, "head", head, self._head_cfg())
         layers.run_conv3(pwh, a, B, R, bias=head.bias, out=out, out_mode=ops.OUT_NCDHW, rows_alloc=8)
-        ctx = dict(B=B, R=R, P=P, emb=emb, t1=t1, temb=temb, x64=x64, v0=v0, last=v, acts=acts, tape=tape, gn_prm=prm,
+        ctx = dict(B=B, R=R, P=P, emb=emb, t1=t1, temb=temb, x16=x16, v0=v0, last=v, acts=acts, tape=tape, gn_prm=prm,
                    a_final=a, foffs=foffs, ftot=ftot, fw=fw)
         return out, ctx
 
@@ -278,13 +275,13 @@ class DDPMUNet3D(layers.HipLayer):
         # stem: h0 = conv(x) + pos_layer(coords) + mask_layer(mask) (+ biases)
         g0 = grads.pop(ctx["v0"])
         stem = mods[2]
-        bw.conv3_backward(self, "stem", stem, g0, ctx["x64"], B, R, need_dx=False, act_channels=64)
-        # (each conv3_backward call also adds sum(g0) to its conv's bias: all three biases get the same sum)
-        m64 = ops.ncdhw_to_s16b(self.mask.detach().expand(B, -1, -1, -1, -1).contiguous(), 64)
-        bw.conv3_backward(self, "mask_layer", self.mask_layer, g0, m64, B, R, need_dx=False, act_channels=64)
+        bsum = bw.channel_sums(g0, B, self.nf, P)     # all three biases receive the same sum of g0
+        bw.conv3_backward(self, "stem", stem, g0, ctx["x16"], B, R, need_dx=False, act_channels=16, bias_sums=bsum)
+        m8 = ops.ncdhw_to_s16b(self.mask.detach().expand(B, -1, -1, -1, -1).contiguous(), 8)
+        bw.conv3_backward(self, "mask_layer", self.mask_layer, g0, m8, B, R, need_dx=False, act_channels=8, bias_sums=bsum)
         if self.USE_COORDS:
-            c64 = ops.ncdhw_to_s16b(self.coords.detach().expand(B, -1, -1, -1, -1).contiguous(), 64)
-            bw.conv3_backward(self, "pos_layer", self.pos_layer, g0, c64, B, R, need_dx=False, act_channels=64)
+            c8 = ops.ncdhw_to_s16b(self.coords.detach().expand(B, -1, -1, -1, -1).contiguous(), 8)
+            bw.conv3_backward(self, "pos_layer", self.pos_layer, g0, c8, B, R, need_dx=False, act_channels=8, bias_sums=bsum)
         del g0
         # FiLM table + timestep MLP (tiny [B,512] algebra: torch ops on the device)
         temb, t1, emb = ctx["temb"], ctx["t1"], ctx["emb"]

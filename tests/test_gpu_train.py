@@ -88,20 +88,24 @@ def test_eval_step_fn_matches_oracle_loss(hip_lib):
     assert abs(loss - ref) / abs(ref) < 1e-4
 
 
-def test_whole_unet_backward_and_train_step_vs_oracle_autograd(hip_lib):
+@pytest.mark.parametrize("arch,B", [("ddpm_res64", 8), ("ddpm_res128", 8), ("ddpm_res128", 1), ("ddpm_res64", 3)])
+def test_whole_unet_backward_and_train_step_vs_oracle_autograd(hip_lib, arch, B):
     """get_step_fn(train=True) on the HIP path (forward, loss, backward, reference optimize_fn) vs the same step
-    computed with torch autograd through the oracle on the CPU: every parameter gradient and the updated weights."""
+    computed with torch autograd through the oracle on the CPU: every parameter gradient and the updated weights.
+    ddpm_res128: 5x5x5 stem / mask_layer / head, no coords, 2 blocks at level 0; B = 1 is its per-GPU batch in the
+    reference config (8 over 8 GPUs), B = 3: a batch that is not a multiple of the 8-sample wgrad block."""
     import copy
     from meshdiffusion_amd import synth
     from meshdiffusion_amd.lib.diffusion import losses, sde_lib
-    from meshdiffusion_amd.lib.diffusion.models import ddpm_res64, utils as mutils  # noqa: F401
+    from meshdiffusion_amd.lib.diffusion.models import ddpm_res64, ddpm_res128, utils as mutils  # noqa: F401
     from meshdiffusion_amd.lib.diffusion.models.ema import ExponentialMovingAverage
     from oracle import unet_oracle as uo
-    cfg = synth.small_config(); cfg.device = torch.device("cuda")
+    cfg = synth.small_config() if arch == "ddpm_res64" else synth.small_config_res128()
+    cfg.device = torch.device("cuda")
     cfg.optim.warmup = 2
     cfg.optim.grad_clip = -1.0        # keep p.grad unscaled so it can be compared with autograd's gradient
     model = mutils.create_model(cfg)
-    R, B = cfg.data.image_size, 8
+    R = cfg.data.image_size
     sd = synth.sensitised_state_dict(model.module.state_dict(), seed=1234, grid_mask=synth.synthetic_grid_mask(R))
     model.module.load_state_dict(sd, strict=True)
     params = [p for p in model.parameters()]

@@ -16,9 +16,9 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from meshdiffusion_amd import synth  # noqa: E402
-from meshdiffusion_amd.config import get_config_res64  # noqa: E402
+from meshdiffusion_amd.config import get_config_res64, get_config_res128  # noqa: E402
 from meshdiffusion_amd.lib.diffusion import losses, parallel, sde_lib  # noqa: E402
-from meshdiffusion_amd.lib.diffusion.models import ddpm_res64, utils as mutils  # noqa: F401,E402
+from meshdiffusion_amd.lib.diffusion.models import ddpm_res64, ddpm_res128, utils as mutils  # noqa: F401,E402
 
 
 def main():
@@ -27,11 +27,15 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--small", action="store_true", help="small U-Net (CI-sized)")
+    ap.add_argument("--arch", default="res64", choices=["res64", "res128"])
     a = ap.parse_args()
     rank, world, local = parallel.init_distributed()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    cfg = synth.small_config() if a.small else get_config_res64()
+    if a.arch == "res128":
+        cfg = synth.small_config_res128() if a.small else get_config_res128()
+    else:
+        cfg = synth.small_config() if a.small else get_config_res64()
     cfg.device = dev
     R = cfg.data.image_size
     model = mutils.create_model(cfg)
@@ -82,11 +86,11 @@ def main():
         torch.distributed.all_reduce(wt, op=torch.distributed.ReduceOp.MAX)
     if rank == 0:
         w = float(wt)
-        print(json.dumps({"metric": "res64 training step (fwd+bwd+Adam/EMA), samples/s", "value": round(world * a.batch * a.steps / w, 3),
+        print(json.dumps({"metric": f"{a.arch} training step (fwd+bwd+Adam/EMA), samples/s", "value": round(world * a.batch * a.steps / w, 3),
                           "n_gpus": world, "batch_per_gpu": a.batch, "steps": a.steps, "s_per_step": round(w / a.steps, 3),
                           "losses": [round(v, 5) for v in ls], "peak_hbm_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
                           "last_step_split_ms": {k: round(v, 1) for k, v in split.items()}, "dropout": cfg.model.dropout,
-                          "model": "small" if a.small else "ddpm_res64"}))
+                          "model": ("small " if a.small else "") + cfg.model.name}))
     if world > 1:
         torch.distributed.destroy_process_group()
 
