@@ -117,10 +117,20 @@ def get_step_fn(sde, train, optimize_fn=None, mask=None, loss_type="l2"):
             if clear_grad:
                 optimizer.zero_grad()
             loss = loss_fn(model, batch)
-            loss.backward()
+            # one process per GPU: the replicas' gradients meet here.  On the step that updates the parameters the
+            # U-Net backward announces finished layers to the reducer, whose bucket all-reduces overlap the rest of
+            # the backward (no-op for a single process).
+            reducer = parallel.GradReducer() if update_param else None
+            net = getattr(model, "module", model)
+            if reducer is not None and reducer.active:
+                net._grad_ready_hook = reducer.ready
+            try:
+                loss.backward()
+            finally:
+                if hasattr(net, "_grad_ready_hook"):
+                    del net._grad_ready_hook
             if update_param:
-                # one process per GPU: the replicas' gradients meet here (no-op for a single process)
-                parallel.allreduce_param_grads_(model.parameters())
+                reducer.finish(model.parameters())
                 optimize_fn(optimizer, model.parameters(), step=state["step"])
             state["step"] += 1
             state["ema"].update(model.parameters())

@@ -261,6 +261,18 @@ class DDPMUNet3D(layers.HipLayer):
         acc(ctx["last"], bw.gn_backward([(hl, c)], d_a, ctx["gn_prm"], gn, B, p, silu=True)[0])
         del d_a
         d_film = torch.zeros((B, ctx["ftot"]), dtype=torch.float32, device=dev)
+        hook = self.__dict__.get("_grad_ready_hook")     # parallel.GradReducer.ready during multi-GPU training
+
+        def announce(layer):
+            # gradients that are final once this layer's backward ran (Dense_0 / Conv_0.bias of a ResnetBlock
+            # are completed by the FiLM algebra at the end)
+            if hook is not None:
+                late = {id(layer.Dense_0.weight), id(layer.Dense_0.bias), id(layer.Conv_0.bias)} \
+                    if isinstance(layer, ResnetBlockDDPM) else set()
+                hook([p for p in layer.parameters() if id(p) not in late])
+
+        if hook is not None:
+            hook(list(gn.parameters()) + list(head.parameters()))
         for kind, layer, sv, ins, out in reversed(tape):
             g = grads.pop(out)
             if kind == "res":
@@ -272,6 +284,7 @@ class DDPMUNet3D(layers.HipLayer):
             else:
                 acc(ins[0], layer.backward_blocked(sv, g))
             del g
+            announce(layer)
         # stem: h0 = conv(x) + pos_layer(coords) + mask_layer(mask) (+ biases)
         g0 = grads.pop(ctx["v0"])
         stem = mods[2]

@@ -108,8 +108,21 @@ def _replica_worker(rank, world, port, q):
     x, y = torch.randn((8, 6), generator=g), torch.randn((8, 3), generator=g)
     sl = slice(rank * 4, rank * 4 + 4)
     ((net(x[sl]) - y[sl]) ** 2).mean().backward()
+    local = [p.grad.clone() for p in net.parameters()]
     parallel.allreduce_param_grads_(net.parameters(), cap_bytes=64)
-    q.put((rank, start, [p.grad.clone() for p in net.parameters()]))
+    reduced = [p.grad.clone() for p in net.parameters()]
+    # the overlapped reducer used by the training step: layers announced in backward order, late parameters
+    # (here: the first layer's bias) only known at finish()
+    for p, g in zip(net.parameters(), local):
+        p.grad.copy_(g)
+    red = parallel.GradReducer(cap_bytes=64)
+    assert red.active
+    red.ready(list(net[2].parameters()))
+    red.ready([net[0].weight])
+    red.finish(net.parameters())
+    for p, g in zip(net.parameters(), reduced):
+        assert torch.allclose(p.grad, g, atol=1e-7)
+    q.put((rank, start, reduced))
     dist.barrier()
     dist.destroy_process_group()
 
