@@ -67,8 +67,15 @@ def time_steps(model, cfg, B, R, steps, warm, cond=False):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-res128", action="store_true")
+    ap.add_argument("--only-res128", action="store_true", help="config #4 only (profiling)")
     a = ap.parse_args()
     res = {}
+    if a.only_res128:
+        cfg = get_config_res128()
+        model = build(cfg, 128, 99)
+        s, peak = time_steps(model, cfg, 2, 128, 2, 1)
+        print(json.dumps({"config4_res128_b2": {"ms_per_step": round(s * 1e3, 1), "peak_hbm_gib": round(peak, 1)}}))
+        return
     cfg = get_config_res64()
     model = build(cfg, 64, 1234)
     s, _ = time_steps(model, cfg, 1, 64, 10, 2)
