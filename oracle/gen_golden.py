@@ -10,6 +10,7 @@ outputs are stored):
   unet_res64.npz     reference DDPMRes64 (res64, B=1) eps_hat: ::4 subsample + statistics
   sampler_small.npz  unmodified reference pc_sampler, first K iterations, uncond + inpainting
   sampler_res64.npz  BASELINE config #1: res64, B=1, first 10 of 1000 ancestral steps
+  train_grads.npz    reference loss function (train mode): loss + per-parameter gradient norms / samples
   dataset.npz        reference ShapeNetDMTetDataset items (augmentation on/off) for seeded on-disk grids
   dmtet.npz          reference DMTet.__call__ on the shipped 64-grid: counts, hashes, samples
   64_tets_cropped.npz  the tet-grid DATA asset (vertices/indices), copied verbatim
@@ -288,6 +289,74 @@ def gen_dmtet():
     np.savez_compressed(os.path.join(GOLD, "dmtet.npz"), **out)
 
 
+def train_step_inputs(B, R, seed):
+    """Seeded (batch, labels, noise) of one DDPM training step; the GPU test regenerates them and feeds the same
+    tensors to the HIP loss function by patching torch.randint / torch.randn_like exactly as done here."""
+    g = torch.Generator().manual_seed(seed)
+    mask = synth.synthetic_grid_mask(R).view(1, 1, R, R, R)
+    batch = synth.synthetic_inputs(B, 4, R, seed=seed + 1) * mask
+    labels = torch.randint(0, 1000, (B,), generator=g)
+    noise = torch.randn((B, 4, R, R, R), generator=g)
+    return batch, labels, noise, mask
+
+
+class fixed_draws:
+    """Make `torch.randint` / `torch.randn_like` return the given tensors once each (the loss function's draws,
+    lib/diffusion/losses.py:59,62), then restore them."""
+
+    def __init__(self, labels, noise):
+        self.labels, self.noise = labels, noise
+
+    def __enter__(self):
+        self.ri, self.rl = torch.randint, torch.randn_like
+        torch.randint = lambda *a, **k: self.labels.to(k.get("device", "cpu"))
+        torch.randn_like = lambda t, *a, **k: self.noise.to(t.device)
+        return self
+
+    def __exit__(self, *exc):
+        torch.randint, torch.randn_like = self.ri, self.rl
+
+
+def gen_train(full):
+    """Loss and parameter gradients of the UNMODIFIED reference loss function (lib/diffusion/losses.py:54-85, train
+    mode, dropout 0) for the small res64/res128 configs and -- `full` -- the real res64 network at B=1.
+    Stored per parameter: gradient norm and a strided sample of <= 256 entries."""
+    rsampling, rsde, rmutils = import_reference()
+    from lib.diffusion import losses as rlosses
+    cases = [("small_res64", synth.small_config(), 8, 1234), ("small_res128", synth.small_config_res128(), 8, 4321)]
+    if full:
+        from meshdiffusion_amd.config import get_config_res64
+        cases.append(("res64", get_config_res64(), 1, 1234))
+    out = {}
+    for name, cfg, B, sd_seed in cases:
+        cfg.device = torch.device("cpu")
+        cfg.model.dropout = 0.0
+        R = cfg.data.image_size
+        sd = make_sd(cfg, R, seed=sd_seed)
+        model = ref_model(rmutils, cfg, sd)
+        batch, labels, noise, mask = train_step_inputs(B, R, seed=2024)
+        sde = rsde.VPSDE(beta_min=cfg.model.beta_min, beta_max=cfg.model.beta_max, N=cfg.model.num_scales)
+        loss_fn = rlosses.get_ddpm_loss_fn(sde, train=True, mask=mask)
+        t0 = time.time()
+        with fixed_draws(labels, noise):
+            loss = loss_fn(model, batch)
+        loss.backward()
+        print(f"[train {name}] reference loss {float(loss):.6f}  ({time.time() - t0:.1f} s)")
+        out[f"{name}_loss"] = np.float64(float(loss))
+        out[f"{name}_B"], out[f"{name}_sd_seed"] = np.int64(B), np.int64(sd_seed)
+        gsq = 0.0
+        for n, p in model.named_parameters():
+            if p.grad is None:
+                continue
+            g = p.grad.detach().flatten()
+            stride = max(1, g.numel() // 256)
+            out[f"{name}/{n}/norm"] = np.float64(float(g.double().norm()))
+            out[f"{name}/{n}/sample"] = g[::stride][:256].numpy().copy()
+            gsq += float(g.double().square().sum())
+        out[f"{name}_gnorm"] = np.float64(gsq ** 0.5)
+    np.savez_compressed(os.path.join(GOLD, "train_grads.npz"), **out)
+
+
 def dataset_inputs(tmp, R=8):
     """Three seeded grids on disk (two at r=R, one smaller than the model grid), a path list and an id
     filter, in the reference's on-disk format (data/tets_to_3dgrid.py:49).  Shared with the CPU test."""
@@ -329,7 +398,7 @@ def gen_dataset():
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-res64", action="store_true")
-    ap.add_argument("--only", choices=["unet", "dmtet", "dataset"], default=None)
+    ap.add_argument("--only", choices=["unet", "dmtet", "dataset", "train"], default=None)
     a = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(os.cpu_count())
@@ -337,6 +406,8 @@ if __name__ == "__main__":
         gen_dmtet()
     if a.only in (None, "dataset"):
         gen_dataset()
+    if a.only in (None, "train"):
+        gen_train(full=not a.skip_res64)
     if a.only in (None, "unet"):
         gen_unet_and_sampler(a.skip_res64)
     print("golden fixtures written to", GOLD)

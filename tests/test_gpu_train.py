@@ -148,3 +148,57 @@ def test_whole_unet_backward_and_train_step_vs_oracle_autograd(hip_lib, arch, B)
     # the optimizer really stepped (reference optimize_fn: warm-up lr 2e-5 * 1/2, Adam) and the EMA moved
     moved = [n for n, p in model.module.named_parameters() if p.requires_grad and not torch.equal(p.detach().cpu(), w_before[n])]
     assert len(moved) == len(grads) and state["step"] == 2 and ema.num_updates == 1
+
+
+@pytest.mark.parametrize("case", ["small_res64", "small_res128", "res64"])
+def test_loss_and_gradients_vs_reference_golden(hip_lib, case):
+    """The UNMODIFIED reference loss function run on the CPU by oracle/gen_golden.py (train mode, dropout 0, fixed
+    labels/noise) pins loss and every parameter gradient of the HIP path -- `res64` is the real 364 M-parameter
+    network at B = 1 (the autograd reference takes 40 s on the build host; here only its recorded norms/samples)."""
+    import os
+    from conftest import GOLD
+    from oracle.gen_golden import fixed_draws, train_step_inputs
+    from meshdiffusion_amd import synth
+    from meshdiffusion_amd.config import get_config_res64
+    from meshdiffusion_amd.lib.diffusion import losses, sde_lib
+    from meshdiffusion_amd.lib.diffusion.models import ddpm_res64, ddpm_res128, utils as mutils  # noqa: F401
+    gold = np.load(os.path.join(GOLD, "train_grads.npz"))
+    cfg = {"small_res64": synth.small_config, "small_res128": synth.small_config_res128, "res64": get_config_res64}[case]()
+    cfg.device = torch.device("cuda")
+    cfg.model.dropout = 0.0
+    R, B = cfg.data.image_size, int(gold[f"{case}_B"])
+    model = mutils.create_model(cfg)
+    sd = synth.sensitised_state_dict(model.module.state_dict(), seed=int(gold[f"{case}_sd_seed"]),
+                                     grid_mask=synth.synthetic_grid_mask(R))
+    model.module.load_state_dict(sd, strict=True)
+    del sd
+    batch, labels, noise, mask = train_step_inputs(B, R, seed=2024)
+    sde = sde_lib.VPSDE(cfg.model.beta_min, cfg.model.beta_max, cfg.model.num_scales, device="cuda")
+    loss_fn = losses.get_ddpm_loss_fn(sde, train=True, mask=mask.cuda())
+    with fixed_draws(labels.cuda(), noise.cuda()):
+        loss = loss_fn(model, batch.cuda())
+    loss.backward()
+    ref_loss = float(gold[f"{case}_loss"])
+    assert abs(float(loss.detach()) - ref_loss) / ref_loss < 2e-5
+    gnorm = float(gold[f"{case}_gnorm"])
+    worst, n_checked, sq = ("", 0.0), 0, 0.0
+    for n, p in model.module.named_parameters():
+        key = f"{case}/{n}/norm"
+        if key not in gold.files:
+            assert p.grad is None or not p.requires_grad, n
+            continue
+        g = p.grad.detach().flatten()
+        sq += float(g.double().square().sum())
+        stride = max(1, g.numel() // 256)
+        smp, ref = g[::stride][:256].cpu().double(), torch.from_numpy(gold[f"{case}/{n}/sample"]).double()
+        rn = float(gold[key])
+        assert abs(float(g.double().norm()) - rn) <= 2e-3 * rn + 1e-5 * gnorm, n
+        # sampled entries: error measured against the RMS entry of this tensor (and the global norm for tiny tensors)
+        scale = max(rn / g.numel() ** 0.5, 1e-4 * gnorm / g.numel() ** 0.5)
+        err = float((smp - ref).abs().max()) / scale
+        if err > worst[1]:
+            worst = (n, err)
+        n_checked += 1
+    print(f"{case}: {n_checked} tensors, worst sampled-entry error / RMS entry = {worst}")
+    assert n_checked > 100 and worst[1] < 2e-3
+    assert abs(sq ** 0.5 - gnorm) / gnorm < 1e-4
