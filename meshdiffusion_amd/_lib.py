@@ -38,6 +38,7 @@ class MdGemmConvArgs(C.Structure):
     ]
 
 
+ABI_VERSION = 2      # MD_ABI_VERSION of include/meshdiffusion_hip.h this host code was written against
 _P, _I32, _I64, _F, _U64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint64
 
 # name -> (restype, argtypes); exactly the entry points of include/meshdiffusion_hip.h
@@ -113,8 +114,8 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.md_abi_version() != 2:
-        raise MeshDiffusionHipError("ABI version mismatch")
+    if lib.md_abi_version() != ABI_VERSION:
+        raise MeshDiffusionHipError(f"ABI version mismatch: library {lib.md_abi_version()}, host code {ABI_VERSION}")
     for cfg, (nt, kc) in CFG_NT_KC.items():
         v = [C.c_int32() for _ in range(6)]
         lib.md_gemm_conv_cfg_info(cfg, *[C.byref(x) for x in v])

@@ -76,7 +76,8 @@ __global__ void md_gn_finalize_kernel(const double* __restrict__ sums, const flo
   }
 }
 
-// out: S16B [B][c_total/8][2][P][8]
+// out: S16B [B][c_total/8][2][P][8].  One thread = one position x 8 channels: two 16-byte loads (32 contiguous bytes),
+// one 16-byte store per output plane, so every store instruction of a wave covers 1 KiB of consecutive positions.
 __global__ __launch_bounds__(GN_BLOCK) void md_gn_apply_kernel(const float* __restrict__ x,
                                                                const float* __restrict__ params,
                                                                uint16_t* __restrict__ out,
@@ -85,14 +86,14 @@ __global__ __launch_bounds__(GN_BLOCK) void md_gn_apply_kernel(const float* __re
                                                                int norm, int silu, uint32_t thr16,
                                                                float drop_scale, uint64_t seed) {
   const int cg = blockIdx.y, b = blockIdx.z;
-  const int tid = threadIdx.x, half = tid & 1;
+  const int tid = threadIdx.x;
   const int64_t p0 = (int64_t)blockIdx.x * GN_CHUNK;
   const f32x4* xp = (const f32x4*)(x + (((int64_t)b * (C / 8) + cg) * P) * 8);
-  float mean[4], a[4], bt[4];
+  float mean[8], a[8], bt[8];
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
+  for (int e = 0; e < 8; ++e) {
     if (norm) {
-      const f32x4 pr = *(const f32x4*)(params + ((int64_t)b * c_total + c_off + cg * 8 + half * 4 + e) * 4);
+      const f32x4 pr = *(const f32x4*)(params + ((int64_t)b * c_total + c_off + cg * 8 + e) * 4);
       mean[e] = pr[0]; a[e] = pr[1]; bt[e] = pr[2];
     } else {
       mean[e] = 0.f; a[e] = 1.f; bt[e] = 0.f;
@@ -101,35 +102,39 @@ __global__ __launch_bounds__(GN_BLOCK) void md_gn_apply_kernel(const float* __re
   const int64_t plane = P * 8;
   uint16_t* ohi = out + (((int64_t)b * (c_total / 8) + (c_off / 8) + cg) * 2) * plane;
   uint16_t* rhi = out_raw ? out_raw + (((int64_t)b * (c_total / 8) + (c_off / 8) + cg) * 2) * plane : nullptr;
+  const uint64_t quad0 = (uint64_t)(((int64_t)b * c_total + c_off + cg * 8) >> 2) * (uint64_t)P;   // dropout quad index base
 #pragma unroll
-  for (int i = 0; i < GN_ITEMS; ++i) {
-    const int64_t pos = p0 + ((tid + i * GN_BLOCK) >> 1);
+  for (int i = 0; i < GN_ITEMS / 2; ++i) {
+    const int64_t pos = p0 + tid + i * GN_BLOCK;
     if (pos < P) {
-      const f32x4 v = xp[pos * 2 + half];
-      uint32_t hi[4], lo[4];
-      uint64_t bits = 0;
-      if (thr16) bits = md_drop_bits(seed, (uint64_t)(((int64_t)b * c_total + c_off + cg * 8 + half * 4) >> 2) * (uint64_t)P + (uint64_t)pos);
+      const f32x4 v0 = xp[pos * 2], v1 = xp[pos * 2 + 1];
+      float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+      uint32_t hi[8], lo[8];
       if (rhi) {  // second output: bf16 split of the raw input (operand of the NIN shortcut), same read
 #pragma unroll
-        for (int e = 0; e < 4; ++e) md_split(v[e], hi[e], lo[e]);
-        const int64_t o = pos * 8 + half * 4;
-        *(uint2*)(rhi + o) = make_uint2(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16));
-        *(uint2*)(rhi + plane + o) = make_uint2(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16));
+        for (int e = 0; e < 8; ++e) md_split(v[e], hi[e], lo[e]);
+        *(uint4*)(rhi + pos * 8) = make_uint4(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16), hi[4] | (hi[5] << 16), hi[6] | (hi[7] << 16));
+        *(uint4*)(rhi + plane + pos * 8) = make_uint4(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16), lo[4] | (lo[5] << 16), lo[6] | (lo[7] << 16));
+      }
+      uint64_t bits[2] = {0, 0};
+      if (thr16) {
+        bits[0] = md_drop_bits(seed, quad0 + (uint64_t)pos);
+        bits[1] = md_drop_bits(seed, quad0 + (uint64_t)P + (uint64_t)pos);
       }
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
+      for (int e = 0; e < 8; ++e) {
         float y = v[e];
         if (norm) y = (y - mean[e]) * a[e] + bt[e];
         if (silu & 1) y = md_silu(y);
-        if (thr16) y = md_drop_keep(bits, e, thr16) ? y * drop_scale : 0.f;   // nn.Dropout (layers.py:682)
+        if (thr16) y = md_drop_keep(bits[e >> 2], e & 3, thr16) ? y * drop_scale : 0.f;   // nn.Dropout (layers.py:682)
         // experiment hook (tools/longrun_parity.py --act-fp16): round the operand to fp16 first, which is
         // what a weights-split-only fp16 scheme (2 MFMAs per product) would feed the matrix cores
         if (silu & 2) y = __half2float(__float2half_rn(y));
         if (silu & 4) { hi[e] = md_f2h(y); lo[e] = 0; } else md_split(y, hi[e], lo[e]);
       }
-      const int64_t o = pos * 8 + half * 4;
-      *(uint2*)(ohi + o) = make_uint2(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16));
-      if (!(silu & 4)) *(uint2*)(ohi + plane + o) = make_uint2(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16));
+      *(uint4*)(ohi + pos * 8) = make_uint4(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16), hi[4] | (hi[5] << 16), hi[6] | (hi[7] << 16));
+      if (!(silu & 4))
+        *(uint4*)(ohi + plane + pos * 8) = make_uint4(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16), lo[4] | (lo[5] << 16), lo[6] | (lo[7] << 16));
     }
   }
 }

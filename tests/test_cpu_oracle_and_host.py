@@ -105,7 +105,9 @@ def test_c_abi_exports_every_declared_symbol(hip_lib):
     raw = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared:
         assert hasattr(raw, name), name
-    assert hip_lib.md_abi_version() == 2
+    assert hip_lib.md_abi_version() == _lib.ABI_VERSION
+    m = re.search(r"#define MD_ABI_VERSION (\d+)", header)
+    assert m and int(m.group(1)) == _lib.ABI_VERSION
     info = _lib.cfg_info(_lib.CFG_C3_128)
     assert info["taps"] == 27 and info["lds_bytes"] <= 160 * 1024 and info["threads"] == 512
     nm = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
@@ -275,3 +277,11 @@ def test_rank_shard_sampler_partitions_every_epoch():
         if epoch == 0:
             first = flat
     assert flat != first
+
+
+def test_graft_entry_build_runs_without_a_gpu():
+    """The driver's build check: compiles every HIP source for gfx950, loads the library, imports the host package."""
+    sys.path.insert(0, ROOT)
+    import __graft_entry__
+    path = __graft_entry__.build()
+    assert os.path.exists(path) and path.endswith("libmeshdiffusion_hip.so")
