@@ -38,7 +38,7 @@ extern "C" {
 #define MD_ERR_UNSUPPORTED (-2)
 #define MD_ERR_NO_DEVICE (-3)
 
-#define MD_ABI_VERSION 2
+#define MD_ABI_VERSION 3
 
 /* ---- tile configurations of md_gemm_conv (compile-time instantiations) ---- */
 enum {
@@ -108,6 +108,10 @@ typedef struct MdGemmConvArgs {
   float* partial;        /* ksplit>1: fp32 workspace [ksplit][B][rows_alloc/8][P][8]            */
   int32_t ksplit;        /* split the K-chunk loop over this many workgroups (grid.z); 0/1 = off */
   int32_t prec;          /* MD_PREC_*: operand format of A (weights) and B (activations)        */
+  double* stats;         /* optional [B][rows_alloc][2]: per-(sample, output channel) sum and sum of   */
+                         /* squares of the values written to `out`, ADDED with fp64 atomics (caller    */
+                         /* zeroes) -- the GroupNorm statistics of the consumer without another pass   */
+                         /* over the tensor.  MD_CFG_C3_128_FAST, F32B output, no split-K; else error  */
 } MdGemmConvArgs;
 
 int md_abi_version(void);

@@ -35,10 +35,11 @@ class MdGemmConvArgs(C.Structure):
         ("H", C.c_int32), ("W", C.c_int32), ("ups", C.c_int32), ("a_src", C.c_int32),
         ("out_mode", C.c_int32), ("a_rows", C.c_int32), ("a_bstride", C.c_int64),
         ("bias_bstride", C.c_int64), ("res_bstride", C.c_int64), ("b_bstride", C.c_int64), ("partial", C.c_void_p), ("ksplit", C.c_int32), ("prec", C.c_int32),
+        ("stats", C.c_void_p),
     ]
 
 
-ABI_VERSION = 2      # MD_ABI_VERSION of include/meshdiffusion_hip.h this host code was written against
+ABI_VERSION = 3      # MD_ABI_VERSION of include/meshdiffusion_hip.h this host code was written against
 _P, _I32, _I64, _F, _U64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint64
 
 # name -> (restype, argtypes); exactly the entry points of include/meshdiffusion_hip.h

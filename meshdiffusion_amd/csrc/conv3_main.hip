@@ -296,6 +296,14 @@ __global__ __launch_bounds__(NTHREADS) void md_conv3_main_kernel(const MdGemmCon
       }
       bv[rm][q] = v;
     }
+  const bool want_stats = A.stats != nullptr && !partial;
+  float st1[2][4][4], st2[2][4][4];   // per lane: sum / sum of squares of its 32 output channels over its 2 positions
+#pragma unroll
+  for (int rm = 0; rm < 2; ++rm)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { st1[rm][q][e] = 0.f; st2[rm][q][e] = 0.f; }
 #pragma unroll
   for (int cm = 0; cm < 2; ++cm) {
     const int y = cm * 4 + (j >> 3), x = j & 7;
@@ -324,9 +332,50 @@ __global__ __launch_bounds__(NTHREADS) void md_conv3_main_kernel(const MdGemmCon
           v += bv[rm][q][e];
           v += rv[rm][q][e];
           o4[e] = v;
+          st1[rm][q][e] += v;
+          st2[rm][q][e] += v * v;
         }
         *(f32x4*)(outp + ((int64_t)(row >> 3) * P + gp) * 8 + (row & 7)) = o4;
       }
+  }
+  // ---- optional: GroupNorm statistics of the tensor just written (consumer skips its md_gn_stats pass) ----------
+  if (want_stats) {   // workgroup-uniform
+    // lanes with equal h hold the same 32 channels at 32 different positions: butterfly over j, then the 4 wc waves
+    // of a row half meet in LDS (free: every wave is past its last fragment read after the barrier)
+#pragma unroll
+    for (int rm = 0; rm < 2; ++rm)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int o = 16; o > 0; o >>= 1) {
+            st1[rm][q][e] += __shfl_xor(st1[rm][q][e], o, 64);
+            st2[rm][q][e] += __shfl_xor(st2[rm][q][e], o, 64);
+          }
+    __syncthreads();
+    float* red = (float*)lds;   // [8 waves][64 channels][2]
+    if (j == 0) {
+#pragma unroll
+      for (int rm = 0; rm < 2; ++rm)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int ch = rm * 32 + 8 * q + 4 * h + e;
+            red[(wid * 64 + ch) * 2] = st1[rm][q][e];
+            red[(wid * 64 + ch) * 2 + 1] = st2[rm][q][e];
+          }
+    }
+    __syncthreads();
+    if (tid < 256) {
+      const int ch = tid >> 1, which = tid & 1;          // channel within the 128-row tile
+      const int w0 = (ch >> 6) * 4, c64 = ch & 63;
+      const float sum = (red[((w0 + 0) * 64 + c64) * 2 + which] + red[((w0 + 1) * 64 + c64) * 2 + which]) +
+                        (red[((w0 + 2) * 64 + c64) * 2 + which] + red[((w0 + 3) * 64 + c64) * 2 + which]);
+      const int row = rt * NT + ch;
+      if (row < rows_alloc) atomicAdd(A.stats + ((int64_t)b * rows_alloc + row) * 2 + which, (double)sum);
+    }
   }
 }
 
@@ -338,6 +387,7 @@ int md_launch_conv3_main(const MdGemmConvArgs& a, hipStream_t stream) {
   if (a.D % TZ || a.H % TY || a.W % TX) return MD_ERR_BAD_ARG;
   if (a.ups && ((a.D | a.H | a.W) & 1)) return MD_ERR_BAD_ARG;
   if (a.a_src != MD_A_PACKED || a.out_mode != MD_OUT_F32B) return MD_ERR_UNSUPPORTED;
+  if (a.stats != nullptr && a.ksplit > 1) return MD_ERR_UNSUPPORTED;
   const int tiles = (a.D / TZ) * (a.H / TY) * (a.W / TX);
   const int ks = a.ksplit > 1 ? a.ksplit : 1;
   if (ks > 1 && (a.partial == nullptr || ks > a.kdim / KC)) return MD_ERR_BAD_ARG;

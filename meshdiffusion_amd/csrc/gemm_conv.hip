@@ -678,6 +678,7 @@ extern "C" int md_gemm_conv(const MdGemmConvArgs* args, void* stream) {
   int rc = MD_OK;
   hipStream_t st = (hipStream_t)stream;
   if (args->cfg == MD_CFG_C3_128_FAST || (args->cfg >= 111 && args->cfg <= 118)) return md_launch_conv3_main(*args, st);
+  if (args->stats != nullptr) return MD_ERR_UNSUPPORTED;   // epilogue statistics: dedicated 3x3x3 kernel only
   MD_CFG_SWITCH(args->cfg, rc = launch_cfg, *args, st);
   return rc;
 }

@@ -115,7 +115,9 @@ def pack_s16b_from_matrix(w_kp, device):
 # ---------------------------------------------------------------------------------------------
 def gemm_conv(*, cfg, a, b, out, batch, rows, rows_alloc, kdim, dims, bias=None, bias_bstride=0,
               residual=None, res_bstride=0, alpha=1.0, ups=0, a_src=A_PACKED, a_rows=0, a_bstride=0,
-              b_bstride=None, out_mode=OUT_F32B, ksplit=1, prec=PREC_BF16X3):
+              b_bstride=None, out_mode=OUT_F32B, ksplit=1, prec=PREC_BF16X3, stats=None):
+    """stats: optional zeroed float64 [batch][rows_alloc][2] receiving per-(sample, channel) sum / sum of squares of
+    the output (CFG_C3_128_FAST without split-K only)."""
     lib = _lib.load()
     D, H, W = dims
     args = MdGemmConvArgs()
@@ -136,6 +138,7 @@ def gemm_conv(*, cfg, a, b, out, batch, rows, rows_alloc, kdim, dims, bias=None,
         b_bstride = (kdim // 8) * 2 * pin * 8
     args.b_bstride = b_bstride
     args.prec = prec
+    args.stats = stats.data_ptr() if stats is not None else None
     part = None
     if ksplit > 1:
         if out_mode != OUT_F32B:
@@ -162,17 +165,29 @@ def gemm_conv(*, cfg, a, b, out, batch, rows, rows_alloc, kdim, dims, bias=None,
 # ---------------------------------------------------------------------------------------------
 # GroupNorm (+SiLU) + split, with concatenated sources
 # ---------------------------------------------------------------------------------------------
+FUSE_GN_STATS = True     # take GroupNorm sums from the producing conv's epilogue when it recorded them (A/B switch)
+
+
 def gn_params(parts, gamma, beta, B, P, eps=1e-6, groups=32):
-    """parts: list of (F32B tensor, C).  Returns the float4 params tensor [B][Ctot][4]."""
+    """parts: list of (F32B tensor, C).  Returns the float4 params tensor [B][Ctot][4].
+    A part whose producer attached `_md_sums` (layers.run_conv3(want_stats=True)) is not read again."""
     lib = _lib.load()
     dev = parts[0][0].device
     ctot = sum(c for _, c in parts)
-    sums = torch.empty((B, ctot, 2), dtype=torch.float64, device=dev)
-    check(lib.md_zero(_ptr(sums), sums.numel() * 8, _stream()), "md_zero")
-    off = 0
-    for t, c in parts:
-        check(lib.md_gn_stats(_ptr(t), _ptr(sums), B, c, P, ctot, off, _stream()), "md_gn_stats")
-        off += c
+    cached = [getattr(t, "_md_sums", None) if FUSE_GN_STATS else None for t, _ in parts]
+    if len(parts) == 1 and cached[0] is not None:
+        sums = cached[0]           # the producing conv already accumulated them in its epilogue
+    else:
+        sums = torch.empty((B, ctot, 2), dtype=torch.float64, device=dev)
+        if any(c is None for c in cached):
+            check(lib.md_zero(_ptr(sums), sums.numel() * 8, _stream()), "md_zero")
+        off = 0
+        for (t, c), cs in zip(parts, cached):
+            if cs is not None:
+                sums[:, off:off + c] = cs
+            else:
+                check(lib.md_gn_stats(_ptr(t), _ptr(sums), B, c, P, ctot, off, _stream()), "md_gn_stats")
+            off += c
     params = torch.empty((B, ctot, 4), dtype=torch.float32, device=dev)
     check(lib.md_gn_finalize(_ptr(sums), _ptr(gamma), _ptr(beta), _ptr(params), B, ctot, groups, P,
                              eps, _stream()), "md_gn_finalize")

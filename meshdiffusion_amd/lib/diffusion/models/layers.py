@@ -111,8 +111,10 @@ def conv3_packed(layer, name, conv, cfg):
 
 
 def run_conv3(pw, act_s16, B, S_out, *, bias=None, bias_bstride=0, residual=None, res_bstride=None, ups=0,
-              out=None, out_mode=ops.OUT_F32B, rows_alloc=None):
-    """3x3x3 conv of an S16B activation tensor with packed weights `pw` on an S_out^3 output grid."""
+              out=None, out_mode=ops.OUT_F32B, rows_alloc=None, want_stats=False):
+    """3x3x3 conv of an S16B activation tensor with packed weights `pw` on an S_out^3 output grid.
+    want_stats: the output feeds a GroupNorm -- when the launch allows it (dedicated kernel, no split-K) its
+    epilogue also accumulates the per-(sample, channel) sums, attached to the result as `_md_sums`."""
     P = S_out ** 3
     rows_alloc = rows_alloc if rows_alloc is not None else ((pw.rows + 7) // 8) * 8
     if out is None:
@@ -120,10 +122,19 @@ def run_conv3(pw, act_s16, B, S_out, *, bias=None, bias_bstride=0, residual=None
     if residual is not None and res_bstride is None:
         res_bstride = rows_alloc * P
     ksplit = ops.ksplit_for(pw.cfg, B, pw.rows, pw.kdim, S_out) if out_mode == ops.OUT_F32B else 1
-    return ops.gemm_conv(cfg=pw.cfg, a=pw.data, b=act_s16, out=out, batch=B, rows=pw.rows,
-                         rows_alloc=rows_alloc, kdim=pw.kdim, dims=(S_out, S_out, S_out), bias=bias,
-                         bias_bstride=bias_bstride, residual=residual, res_bstride=res_bstride or 0, ups=ups,
-                         out_mode=out_mode, ksplit=ksplit, prec=pw.prec)
+    stats = None
+    if (want_stats and ops.FUSE_GN_STATS and pw.cfg == ops.CFG_C3_128_FAST and ksplit == 1
+            and out_mode == ops.OUT_F32B and rows_alloc == pw.rows):
+        stats = torch.zeros((B, rows_alloc, 2), dtype=torch.float64, device=act_s16.device)
+    ops.gemm_conv(cfg=pw.cfg, a=pw.data, b=act_s16, out=out, batch=B, rows=pw.rows,
+                  rows_alloc=rows_alloc, kdim=pw.kdim, dims=(S_out, S_out, S_out), bias=bias,
+                  bias_bstride=bias_bstride, residual=residual, res_bstride=res_bstride or 0, ups=ups,
+                  out_mode=out_mode, ksplit=ksplit, prec=pw.prec, stats=stats)
+    if stats is not None:
+        out._md_sums = stats
+    elif hasattr(out, "_md_sums"):
+        del out._md_sums
+    return out
 
 
 def run_gemm(pw, act_s16, B, P, *, bias=None, bias_bstride=0, residual=None, out=None, out_mode=ops.OUT_F32B,
@@ -249,7 +260,7 @@ class Upsample(HipLayer):
         if tape is not None:
             assert pw.prec == ops.PREC_BF16X3
             tape.append(dict(layer=self, act=act, B=B, S_out=s_out))
-        return run_conv3(pw, act, B, s_out, bias=self.Conv_0.bias, ups=1)
+        return run_conv3(pw, act, B, s_out, bias=self.Conv_0.bias, ups=1, want_stats=True)
 
     def backward_blocked(self, sv, dy):
         from . import backward as bw
@@ -333,12 +344,12 @@ class ResnetBlockDDPM(HipLayer):
         if need_nin:
             a0, xs = a0
         if bias0 is not None:
-            h = run_conv3(pw0, a0, B, S, bias=bias0, bias_bstride=bias0_stride)
+            h = run_conv3(pw0, a0, B, S, bias=bias0, bias_bstride=bias0_stride, want_stats=True)
         elif temb is not None:   # per-(sample, channel) additive bias = Conv_0.b + Dense_0(SiLU(temb))
             bias0 = ops.linear(temb, self.Dense_0.weight, self._bias0(), silu_in=True)
-            h = run_conv3(pw0, a0, B, S, bias=bias0, bias_bstride=self.out_ch)
+            h = run_conv3(pw0, a0, B, S, bias=bias0, bias_bstride=self.out_ch, want_stats=True)
         else:
-            h = run_conv3(pw0, a0, B, S, bias=self.Conv_0.bias)
+            h = run_conv3(pw0, a0, B, S, bias=self.Conv_0.bias, want_stats=True)
         prm1 = ops.gn_params([(h, self.out_ch)], g1.weight, g1.bias, B, P, eps=g1.eps, groups=g1.num_groups)
         a1 = ops.gn_apply([(h, self.out_ch)], prm1, B, P, norm=True, silu=True, fp16=f16, drop=drop)
         if need_nin:
@@ -350,7 +361,7 @@ class ResnetBlockDDPM(HipLayer):
             assert not f16, "the backward pass uses the bf16x3 operand format"
             tape.append(dict(layer=self, parts=parts, prm0=prm, a0=a0, h=h, prm1=prm1, a1=a1, xs=xs, B=B, P=P, S=S,
                              temb=temb, drop=drop))
-        return run_conv3(pw1, a1, B, S, bias=self.Conv_1.bias, residual=res)
+        return run_conv3(pw1, a1, B, S, bias=self.Conv_1.bias, residual=res, want_stats=True)
 
     def backward_blocked(self, sv, dy):
         """dy: F32B [B][out_ch][P].  Returns ([grad per input part], dbias0 [B, out_ch]); accumulates .grad of

@@ -282,3 +282,45 @@ def test_inpaint_blend_and_renoise(ops):
     upd = coef[:, 0, None, None, None] * ref[:, 0] + coef[:, 1, None, None, None] * z
     ref2 = ref.clone(); ref2[:, 0] = (ref[:, 0] * (1 - pm) + upd * pm) * gm
     assert rel_l2(xg.cpu(), ref2) < 1e-6 and torch.equal(xm[:, 0].cpu(), xg[:, 0].cpu())
+
+
+def test_conv_epilogue_groupnorm_statistics(hip_lib):
+    """MdGemmConvArgs.stats: the dedicated 3x3x3 kernel adds per-(sample, channel) sum / sum of squares of what it
+    writes (after bias + residual) -- must equal md_gn_stats over the written tensor, and a GroupNorm fed from the
+    attached sums must equal one fed from a fresh statistics pass (hip_ops.FUSE_GN_STATS A/B)."""
+    from meshdiffusion_amd import hip_ops as ops
+    from meshdiffusion_amd.lib.diffusion.models import layers
+    B, Ci, Co, S = 8, 64, 256, 16          # 16 tiles x 8 samples x 2 row tiles = 256 workgroups: no split-K
+    g = torch.Generator().manual_seed(0)
+    conv = layers.ddpm_conv3x3(Ci, Co).cuda()
+    conv.weight.data = (torch.rand(conv.weight.shape, generator=g) - 0.5).cuda() * 0.1
+    conv.bias.data = torch.randn(Co, generator=g).cuda()
+    x = torch.randn((B, Ci, S, S, S), generator=g).cuda()
+    res = ops.ncdhw_to_f32b(torch.randn((B, Co, S, S, S), generator=g).cuda())
+    pw = ops.PackedWeight(conv.weight, "conv", ops.CFG_C3_128_FAST, x.device)
+    a = ops.ncdhw_to_s16b(x, Ci)
+    y = layers.run_conv3(pw, a, B, S, bias=conv.bias, residual=res, want_stats=True)
+    sums = y._md_sums
+    yn = ops.f32b_to_ncdhw(y, (S, S, S)).double()
+    ref = torch.stack([yn.sum(dim=(2, 3, 4)), (yn * yn).sum(dim=(2, 3, 4))], dim=-1)
+    assert torch.allclose(sums, ref, rtol=1e-5, atol=1e-3)
+    gn = torch.nn.GroupNorm(32, Co, eps=1e-6).cuda()
+    gn.weight.data, gn.bias.data = torch.randn(Co, generator=g).cuda(), torch.randn(Co, generator=g).cuda()
+    P = S ** 3
+    p_fused = ops.gn_params([(y, Co)], gn.weight, gn.bias, B, P)
+    ops.FUSE_GN_STATS = False
+    try:
+        p_plain = ops.gn_params([(y, Co)], gn.weight, gn.bias, B, P)
+    finally:
+        ops.FUSE_GN_STATS = True
+    assert rel_l2(p_fused.cpu(), p_plain.cpu()) < 1e-6
+    # concatenated GroupNorm: one part with attached sums, one without
+    z = ops.ncdhw_to_f32b(torch.randn((B, 64, S, S, S), generator=g).cuda())
+    gn2 = torch.nn.GroupNorm(32, Co + 64, eps=1e-6).cuda()
+    p_cat = ops.gn_params([(y, Co), (z, 64)], gn2.weight, gn2.bias, B, P)
+    ops.FUSE_GN_STATS = False
+    try:
+        p_cat_plain = ops.gn_params([(y, Co), (z, 64)], gn2.weight, gn2.bias, B, P)
+    finally:
+        ops.FUSE_GN_STATS = True
+    assert rel_l2(p_cat.cpu(), p_cat_plain.cpu()) < 1e-6
