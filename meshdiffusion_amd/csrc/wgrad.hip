@@ -37,7 +37,6 @@ struct WgArgs {
   int pad;               // halo of the PB16 grids: 1 (3x3x3, 1x1x1) or 2 (5x5x5)
   int ksz;               // 1, 3 or 5
   int spr;               // stages per grid row = ceil(S / 8)
-  int debug;             // tools/bench_wgrad.py ablations: 1 = no global loads in the loop, 2 = no MFMAs (results invalid)
 };
 
 // The contraction walks the INTERIOR rows of the padded grid only (dY is zero on the halo): stage st of sample
@@ -67,9 +66,50 @@ struct WgCursor {
   }
 };
 
-// FULL: every wave's 64 x 32 sub-tile lies inside rows x cols, so the MFMA section carries no predication at all
-// (exec-mask branches between MFMA groups cost the scheduler its freedom to overlap LDS reads with the matrix pipe).
-template <int NTAP, bool FULL>
+// One half of a stage (4 of its 8 dY positions = two k-steps) for one wave.  Fragments: lanes 0-31 take position q,
+// lanes 32-63 position q + 2.  k-step k2 uses the dY pair (base, base+2), base = 4 hq + k2, and tap t pairs it with the
+// A-window pair (base + t, base + t + 2): NTAP + 1 distinct A fragments serve the 2 NTAP (k-step, tap) combinations.
+// NS = row sub-tiles this wave owns (2, or 1 when the second lies outside `rows`).
+template <int NTAP, int NS>
+__device__ __forceinline__ void wg_half(f32x16 (&acc)[2][NTAP], const uint4* sa, const uint4* sb, const int hq, const int a_idx,
+                                        const int b_idx) {
+  bf16x8 bh[NTAP + 1], bl[NTAP + 1];
+#pragma unroll
+  for (int j = 0; j < NTAP + 1; ++j) {
+    const int idx = b_idx + (hq * 4 + j) * 2 * WG_TILE;
+    bh[j] = __builtin_bit_cast(bf16x8, sb[idx]);
+    bl[j] = __builtin_bit_cast(bf16x8, sb[idx + WG_TILE]);
+  }
+#pragma unroll
+  for (int k2 = 0; k2 < 2; ++k2) {
+    bf16x8 ah[NS], al[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const int idx = a_idx + (hq * 4 + k2) * 2 * WG_TILE + s * 32;
+      ah[s] = __builtin_bit_cast(bf16x8, sa[idx]);
+      al[s] = __builtin_bit_cast(bf16x8, sa[idx + WG_TILE]);
+    }
+    // three passes over the independent (s, t) accumulators: no back-to-back dependent MFMAs
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+      for (int t = 0; t < NTAP; ++t) acc[s][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[s], bh[k2 + t], acc[s][t], 0, 0, 0);
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+      for (int t = 0; t < NTAP; ++t) acc[s][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s], bl[k2 + t], acc[s][t], 0, 0, 0);
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+      for (int t = 0; t < NTAP; ++t) acc[s][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s], bh[k2 + t], acc[s][t], 0, 0, 0);
+  }
+}
+
+// FULL: rows, cols multiples of 128 and S a multiple of 8: neither the MFMA section nor the global loads carry any
+// predication (exec-mask branches between MFMA groups cost the scheduler its freedom to overlap LDS reads and
+// memory instructions with the matrix pipe).
+// DBG (tools/bench_wgrad.py only): 1 = no global loads in the loop, 2 = no MFMAs; results are then meaningless.
+template <int NTAP, bool FULL, int DBG>
 __global__ __launch_bounds__(WG_THREADS) void md_wgrad_kernel(const WgArgs g) {
   constexpr int WIN = NTAP == 3 ? WG_STAGE + 2 : WG_STAGE;   // A positions per stage
   constexpr int B_VEC = WIN * 2 * WG_TILE;
@@ -129,13 +169,13 @@ __global__ __launch_bounds__(WG_THREADS) void md_wgrad_kernel(const WgArgs g) {
 #pragma unroll
     for (int i = 0; i < A_ITERS; ++i) {
       uint4 x = make_uint4(0, 0, 0, 0);
-      if (a_ok && fpos + 2 * i < valid) x = *(const uint4*)(pa + 2 * i * a_pos);
+      if (FULL || (a_ok && fpos + 2 * i < valid)) x = *(const uint4*)(pa + 2 * i * a_pos);
       ra[i] = x;
     }
 #pragma unroll
     for (int i = 0; i < B_ITERS; ++i) {
       uint4 x = make_uint4(0, 0, 0, 0);
-      if (b_ok) x = *(const uint4*)(pb + 2 * i * b_pos);
+      if (FULL || b_ok) x = *(const uint4*)(pb + 2 * i * b_pos);
       rb[i] = x;
     }
   };
@@ -153,64 +193,46 @@ __global__ __launch_bounds__(WG_THREADS) void md_wgrad_kernel(const WgArgs g) {
     stash(0);
   }
   __syncthreads();
-  for (int st = st0; st < st1; ++st) {
+  // wave-uniform: does this wave own any output at all / both row sub-tiles
+  const bool active = (FULL || (col_on && row_on[0])) && !(DBG & 2);
+  const bool both = FULL || row_on[1];
+  const int a_idx = (2 * half) * 2 * WG_TILE + wr * 64 + l31, b_idx = (2 * half) * 2 * WG_TILE + wc * 32 + l31;
+  int st = st0;
+  // steady state: a next stage exists.  Its operands are requested first, written to the other LDS buffer between
+  // the two halves (that buffer is free since the last barrier; the writes overlap the second half's MFMAs).
+  for (; st + 1 < st1; ++st) {
     const int buf = (st - st0) & 1;
-    if (st + 1 < st1 && !(g.debug & 1)) {
+    if (!(DBG & 1)) {
       cur.next(S, g.spr);
       fetch();
     }
+    // keep the requests up here: left alone the scheduler sinks them next to their use (the LDS writes below) to
+    // save registers, which exposes the whole memory latency
+    __builtin_amdgcn_sched_barrier(0);
     const uint4* sa = smem + buf * (WG_A_VEC + B_VEC);
     const uint4* sb = sa + WG_A_VEC;
-    if ((FULL || (col_on && row_on[0])) && !(g.debug & 2)) {
-      // Fragments: lanes 0-31 take position q, lanes 32-63 position q + 2.  k-step kk uses the dY pair
-      // (base, base+2), base = 4 (kk >> 1) + (kk & 1), so the four k-steps cover the eight positions, and tap t
-      // pairs it with the A-window pair (base + t, base + t + 2): eight distinct A fragments serve 12 (kk, t).
-#pragma unroll
-      for (int hq = 0; hq < 2; ++hq) {
-        // the next stage's operands (requested at the top of this stage) go to the other LDS buffer half way through:
-        // the buffer is free since the last barrier, and the writes overlap the second half's MFMAs
-        if (hq == 1 && st + 1 < st1) stash(buf ^ 1);
-        bf16x8 bh[NTAP + 1], bl[NTAP + 1];
-#pragma unroll
-        for (int j = 0; j < NTAP + 1; ++j) {
-          const int idx = ((hq * 4 + j + 2 * half) * 2) * WG_TILE + wc * 32 + l31;
-          bh[j] = __builtin_bit_cast(bf16x8, sb[idx]);
-          bl[j] = __builtin_bit_cast(bf16x8, sb[idx + WG_TILE]);
-        }
-#pragma unroll
-        for (int k2 = 0; k2 < 2; ++k2) {
-          bf16x8 ah[2], al[2];
-#pragma unroll
-          for (int s = 0; s < 2; ++s) {
-            const int idx = ((hq * 4 + k2 + 2 * half) * 2) * WG_TILE + wr * 64 + s * 32 + l31;
-            ah[s] = __builtin_bit_cast(bf16x8, sa[idx]);
-            al[s] = __builtin_bit_cast(bf16x8, sa[idx + WG_TILE]);
-          }
-          const int ns = (FULL || row_on[1]) ? 2 : 1;
-          // three passes over the independent (s, t) accumulators: no back-to-back dependent MFMAs
-#pragma unroll
-          for (int s = 0; s < 2; ++s)
-            if (s < ns)
-#pragma unroll
-              for (int t = 0; t < NTAP; ++t)
-                acc[s][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[s], bh[k2 + t], acc[s][t], 0, 0, 0);
-#pragma unroll
-          for (int s = 0; s < 2; ++s)
-            if (s < ns)
-#pragma unroll
-              for (int t = 0; t < NTAP; ++t)
-                acc[s][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s], bl[k2 + t], acc[s][t], 0, 0, 0);
-#pragma unroll
-          for (int s = 0; s < 2; ++s)
-            if (s < ns)
-#pragma unroll
-              for (int t = 0; t < NTAP; ++t)
-                acc[s][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s], bh[k2 + t], acc[s][t], 0, 0, 0);
-        }
-      }
+    if (active) {
+      if (both) wg_half<NTAP, 2>(acc, sa, sb, 0, a_idx, b_idx);
+      else wg_half<NTAP, 1>(acc, sa, sb, 0, a_idx, b_idx);
     }
-    else if (st + 1 < st1) stash(buf ^ 1);
+    stash(buf ^ 1);
+    if (active) {
+      if (both) wg_half<NTAP, 2>(acc, sa, sb, 1, a_idx, b_idx);
+      else wg_half<NTAP, 1>(acc, sa, sb, 1, a_idx, b_idx);
+    }
     __syncthreads();
+  }
+  if (st < st1 && active) {   // last stage: nothing left to prefetch
+    const int buf = (st - st0) & 1;
+    const uint4* sa = smem + buf * (WG_A_VEC + B_VEC);
+    const uint4* sb = sa + WG_A_VEC;
+    if (both) {
+      wg_half<NTAP, 2>(acc, sa, sb, 0, a_idx, b_idx);
+      wg_half<NTAP, 2>(acc, sa, sb, 1, a_idx, b_idx);
+    } else {
+      wg_half<NTAP, 1>(acc, sa, sb, 0, a_idx, b_idx);
+      wg_half<NTAP, 1>(acc, sa, sb, 1, a_idx, b_idx);
+    }
   }
 
   // ---- partial sums: [r][grp][t][co][ci], lane -> ci (coalesced 128 B rows) ----
@@ -291,17 +313,24 @@ extern "C" int md_wgrad(const void* dy_pb, const void* act_pb, float* dw, void* 
   g.rows = rows; g.cols = cols;
   g.S = D;
   g.spr = (D + WG_STAGE - 1) / WG_STAGE;
-  g.debug = md_wgrad_debug;
   const int units = g.co_tiles * g.ci_tiles * g.ngroups;
   const int64_t blocks = ((int64_t)ksplit * units + 255) / 256 * 256;
   if (blocks > 0x7fffffff) return MD_ERR_BAD_ARG;
   MD_HIP_CLEAR_ERROR();
-  const bool full = (rows % 64) == 0 && (cols % 32) == 0;
+  // FULL: no predication anywhere -- whole 128-channel tiles on both operands and whole 8-position stages
+  const bool full = (rows % WG_TILE) == 0 && (cols % WG_TILE) == 0 && (D % WG_STAGE) == 0;
   const dim3 grid((unsigned)blocks), blk(WG_THREADS);
-  if (taps != 1 && full) hipLaunchKernelGGL((md_wgrad_kernel<3, true>), grid, blk, 0, (hipStream_t)stream, g);
-  else if (taps != 1) hipLaunchKernelGGL((md_wgrad_kernel<3, false>), grid, blk, 0, (hipStream_t)stream, g);
-  else if (full) hipLaunchKernelGGL((md_wgrad_kernel<1, true>), grid, blk, 0, (hipStream_t)stream, g);
-  else hipLaunchKernelGGL((md_wgrad_kernel<1, false>), grid, blk, 0, (hipStream_t)stream, g);
+  const hipStream_t hs = (hipStream_t)stream;
+  if (taps != 1 && full) {
+    switch (md_wgrad_debug) {   // timing ablations exist for the dominant instantiation only
+      case 1: hipLaunchKernelGGL((md_wgrad_kernel<3, true, 1>), grid, blk, 0, hs, g); break;
+      case 2: hipLaunchKernelGGL((md_wgrad_kernel<3, true, 2>), grid, blk, 0, hs, g); break;
+      case 3: hipLaunchKernelGGL((md_wgrad_kernel<3, true, 3>), grid, blk, 0, hs, g); break;
+      default: hipLaunchKernelGGL((md_wgrad_kernel<3, true, 0>), grid, blk, 0, hs, g); break;
+    }
+  } else if (taps != 1) hipLaunchKernelGGL((md_wgrad_kernel<3, false, 0>), grid, blk, 0, hs, g);
+  else if (full) hipLaunchKernelGGL((md_wgrad_kernel<1, true, 0>), grid, blk, 0, hs, g);
+  else hipLaunchKernelGGL((md_wgrad_kernel<1, false, 0>), grid, blk, 0, hs, g);
   MD_HIP_CHECK_LAUNCH();
   const int nslots = md_wgrad_slots(taps);
   const int64_t total = (int64_t)nslots * rows * cols;
