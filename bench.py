@@ -32,7 +32,7 @@ ACT_BYTES_PER_SAMPLE_STEP = 8.21e9
 WEIGHT_BYTES_PER_STEP = 1.456e9
 PEAK_BF16_TFLOPS = 2500.0     # dense bf16 MFMA peak, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
-PMC_TRAFFIC_BYTES_PER_LAUNCH = 1.469e9   # measured: (2*FETCH_SIZE + WRITE_SIZE) KiB per md_conv3_main_kernel launch
+PMC_TRAFFIC_BYTES_PER_LAUNCH = 1.480e9   # measured: (2*FETCH_SIZE + WRITE_SIZE) KiB per md_conv3_main_kernel launch
 
 
 def parse():
