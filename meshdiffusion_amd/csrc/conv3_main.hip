@@ -296,7 +296,7 @@ __global__ __launch_bounds__(NTHREADS) void md_conv3_main_kernel(const MdGemmCon
       }
       bv[rm][q] = v;
     }
-  const bool want_stats = A.stats != nullptr && !partial;
+  const bool want_stats = (ABL == 0) && A.stats != nullptr && !partial;   // ablation builds carry no statistics code
   float st1[2][4][4], st2[2][4][4];   // per lane: sum / sum of squares of its 32 output channels over its 2 positions
 #pragma unroll
   for (int rm = 0; rm < 2; ++rm)
@@ -339,7 +339,7 @@ __global__ __launch_bounds__(NTHREADS) void md_conv3_main_kernel(const MdGemmCon
       }
   }
   // ---- optional: GroupNorm statistics of the tensor just written (consumer skips its md_gn_stats pass) ----------
-  if (want_stats) {   // workgroup-uniform
+  if constexpr (ABL == 0) if (want_stats) {   // workgroup-uniform
     // lanes with equal h hold the same 32 channels at 32 different positions: butterfly over j, then the 4 wc waves
     // of a row half meet in LDS (free: every wave is past its last fragment read after the barrier)
 #pragma unroll
@@ -399,12 +399,16 @@ int md_launch_conv3_main(const MdGemmConvArgs& a, hipStream_t stream) {
     return MD_ERR_BAD_ARG;
   } else {
     switch (a.cfg) {
+#ifdef MD_BUILD_ABLATIONS   // timing-only variants for tools/bench_conv.py: each costs ~35 s of compile time
       case 111: hipLaunchKernelGGL((md_conv3_main_kernel<1, 0>), grid, dim3(NTHREADS), 0, stream, a); break;
       case 113: hipLaunchKernelGGL((md_conv3_main_kernel<3, 0>), grid, dim3(NTHREADS), 0, stream, a); break;
       case 114: hipLaunchKernelGGL((md_conv3_main_kernel<4, 0>), grid, dim3(NTHREADS), 0, stream, a); break;
       case 116: hipLaunchKernelGGL((md_conv3_main_kernel<6, 0>), grid, dim3(NTHREADS), 0, stream, a); break;
       case 117: hipLaunchKernelGGL((md_conv3_main_kernel<7, 0>), grid, dim3(NTHREADS), 0, stream, a); break;
       case 118: hipLaunchKernelGGL((md_conv3_main_kernel<8, 0>), grid, dim3(NTHREADS), 0, stream, a); break;
+#else
+      case 111: case 113: case 114: case 116: case 117: case 118: return MD_ERR_UNSUPPORTED;   // MD_BUILD_ABLATIONS=1 python -m meshdiffusion_amd.build --force
+#endif
       default: hipLaunchKernelGGL((md_conv3_main_kernel<0, 0>), grid, dim3(NTHREADS), 0, stream, a); break;
     }
   }

@@ -2,6 +2,9 @@
 res64 shapes (HIP-event timed, interleaved rounds) + bit-equality check against the baseline cfg.
 
     python tools/bench_conv.py [--cfgs C3_128,C3_128_V2,...] [--rounds 5]
+
+The timing-only ablations of the dedicated kernel (cfgs F1/F3/F4/F6/F7/F8 = 111..118) are compiled only with
+`MD_BUILD_ABLATIONS=1 python -m meshdiffusion_amd.build --force` (they add ~4 minutes of compile time).
 """
 import argparse
 import os
