@@ -15,21 +15,30 @@
 // mode 0: src = F32B fp32 [B][C/8][P][8] (split here); mode 1: src = S16B [B][C/8][2][P][8] (planes copied)
 // up: source grid is (D/2,H/2,W/2) and is nearest-upsampled; stuff: source grid is (D/2..) placed at odd fine
 // positions (2o+1), zeros elsewhere (dgrad/wgrad of the stride-2 Downsample conv).
-__global__ void md_to_pb16_kernel(const void* __restrict__ src, uint16_t* __restrict__ out, int B, int C, int Cs, int D,
-                                  int H, int W, int guard, int mode, int up, int stuff, int pad) {
+// One thread = one (padded position, sample block, group of 8 channels): consecutive lanes take consecutive positions,
+// so each of the 8 per-sample loads of a wave covers 64 x 32 contiguous bytes of the source, and every lane writes the
+// two full 128-byte lines [8 channels][8 samples] (hi / lo plane) of its position.
+__global__ __launch_bounds__(256) void md_to_pb16_kernel(const void* __restrict__ src, uint16_t* __restrict__ out, int B, int C,
+                                                         int Cs, int D, int H, int W, int guard, int mode, int up, int stuff,
+                                                         int pad) {
   const int Dp = D + 2 * pad, Hp = H + 2 * pad, Wp = W + 2 * pad;
   const int64_t Pp = (int64_t)Dp * Hp * Wp;
   const int bg_n = (B + 7) / 8;   // a partial last block of 8 samples is zero filled
-  const int64_t total = Pp * bg_n * C;  // one thread = one (pos, bgroup, c): 8 samples, hi + lo
+  const int cg_n = C / 8;
+  const int64_t total = Pp * bg_n * cg_n;
   const int Ds = (up || stuff) ? D / 2 : D, Hs = (up || stuff) ? H / 2 : H, Ws = (up || stuff) ? W / 2 : W;
   const int64_t Ps = (int64_t)Ds * Hs * Ws;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int c = (int)(i % C);
-    const int bg = (int)((i / C) % bg_n);
-    const int64_t pp = i / ((int64_t)C * bg_n);
+    const int64_t pp = i % Pp;
+    const int cg = (int)((i / Pp) % cg_n);
+    const int bg = (int)(i / (Pp * cg_n));
     const int px = (int)(pp % Wp) - pad, py = (int)((pp / Wp) % Hp) - pad, pz = (int)(pp / ((int64_t)Wp * Hp)) - pad;
-    uint32_t hi[8] = {0, 0, 0, 0, 0, 0, 0, 0}, lo[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    bool inb = (px >= 0) & (px < W) & (py >= 0) & (py < H) & (pz >= 0) & (pz < D) & (c < Cs);
+    uint32_t hi[8][8], lo[8][8];   // [sample][channel]
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { hi[k][e] = 0; lo[k][e] = 0; }
+    bool inb = (px >= 0) & (px < W) & (py >= 0) & (py < H) & (pz >= 0) & (pz < D) & (cg * 8 < Cs);
     int sx = px, sy = py, sz = pz;
     if (up) { sx >>= 1; sy >>= 1; sz >>= 1; }
     if (stuff) { inb = inb & (px & 1) & (py & 1) & (pz & 1); sx >>= 1; sy >>= 1; sz >>= 1; }
@@ -40,18 +49,28 @@ __global__ void md_to_pb16_kernel(const void* __restrict__ src, uint16_t* __rest
         const int b = bg * 8 + k;
         if (b >= B) break;
         if (mode == 0) {
-          const float v = ((const float*)src)[(((int64_t)b * (Cs / 8) + (c >> 3)) * Ps + sp) * 8 + (c & 7)];
-          md_split(v, hi[k], lo[k]);
+          const f32x4* s4 = (const f32x4*)((const float*)src + (((int64_t)b * (Cs / 8) + cg) * Ps + sp) * 8);
+          const f32x4 v0 = s4[0], v1 = s4[1];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { md_split(v0[e], hi[k][e], lo[k][e]); md_split(v1[e], hi[k][4 + e], lo[k][4 + e]); }
         } else {
-          const uint16_t* s = (const uint16_t*)src;
-          const int64_t o = ((((int64_t)b * (Cs / 8) + (c >> 3)) * 2) * Ps + sp) * 8 + (c & 7);
-          hi[k] = s[o]; lo[k] = s[o + Ps * 8];
+          const uint16_t* s16 = (const uint16_t*)src + ((((int64_t)b * (Cs / 8) + cg) * 2) * Ps + sp) * 8;
+          const uint4 h4 = *(const uint4*)s16, l4 = *(const uint4*)(s16 + Ps * 8);
+          const uint32_t hw[4] = {h4.x, h4.y, h4.z, h4.w}, lw[4] = {l4.x, l4.y, l4.z, l4.w};
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            hi[k][e] = (hw[e >> 1] >> (16 * (e & 1))) & 0xffffu;
+            lo[k][e] = (lw[e >> 1] >> (16 * (e & 1))) & 0xffffu;
+          }
         }
       }
     }
-    uint4* o = (uint4*)(out + ((((int64_t)(guard + pp) * bg_n + bg) * 2) * C + c) * 8);
-    o[0] = make_uint4(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16), hi[4] | (hi[5] << 16), hi[6] | (hi[7] << 16));
-    o[C] = make_uint4(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16), lo[4] | (lo[5] << 16), lo[6] | (lo[7] << 16));
+    uint4* o = (uint4*)(out + ((((int64_t)(guard + pp) * bg_n + bg) * 2) * C + cg * 8) * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      o[e] = make_uint4(hi[0][e] | (hi[1][e] << 16), hi[2][e] | (hi[3][e] << 16), hi[4][e] | (hi[5][e] << 16), hi[6][e] | (hi[7][e] << 16));
+      o[C + e] = make_uint4(lo[0][e] | (lo[1][e] << 16), lo[2][e] | (lo[3][e] << 16), lo[4][e] | (lo[5][e] << 16), lo[6][e] | (lo[7][e] << 16));
+    }
   }
 }
 
@@ -75,9 +94,9 @@ extern "C" int md_to_pb16(const void* src, void* out, int32_t batch, int32_t C, 
       e = hipMemsetAsync((char*)out + (guard + Pp) * pos_bytes, 0, (size_t)(guard * pos_bytes), (hipStream_t)stream);
     if (e != hipSuccess) return (int)e;
   }
-  const int64_t total = Pp * ((batch + 7) / 8) * C;
+  const int64_t total = Pp * ((batch + 7) / 8) * (C / 8);
   int blocks = (int)((total + 255) / 256);
-  if (blocks > 8192) blocks = 8192;
+  if (blocks > 65536) blocks = 65536;
   MD_HIP_CLEAR_ERROR();
   hipLaunchKernelGGL(md_to_pb16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, (uint16_t*)out,
                      batch, C, c_src, D, H, W, guard, mode, up, stuff, pad);
