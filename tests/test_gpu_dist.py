@@ -1,0 +1,92 @@
+"""Two training replicas on ONE GPU (gloo carries the exchange; on a node each rank has its own GPU and RCCL):
+the real HIP forward/backward + start-up broadcast + overlapped bucket reducer + optimizer must leave both replicas
+with identical parameters, equal to a single process stepping on the whole batch."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+B_TOTAL = 16
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _one_step(rank, world, shard):
+    """Build the small U-Net (per-rank init seed), broadcast, run one training step on `shard` of the common batch."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle.gen_golden import fixed_draws, train_step_inputs
+    from meshdiffusion_amd import synth
+    from meshdiffusion_amd.lib.diffusion import losses, parallel, sde_lib
+    from meshdiffusion_amd.lib.diffusion.models import ddpm_res64, utils as mutils  # noqa: F401
+    from meshdiffusion_amd.lib.diffusion.models.ema import ExponentialMovingAverage
+    torch.cuda.set_device(0)
+    cfg = synth.small_config(); cfg.device = torch.device("cuda:0")
+    cfg.optim.warmup, cfg.optim.lr = 1, 1e-3
+    R = cfg.data.image_size
+    model = mutils.create_model(cfg)
+    sd = synth.sensitised_state_dict(model.module.state_dict(), seed=100 + rank, grid_mask=synth.synthetic_grid_mask(R))
+    model.module.load_state_dict(sd, strict=True)          # replicas start DIFFERENT on purpose
+    parallel.broadcast_params_(model.parameters())          # ... and leave the broadcast as rank 0's copy
+    ema = ExponentialMovingAverage(model.parameters(), decay=0.999)
+    opt = losses.get_optimizer(cfg, model.parameters())
+    batch, labels, noise, mask = train_step_inputs(B_TOTAL, R, seed=77)
+    sde = sde_lib.VPSDE(cfg.model.beta_min, cfg.model.beta_max, cfg.model.num_scales, device="cuda")
+    step_fn = losses.get_step_fn(sde, train=True, optimize_fn=losses.optimization_manager(cfg), mask=mask.cuda())
+    state = dict(model=model, ema=ema, optimizer=opt, step=1)
+    with fixed_draws(labels[shard].cuda(), noise[shard].cuda()):
+        loss = step_fn(state, batch[shard].cuda())["loss"]
+    return (float(loss.detach()), [p.detach().cpu().clone() for p in model.parameters()],
+            [p.grad.detach().cpu().clone() for p in model.parameters() if p.grad is not None])
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from meshdiffusion_amd.lib.diffusion import parallel
+    parallel.init_distributed(backend="gloo")
+    per = B_TOTAL // world
+    loss, params, grads = _one_step(rank, world, slice(rank * per, (rank + 1) * per))
+    q.put((rank, loss, [t.numpy() for t in params], [t.numpy() for t in grads]))       # by value: the child exits before the parent reads
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_replicas_one_step_equals_full_batch_step(hip_lib):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(2):
+        rank, loss, params, grads = q.get(timeout=300)
+        res[rank] = (loss, [torch.from_numpy(a) for a in params], [torch.from_numpy(a) for a in grads])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    # replicas identical after the step (same averaged gradient, same update)
+    for a, b in zip(res[0][1], res[1][1]):
+        assert torch.equal(a, b)
+    # single process, whole batch, rank 0's initialisation: the averaged shard gradients are the full-batch gradient
+    loss_full, params_full, grads_full = _one_step(0, 1, slice(0, B_TOTAL))
+    assert abs(0.5 * (res[0][0] + res[1][0]) - loss_full) < 1e-5 * abs(loss_full)
+
+    def rel(xs, ys):
+        num = sum(float((a.double() - b.double()).pow(2).sum()) for a, b in zip(xs, ys))
+        return (num / sum(float(b.double().pow(2).sum()) for b in ys)) ** 0.5
+
+    assert len(res[0][2]) == len(grads_full) and rel(res[0][2], grads_full) < 1e-5
+    # ... and so is the update, up to Adam's first step turning 1e-7 differences of near-zero gradients into +-lr
+    assert rel(res[0][1], params_full) < 1e-4
