@@ -17,7 +17,11 @@
 // nearest-x2 upsampled input (layers.py:618-623, `ups`).
 #include "md_common.h"
 
+#ifndef MD_SETPRIO_VALUE
+#define MD_SETPRIO_VALUE 0
+#endif
 namespace {
+constexpr bool MD_SETPRIO = MD_SETPRIO_VALUE != 0;   // s_setprio 1/0 around each MFMA group: measured neutral (-DMD_SETPRIO_VALUE=1 to A/B)
 constexpr int NT = 128, KC = 32, TZ = 4, TY = 8, TX = 8, TAPS = 27;
 constexpr int ZH = 6, YH = 10, XH = 10;
 constexpr int HS = 3 * YH * 24;          // 720 halo slots (odd z-planes interleaved at +12, y stride 24)
@@ -240,7 +244,9 @@ __global__ __launch_bounds__(NTHREADS) void md_conv3_main_kernel(const MdGemmCon
         const unsigned char* pb = lds + vB[dz] + (dy * 24 + dx) * 16;
         MD_LOAD_FRAGS(F1, pa, pb, 1)
       }
+      if constexpr (MD_SETPRIO) __builtin_amdgcn_s_setprio(1);
       MD_MMA(F0)
+      if constexpr (MD_SETPRIO) __builtin_amdgcn_s_setprio(0);
       MD_INTERLEAVE()
       if constexpr (ABL != 3) {  // W(s+1): registers -> LDS (the other buffer; its last readers passed a barrier)
         *(uint4*)(lds + nxt + tid * 16) = wreg0;
@@ -262,7 +268,9 @@ __global__ __launch_bounds__(NTHREADS) void md_conv3_main_kernel(const MdGemmCon
         const unsigned char* pb = lds + vB[ndz] + (ndy * 24 + ndx) * 16;
         MD_LOAD_FRAGS(F0, pa, pb, 0)
       }
+      if constexpr (MD_SETPRIO) __builtin_amdgcn_s_setprio(1);
       MD_MMA(F1)
+      if constexpr (MD_SETPRIO) __builtin_amdgcn_s_setprio(0);
       MD_INTERLEAVE()
       cur = nxt;
       ++s;
