@@ -59,7 +59,8 @@ enum {
   MD_CFG_C3_128_FAST = 14, /* dedicated kernel for the hot conv: C3_128_V2 layout, taps unrolled, F32B out */
   MD_CFG_C5_128_K16 = 15, /* 5x5x5 s1 pad 2, tile 4x8x8, NT=128, KC=16 (ddpm_res128 stem / mask_layer)  */
   MD_CFG_C5_32_K16 = 16,  /* 5x5x5 s1 pad 2, tile 4x8x8, NT=32,  KC=16 (ddpm_res128 head)               */
-  MD_CFG_COUNT = 17
+  MD_CFG_C3_128_W4 = 17,  /* experiment: 3x3x3, tile 4x4x8, NT=128, 4 waves (2 workgroups/CU)          */
+  MD_CFG_COUNT = 18
 };
 
 enum { MD_OUT_F32B = 0, MD_OUT_S16B = 1, MD_OUT_NCDHW = 2 };
