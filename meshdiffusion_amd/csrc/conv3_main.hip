@@ -348,22 +348,30 @@ __global__ __launch_bounds__(NTHREADS) void md_conv3_main_kernel(const MdGemmCon
   }
   // ---- optional: GroupNorm statistics of the tensor just written (consumer skips its md_gn_stats pass) ----------
   if constexpr (ABL == 0) if (want_stats) {   // workgroup-uniform
-    // lanes with equal h hold the same 32 channels at 32 different positions: butterfly over j, then the 4 wc waves
-    // of a row half meet in LDS (free: every wave is past its last fragment read after the barrier)
+    // A 16-lane DPP row holds the same 32 channels at 16 different positions: four DPP adds (quad_perm xor 1, xor 2,
+    // row_half_mirror, row_mirror -- VALU only, no LDS crossbar traffic) leave the row total in every lane; lane 0 of
+    // each row parks it in LDS (free: all waves are past their last fragment read after the barrier), where the two
+    // rows of a half-wave and the 4 wc waves of a row half are added up.
+    auto row_sum = [](float v) {
+      v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+      v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+      v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+      v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
+      return v;
+    };
 #pragma unroll
     for (int rm = 0; rm < 2; ++rm)
 #pragma unroll
       for (int q = 0; q < 4; ++q)
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-          for (int o = 16; o > 0; o >>= 1) {
-            st1[rm][q][e] += __shfl_xor(st1[rm][q][e], o, 64);
-            st2[rm][q][e] += __shfl_xor(st2[rm][q][e], o, 64);
-          }
+        for (int e = 0; e < 4; ++e) {
+          st1[rm][q][e] = row_sum(st1[rm][q][e]);
+          st2[rm][q][e] = row_sum(st2[rm][q][e]);
+        }
     __syncthreads();
-    float* red = (float*)lds;   // [8 waves][64 channels][2]
-    if (j == 0) {
+    float* red = (float*)lds;   // [8 waves][2 rows of a half-wave][64 channels][2]
+    if ((lane & 15) == 0) {
+      const int jr = (lane >> 4) & 1;
 #pragma unroll
       for (int rm = 0; rm < 2; ++rm)
 #pragma unroll
@@ -371,16 +379,17 @@ __global__ __launch_bounds__(NTHREADS) void md_conv3_main_kernel(const MdGemmCon
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const int ch = rm * 32 + 8 * q + 4 * h + e;
-            red[(wid * 64 + ch) * 2] = st1[rm][q][e];
-            red[(wid * 64 + ch) * 2 + 1] = st2[rm][q][e];
+            red[((wid * 2 + jr) * 64 + ch) * 2] = st1[rm][q][e];
+            red[((wid * 2 + jr) * 64 + ch) * 2 + 1] = st2[rm][q][e];
           }
     }
     __syncthreads();
     if (tid < 256) {
       const int ch = tid >> 1, which = tid & 1;          // channel within the 128-row tile
       const int w0 = (ch >> 6) * 4, c64 = ch & 63;
-      const float sum = (red[((w0 + 0) * 64 + c64) * 2 + which] + red[((w0 + 1) * 64 + c64) * 2 + which]) +
-                        (red[((w0 + 2) * 64 + c64) * 2 + which] + red[((w0 + 3) * 64 + c64) * 2 + which]);
+      float sum = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) sum += red[(((w0 + (k >> 1)) * 2 + (k & 1)) * 64 + c64) * 2 + which];
       const int row = rt * NT + ch;
       if (row < rows_alloc) atomicAdd(A.stats + ((int64_t)b * rows_alloc + row) * 2 + which, (double)sum);
     }
