@@ -60,7 +60,9 @@ enum {
   MD_CFG_C5_128_K16 = 15, /* 5x5x5 s1 pad 2, tile 4x8x8, NT=128, KC=16 (ddpm_res128 stem / mask_layer)  */
   MD_CFG_C5_32_K16 = 16,  /* 5x5x5 s1 pad 2, tile 4x8x8, NT=32,  KC=16 (ddpm_res128 head)               */
   MD_CFG_C3_128_W4 = 17,  /* experiment: 3x3x3, tile 4x4x8, NT=128, 4 waves (2 workgroups/CU)          */
-  MD_CFG_COUNT = 18
+  MD_CFG_C3X_32 = 18,     /* 3x3x1 taps (one dx column of a 3x3x3 kernel), tile 4x8x8, NT=32, KC=32: dx-folded head */
+  MD_CFG_C5X_32_K16 = 19, /* 5x5x1 taps, NT=32, KC=16: dx-folded 5x5x5 head of ddpm_res128                        */
+  MD_CFG_COUNT = 20
 };
 
 enum { MD_OUT_F32B = 0, MD_OUT_S16B = 1, MD_OUT_NCDHW = 2 };
@@ -183,6 +185,15 @@ int md_timestep_embedding(const float* t, float* emb, int32_t batch, int32_t dim
 int md_linear(const float* x, const float* w, const float* bias, float* y, int32_t batch,
               int32_t in_dim, int32_t out_dim, int32_t silu_in, void* stream);
 
+/*
+ * md_fold_dx: second half of the dx-folded head convolution (ddpm_res64.py:121,189 / ddpm_res128.py:132,208).  The conv
+ * runs with rows = (co, dx) and k x k x 1 taps (MD_CFG_C3X_32 / MD_CFG_C5X_32_K16: the 4 output channels would fill 4
+ * of the 32 rows of an MFMA tile, the kx (co, dx) pairs fill 12 / 20), y: F32B [B][rows_alloc/8][P][8]; this kernel adds
+ * the kx shifted columns: out[b][co][z][y][x] = bias[co] + sum_dx y[b][co*kx + dx][z][y][x + dx - kx/2] (x in range),
+ * NCDHW fp32 [B][co][D*H*W].
+ */
+int md_fold_dx(const float* y, const float* bias, float* out, int32_t batch, int32_t co, int32_t kx, int32_t rows_alloc,
+               int32_t D, int32_t H, int32_t W, void* stream);
 /* NCDHW fp32 [B][C][P] -> S16B [B][c_pad/8][2][P][8] (channels >= C zero filled). */
 int md_ncdhw_to_s16b(const float* x, void* out, int32_t batch, int32_t C, int32_t c_pad,
                      int64_t P, void* stream);

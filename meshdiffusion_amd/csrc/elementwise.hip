@@ -311,3 +311,38 @@ extern "C" int md_timestep_embedding(const float* t, float* emb, int32_t batch, 
   MD_HIP_CHECK_LAUNCH();
   return MD_OK;
 }
+
+// ---- dx-folded head: out[b][co][p] = bias[co] + sum_dx y[b][co*kx + dx][p shifted by dx - kx/2 along x] -----------------
+__global__ void md_fold_dx_kernel(const float* __restrict__ y, const float* __restrict__ bias, float* __restrict__ out, int B,
+                                  int co, int kx, int rows_alloc, int64_t P, int W) {
+  const int64_t total = (int64_t)B * co * P;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t p = i % P;
+    const int c = (int)((i / P) % co);
+    const int b = (int)(i / (P * co));
+    const int x = (int)(p % W);
+    float acc = bias ? bias[c] : 0.f;
+    for (int dx = 0; dx < kx; ++dx) {
+      const int xs = x + dx - kx / 2;
+      if (xs < 0 || xs >= W) continue;
+      const int row = c * kx + dx;
+      acc += y[(((int64_t)b * (rows_alloc / 8) + (row >> 3)) * P + (p + dx - kx / 2)) * 8 + (row & 7)];
+    }
+    out[i] = acc;
+  }
+}
+
+extern "C" int md_fold_dx(const float* y, const float* bias, float* out, int32_t batch, int32_t co, int32_t kx, int32_t rows_alloc,
+                          int32_t D, int32_t H, int32_t W, void* stream) {
+  if (!y || !out || batch <= 0 || co <= 0 || (kx != 3 && kx != 5) || rows_alloc < co * kx || (rows_alloc % 8) || D <= 0 || H <= 0 ||
+      W <= 0)
+    return MD_ERR_BAD_ARG;
+  const int64_t P = (int64_t)D * H * W, total = (int64_t)batch * co * P;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 65536) blocks = 65536;
+  MD_HIP_CLEAR_ERROR();
+  hipLaunchKernelGGL(md_fold_dx_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, y, bias, out, batch, co, kx,
+                     rows_alloc, P, W);
+  MD_HIP_CHECK_LAUNCH();
+  return MD_OK;
+}

@@ -31,10 +31,13 @@ struct GCfg {
   static constexpr int NTHREADS = NW * 64;
   static constexpr int RM = NT / (32 * WR);
   static constexpr int CM = MT / (32 * WC);
-  static constexpr int KSZ = (TAPS == 125) ? 5 : (TAPS == 27) ? 3 : 1;  // cubic kernel extent
+  // kernel extent: cubic k^3 (27, 125), or k x k x 1 (9, 25) = one dx column of a k^3 kernel -- the dx-folded head,
+  // whose output rows are (co, dx) pairs summed with an x shift by md_fold_dx
+  static constexpr int KSZ = (TAPS == 125 || TAPS == 25) ? 5 : (TAPS == 27 || TAPS == 9) ? 3 : 1;
+  static constexpr int KSX = (TAPS == 25 || TAPS == 9) ? 1 : KSZ;
   static constexpr int ZH = (TAPS > 1) ? (TZ - 1) * STRIDE + KSZ : 1;
   static constexpr int YH = (TAPS > 1) ? (TY - 1) * STRIDE + KSZ : 1;
-  static constexpr int XH = (TAPS > 1) ? (TX - 1) * STRIDE + KSZ : MT;
+  static constexpr int XH = (TAPS > 1) ? (TX - 1) * STRIDE + KSX : MT;
   static constexpr int XHP = XH;
   // SW=1 (tile x-extent 8, stride 1): y-rows are 24 slots apart with odd z-planes interleaved at +12,
   // so a 32-position fragment (8 x by 4 y) touches every 16-byte LDS slot class exactly twice, once
@@ -54,7 +57,8 @@ struct GCfg {
   static constexpr int LDS_ITEMS = W_LDS_ITEMS + KG * 2 * HS;
   static constexpr int LDS_BYTES = LDS_ITEMS * 16;
   static constexpr int PADLO = (STRIDE == 2) ? 0 : (KSZ - 1) / 2;  // 'same' padding; Downsample pads (0,1)
-  static_assert(TAPS == 1 || TAPS == 27 || TAPS == 125, "1x1x1, 3x3x3 or 5x5x5");
+  static constexpr int PADLO_X = (STRIDE == 2) ? 0 : (KSX - 1) / 2;
+  static_assert(TAPS == 1 || TAPS == 27 || TAPS == 125 || TAPS == 9 || TAPS == 25, "1x1x1, 3x3x3, 5x5x5, 3x3x1 or 5x5x1");
   static_assert(RM >= 1 && CM >= 1, "tile too small for the wave grid");
   static_assert(NT % (32 * WR) == 0 && MT % (32 * WC) == 0, "tile / wave grid mismatch");
   static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
@@ -177,7 +181,7 @@ __global__ __launch_bounds__(C::NTHREADS) void md_gemm_conv_kernel(const MdGemmC
           const int hx = r % C::XH, hy = (r / C::XH) % C::YH, hz = r / (C::XH * C::YH);
           int uz = z0 * C::STRIDE + hz - C::PADLO;
           int uy = y0 * C::STRIDE + hy - C::PADLO;
-          int ux = x0 * C::STRIDE + hx - C::PADLO;
+          int ux = x0 * C::STRIDE + hx - C::PADLO_X;
           if (A.ups) {
             inb = (uz >= 0) & (uz < D) & (uy >= 0) & (uy < H) & (ux >= 0) & (ux < W);
             uz >>= 1; uy >>= 1; ux >>= 1;
@@ -266,7 +270,7 @@ __global__ __launch_bounds__(C::NTHREADS) void md_gemm_conv_kernel(const MdGemmC
   auto advance = [&](int& cc, int& tap, int& dz, int& dy, int& dx) {
     ++tap; ++dx;
     if constexpr (C::TAPS > 1) {
-      if (dx == C::KSZ) { dx = 0; ++dy; }
+      if (dx == C::KSX) { dx = 0; ++dy; }
       if (dy == C::KSZ) { dy = 0; ++dz; }
     }
     if (tap == C::TAPS) { tap = 0; dz = dy = dx = 0; ++cc; }
@@ -552,6 +556,8 @@ using Cfg_ABL4 = GCfg<128, 32, 4, 8, 8, 27, 1, 2, 4, 1, 1, 4>;
 using Cfg_ABL5 = GCfg<128, 32, 4, 8, 8, 27, 1, 2, 4, 1, 1, 5>;
 using Cfg_C3_128_K16 = GCfg<128, 16, 4, 8, 8, 27, 1, 2, 4>;
 using Cfg_C3_32 = GCfg<32, 32, 4, 8, 8, 27, 1, 1, 8>;
+using Cfg_C3X_32 = GCfg<32, 32, 4, 8, 8, 9, 1, 1, 8>;        // 3x3x1 taps: dx-folded 3x3x3 head (rows = (co, dx))
+using Cfg_C5X_32_K16 = GCfg<32, 16, 4, 8, 8, 25, 1, 1, 8>;   // 5x5x1 taps: dx-folded 5x5x5 head of ddpm_res128
 using Cfg_C3_LOW = GCfg<128, 32, 4, 4, 4, 27, 1, 4, 2>;
 // experiment: 4-wave workgroups on a 4x4x8 tile (78.8 KB of LDS => two independent workgroups per CU instead of one
 // 8-wave workgroup): +4.5 % on 128->128 @64^3, -3 % on 256->128 against Cfg_C3_128 -- decoupling the barriers does not pay
@@ -653,6 +659,8 @@ static void cfg_info(int32_t* nt, int32_t* kc, int32_t* cols, int32_t* taps, int
     case MD_CFG_C3_128: F<Cfg_C3_128>(__VA_ARGS__); break;          \
     case MD_CFG_C3_128_K16: F<Cfg_C3_128_K16>(__VA_ARGS__); break;  \
     case MD_CFG_C3_32: F<Cfg_C3_32>(__VA_ARGS__); break;            \
+    case MD_CFG_C3X_32: F<Cfg_C3X_32>(__VA_ARGS__); break;          \
+    case MD_CFG_C5X_32_K16: F<Cfg_C5X_32_K16>(__VA_ARGS__); break;  \
     case MD_CFG_C3_LOW: F<Cfg_C3_LOW>(__VA_ARGS__); break;          \
     case MD_CFG_C3_128_W4: F<Cfg_C3_128_W4>(__VA_ARGS__); break;    \
     case MD_CFG_C3_S2: F<Cfg_C3_S2>(__VA_ARGS__); break;            \

@@ -229,9 +229,7 @@ class DDPMUNet3D(layers.HipLayer):
         prm = ops.gn_params([(hl, c)], gn.weight, gn.bias, B, p, eps=gn.eps, groups=gn.num_groups)
         a = ops.gn_apply([(hl, c)], prm, B, p, norm=True, silu=True)
         head = mods[i]
-        out = torch.empty((B, self.out_channels, R, R, R), dtype=torch.float32, device=x.device)
-        pwh = layers.conv3_packed(self, "head", head, self._head_cfg())
-        layers.run_conv3(pwh, a, B, R, bias=head.bias, out=out, out_mode=ops.OUT_NCDHW, rows_alloc=8)
+        out = self._head_forward(head, a, B, R)
         ctx = dict(B=B, R=R, P=P, emb=emb, t1=t1, temb=temb, x16=x16, v0=v0, last=v, acts=acts, tape=tape, gn_prm=prm,
                    a_final=a, foffs=foffs, ftot=ftot, fw=fw)
         return out, ctx
@@ -324,6 +322,22 @@ class DDPMUNet3D(layers.HipLayer):
     def _head_cfg(self):
         return ops.CFG_C3_32 if self.KSIZE == 3 else ops.CFG_C5_32_K16
 
+    def _head_forward(self, head, a, B, R):
+        """The k^3 head conv to 4 channels, dx-folded: a k x k x 1 conv whose rows are the (co, dx) pairs (12 or 20 of the
+        32 rows of an MFMA tile instead of 4, with k times fewer taps), then `md_fold_dx` adds the k x-shifted columns
+        and the bias and writes NCDHW.  Same products as the reference conv, summed in a different order."""
+        k, co = self.KSIZE, self.out_channels
+        cfg = ops.CFG_C3X_32 if k == 3 else ops.CFG_C5X_32_K16
+
+        def build():
+            w = head.weight.detach()                                   # [co][ci][kz][ky][kx]
+            w2 = w.permute(0, 4, 1, 2, 3).reshape(co * k, w.shape[1], k, k, 1).contiguous()
+            return ops.PackedWeight(w2, "conv", cfg, w.device)
+        pw = self._cached(f"head_fold{cfg}", [head.weight], build)
+        rows_alloc = ((co * k + 7) // 8) * 8
+        y = layers.run_conv3(pw, a, B, R, rows_alloc=rows_alloc)
+        return ops.fold_dx(y, head.bias, B, co, k, rows_alloc, R)
+
     # ---- forward ------------------------------------------------------------------------------
     def forward(self, x, labels):
         if not x.is_cuda:
@@ -389,9 +403,7 @@ class DDPMUNet3D(layers.HipLayer):
         a = ops.gn_apply([(h, c)], prm, B, p, norm=True, silu=True)
         head = mods[i]; i += 1
         assert i == len(mods)
-        out = torch.empty((B, self.out_channels, R, R, R), dtype=torch.float32, device=x.device)
-        pw = layers.conv3_packed(self, "head", head, self._head_cfg())
-        layers.run_conv3(pw, a, B, R, bias=head.bias, out=out, out_mode=ops.OUT_NCDHW, rows_alloc=8)
+        out = self._head_forward(head, a, B, R)
 
         if self.scale_by_sigma:
             out = out / self.sigmas[labels.long(), None, None, None, None].to(out.dtype)
