@@ -62,7 +62,9 @@ enum {
   MD_CFG_C3_128_W4 = 17,  /* experiment: 3x3x3, tile 4x4x8, NT=128, 4 waves (2 workgroups/CU)          */
   MD_CFG_C3X_32 = 18,     /* 3x3x1 taps (one dx column of a 3x3x3 kernel), tile 4x8x8, NT=32, KC=32: dx-folded head */
   MD_CFG_C5X_32_K16 = 19, /* 5x5x1 taps, NT=32, KC=16: dx-folded 5x5x5 head of ddpm_res128                        */
-  MD_CFG_COUNT = 20
+  MD_CFG_C3X_128_K16 = 20, /* 3x3x1 taps, NT=128, KC=16: dx-folded 3x3x3 stem (K = 4 channels x 3 dx)                    */
+  MD_CFG_C5X_128 = 21,     /* 5x5x1 taps, NT=128, KC=32: dx-folded 5x5x5 stem of ddpm_res128 (K = 4 channels x 5 dx)     */
+  MD_CFG_COUNT = 22
 };
 
 enum { MD_OUT_F32B = 0, MD_OUT_S16B = 1, MD_OUT_NCDHW = 2 };
@@ -194,6 +196,10 @@ int md_linear(const float* x, const float* w, const float* bias, float* y, int32
  */
 int md_fold_dx(const float* y, const float* bias, float* out, int32_t batch, int32_t co, int32_t kx, int32_t rows_alloc,
                int32_t D, int32_t H, int32_t W, void* stream);
+/* NCDHW fp32 -> S16B with kx x-shifted copies per channel (channel ci*kx + dx = x[ci] shifted by dx - kx/2 along x, zero
+ * outside): operand of the dx-folded stem conv (ddpm_res64.py:87,140 / ddpm_res128.py:90,150), MD_CFG_C3X_128_K16 / C5X_128. */
+int md_ncdhw_to_s16b_xfold(const float* x, void* out, int32_t batch, int32_t C, int32_t kx, int32_t c_pad, int32_t D, int32_t H,
+                           int32_t W, void* stream);
 /* NCDHW fp32 [B][C][P] -> S16B [B][c_pad/8][2][P][8] (channels >= C zero filled). */
 int md_ncdhw_to_s16b(const float* x, void* out, int32_t batch, int32_t C, int32_t c_pad,
                      int64_t P, void* stream);

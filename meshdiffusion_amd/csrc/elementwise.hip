@@ -78,6 +78,43 @@ extern "C" int md_ncdhw_to_s16b(const float* x, void* out, int32_t batch, int32_
   return MD_OK;
 }
 
+// NCDHW fp32 [B][C][D][H][W] -> S16B [B][c_pad/8][2][P][8] with the kx x-shifted copies of every channel side by side:
+// channel ci*kx + dx holds x[ci] shifted by dx - kx/2 along x (zero outside the grid).  Operand of the dx-folded stem
+// conv: a k^3 conv over C channels = a k x k x 1 conv over C*kx channels (K = 12 or 20 instead of 4 per tap, k times
+// fewer taps).
+__global__ void md_ncdhw_to_s16b_xfold_kernel(const float* __restrict__ x, uint4* __restrict__ out, int C, int kx, int c_pad,
+                                              int64_t P, int W) {
+  const int b = blockIdx.y;
+  const int64_t pos = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (pos >= P) return;
+  const int xx = (int)(pos % W);
+  for (int cg = 0; cg < c_pad / 8; ++cg) {
+    uint32_t hi[8], lo[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = cg * 8 + e, ci = c / kx, sh = c % kx - kx / 2;
+      float v = 0.f;
+      if (ci < C && xx + sh >= 0 && xx + sh < W) v = x[((int64_t)b * C + ci) * P + pos + sh];
+      md_split(v, hi[e], lo[e]);
+    }
+    uint4* o = out + (((int64_t)b * (c_pad / 8) + cg) * 2) * P + pos;
+    o[0] = make_uint4(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16), hi[4] | (hi[5] << 16), hi[6] | (hi[7] << 16));
+    o[P] = make_uint4(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16), lo[4] | (lo[5] << 16), lo[6] | (lo[7] << 16));
+  }
+}
+
+extern "C" int md_ncdhw_to_s16b_xfold(const float* x, void* out, int32_t batch, int32_t C, int32_t kx, int32_t c_pad, int32_t D,
+                                      int32_t H, int32_t W, void* stream) {
+  if (!x || !out || batch <= 0 || C <= 0 || (kx != 3 && kx != 5) || c_pad < C * kx || (c_pad % 8) || D <= 0 || H <= 0 || W <= 0)
+    return MD_ERR_BAD_ARG;
+  const int64_t P = (int64_t)D * H * W;
+  dim3 grid((unsigned)((P + 255) / 256), (unsigned)batch);
+  MD_HIP_CLEAR_ERROR();
+  hipLaunchKernelGGL(md_ncdhw_to_s16b_xfold_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, (uint4*)out, C, kx, c_pad, P, W);
+  MD_HIP_CHECK_LAUNCH();
+  return MD_OK;
+}
+
 // mode 0: F32B -> NCDHW ; mode 1: NCDHW -> F32B ; mode 2: S16B (hi+lo) -> NCDHW
 __global__ void md_relayout_kernel(const void* __restrict__ xin, float* __restrict__ out, int C,
                                    int64_t P, int mode) {

@@ -558,6 +558,8 @@ using Cfg_C3_128_K16 = GCfg<128, 16, 4, 8, 8, 27, 1, 2, 4>;
 using Cfg_C3_32 = GCfg<32, 32, 4, 8, 8, 27, 1, 1, 8>;
 using Cfg_C3X_32 = GCfg<32, 32, 4, 8, 8, 9, 1, 1, 8>;        // 3x3x1 taps: dx-folded 3x3x3 head (rows = (co, dx))
 using Cfg_C5X_32_K16 = GCfg<32, 16, 4, 8, 8, 25, 1, 1, 8>;   // 5x5x1 taps: dx-folded 5x5x5 head of ddpm_res128
+using Cfg_C3X_128_K16 = GCfg<128, 16, 4, 8, 8, 9, 1, 2, 4>;  // dx-folded 3x3x3 stem: K = 4 ch x 3 dx (12 -> 16)
+using Cfg_C5X_128 = GCfg<128, 32, 4, 8, 8, 25, 1, 2, 4>;     // dx-folded 5x5x5 stem: K = 4 ch x 5 dx (20 -> 32)
 using Cfg_C3_LOW = GCfg<128, 32, 4, 4, 4, 27, 1, 4, 2>;
 // experiment: 4-wave workgroups on a 4x4x8 tile (78.8 KB of LDS => two independent workgroups per CU instead of one
 // 8-wave workgroup): +4.5 % on 128->128 @64^3, -3 % on 256->128 against Cfg_C3_128 -- decoupling the barriers does not pay
@@ -661,6 +663,8 @@ static void cfg_info(int32_t* nt, int32_t* kc, int32_t* cols, int32_t* taps, int
     case MD_CFG_C3_32: F<Cfg_C3_32>(__VA_ARGS__); break;            \
     case MD_CFG_C3X_32: F<Cfg_C3X_32>(__VA_ARGS__); break;          \
     case MD_CFG_C5X_32_K16: F<Cfg_C5X_32_K16>(__VA_ARGS__); break;  \
+    case MD_CFG_C3X_128_K16: F<Cfg_C3X_128_K16>(__VA_ARGS__); break; \
+    case MD_CFG_C5X_128: F<Cfg_C5X_128>(__VA_ARGS__); break;        \
     case MD_CFG_C3_LOW: F<Cfg_C3_LOW>(__VA_ARGS__); break;          \
     case MD_CFG_C3_128_W4: F<Cfg_C3_128_W4>(__VA_ARGS__); break;    \
     case MD_CFG_C3_S2: F<Cfg_C3_S2>(__VA_ARGS__); break;            \

@@ -10,7 +10,7 @@ import os
 import torch
 
 from . import _lib
-from ._lib import (A_PACKED, A_S16B, PREC_BF16X3, PREC_FP16X2, CFG_C3_128, CFG_C3_128_V2, CFG_C3_128_SW, CFG_C3_128_PIPE, CFG_C3_128_V3, CFG_C3_128_V3B, CFG_C3_128_V4, CFG_C3_128_FAST, CFG_C5_128_K16, CFG_C5_32_K16, CFG_C3_128_W4, CFG_C3X_32, CFG_C5X_32_K16, CFG_C3_128_K16, CFG_C3_32, CFG_C3_LOW, CFG_C3_S2,
+from ._lib import (A_PACKED, A_S16B, PREC_BF16X3, PREC_FP16X2, CFG_C3_128, CFG_C3_128_V2, CFG_C3_128_SW, CFG_C3_128_PIPE, CFG_C3_128_V3, CFG_C3_128_V3B, CFG_C3_128_V4, CFG_C3_128_FAST, CFG_C5_128_K16, CFG_C5_32_K16, CFG_C3_128_W4, CFG_C3X_32, CFG_C5X_32_K16, CFG_C3X_128_K16, CFG_C5X_128, CFG_C3_128_K16, CFG_C3_32, CFG_C3_LOW, CFG_C3_S2,
                    CFG_G1_128, CFG_G1_128_LOW, CFG_G1_64_LOW, CFG_NT_KC, OUT_F32B, OUT_NCDHW, OUT_S16B,
                    MdGemmConvArgs, check)
 
@@ -267,6 +267,17 @@ def ncdhw_to_s16b(x, c_pad):
     P = x[0, 0].numel()
     out = s16b_empty(B, c_pad, P, x.device)
     check(lib.md_ncdhw_to_s16b(_ptr(x), _ptr(out), B, Cc, c_pad, P, _stream()), "md_ncdhw_to_s16b")
+    return out
+
+
+def ncdhw_to_s16b_xfold(x, kx, c_pad):
+    """[B,C,S,S,S] fp32 -> S16B with kx x-shifted copies per channel (operand of the dx-folded stem conv)."""
+    lib = _lib.load()
+    _require_cuda(x, "x")
+    x = x.to(torch.float32).contiguous()
+    B, Cc, D, H, W = x.shape
+    out = s16b_empty(B, c_pad, D * H * W, x.device)
+    check(lib.md_ncdhw_to_s16b_xfold(_ptr(x), _ptr(out), B, Cc, kx, c_pad, D, H, W, _stream()), "md_ncdhw_to_s16b_xfold")
     return out
 
 

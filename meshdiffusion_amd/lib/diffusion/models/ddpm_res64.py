@@ -161,9 +161,9 @@ class DDPMUNet3D(layers.HipLayer):
         t1 = ops.linear(emb, mods[0].weight, mods[0].bias); i += 1
         temb = ops.linear(t1, mods[1].weight, mods[1].bias, silu_in=True); i += 1
         stem = mods[i]; i += 1
-        x16 = ops.ncdhw_to_s16b(x if self.centered else 2 * x - 1.0, 16)
-        pw = layers.conv3_packed(self, "stem", stem, self._stem_cfg())
-        h = layers.run_conv3(pw, x16, B, R, bias=stem.bias, residual=self._stem_const(), res_bstride=0)
+        xin = x if self.centered else 2 * x - 1.0
+        x16 = ops.ncdhw_to_s16b(xin, 16)            # unfolded operand: the stem's weight gradient contracts against it
+        h = self._stem_forward(stem, xin, B, R)
         fw, fb, foffs, ftot = self._film_table()
         film = ops.linear(temb, fw, fb, silu_in=True)
         acts, tape = {}, []
@@ -322,6 +322,21 @@ class DDPMUNet3D(layers.HipLayer):
     def _head_cfg(self):
         return ops.CFG_C3_32 if self.KSIZE == 3 else ops.CFG_C5_32_K16
 
+    def _stem_forward(self, stem, xin, B, R):
+        """The k^3 stem conv from 4 channels, dx-folded the other way round: the k x-shifted copies of the input become
+        extra input channels (K = 12 or 20 instead of 4 per tap) of a k x k x 1 conv, so the matrix cores do k times
+        fewer, fuller K steps.  pos_layer / mask_layer outputs (input independent) come in as the residual."""
+        k = self.KSIZE
+        cfg, c_pad = (ops.CFG_C3X_128_K16, 16) if k == 3 else (ops.CFG_C5X_128, 32)
+
+        def build():
+            w = stem.weight.detach()                                   # [co][ci][kz][ky][kx]
+            w2 = w.permute(0, 1, 4, 2, 3).reshape(w.shape[0], w.shape[1] * k, k, k, 1).contiguous()
+            return ops.PackedWeight(w2, "conv", cfg, w.device)
+        pw = self._cached(f"stem_fold{cfg}", [stem.weight], build)
+        xf = ops.ncdhw_to_s16b_xfold(xin, k, c_pad)
+        return layers.run_conv3(pw, xf, B, R, bias=stem.bias, residual=self._stem_const(), res_bstride=0)
+
     def _head_forward(self, head, a, B, R):
         """The k^3 head conv to 4 channels, dx-folded: a k x k x 1 conv whose rows are the (co, dx) pairs (12 or 20 of the
         32 rows of an MFMA tile instead of 4, with k times fewer taps), then `md_fold_dx` adds the k x-shifted columns
@@ -359,9 +374,7 @@ class DDPMUNet3D(layers.HipLayer):
 
         h_in = x if self.centered else 2 * x - 1.0
         stem = mods[i]; i += 1
-        x16 = ops.ncdhw_to_s16b(h_in, 16)
-        pw = layers.conv3_packed(self, "stem", stem, self._stem_cfg())
-        h = layers.run_conv3(pw, x16, B, R, bias=stem.bias, residual=self._stem_const(), res_bstride=0)
+        h = self._stem_forward(stem, h_in, B, R)
 
         fw, fb, foffs, ftot = self._film_table()
         film = ops.linear(temb, fw, fb, silu_in=True)            # [B, sum(out_ch)]
