@@ -43,6 +43,20 @@ def bump_param_epoch():
     PARAM_EPOCH += 1
 
 
+# A/B (MD_NIN_SIDE_STREAM=1): ResnetBlock shortcut GEMM on a second HIP stream next to Conv_0.  Measured neutral on
+# MI355X (62.3 vs 62.8 sample-steps/s): a 125 KB-LDS conv workgroup and the GEMM never share a CU, so the two
+# kernels only trade CUs.  Off by default.
+NIN_SIDE_STREAM = os.environ.get("MD_NIN_SIDE_STREAM", "0") == "1"
+_SIDE = {}
+
+
+def side_stream():
+    dev = torch.cuda.current_device()
+    if dev not in _SIDE:
+        _SIDE[dev] = torch.cuda.Stream(device=dev)
+    return _SIDE[dev]
+
+
 PROFILE = None   # set to a list by bench.py to collect (cfg, flops, start_event, end_event) per GEMM/conv launch
 
 

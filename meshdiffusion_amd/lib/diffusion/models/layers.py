@@ -341,8 +341,18 @@ class ResnetBlockDDPM(HipLayer):
         need_nin = self.in_ch != self.out_ch
         a0 = ops.gn_apply(parts, prm, B, P, norm=True, silu=True, fp16=f16, want_raw=need_nin)
         xs = None
+        res = None
         if need_nin:
             a0, xs = a0
+            if ops.NIN_SIDE_STREAM:
+                # The shortcut GEMM is HBM-bound and independent of Conv_0 (MFMA-bound): launch it on a second HIP
+                # stream so that it shares the GPU with the convolution instead of preceding Conv_1 serially.
+                main, side = torch.cuda.current_stream(), ops.side_stream()
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    res = self.NIN_0.forward_s16(xs, B, P)
+                res.record_stream(main)
+                xs.record_stream(side)
         if bias0 is not None:
             h = run_conv3(pw0, a0, B, S, bias=bias0, bias_bstride=bias0_stride, want_stats=True)
         elif temb is not None:   # per-(sample, channel) additive bias = Conv_0.b + Dense_0(SiLU(temb))
@@ -353,7 +363,10 @@ class ResnetBlockDDPM(HipLayer):
         prm1 = ops.gn_params([(h, self.out_ch)], g1.weight, g1.bias, B, P, eps=g1.eps, groups=g1.num_groups)
         a1 = ops.gn_apply([(h, self.out_ch)], prm1, B, P, norm=True, silu=True, fp16=f16, drop=drop)
         if need_nin:
-            res = self.NIN_0.forward_s16(xs, B, P)
+            if res is None:
+                res = self.NIN_0.forward_s16(xs, B, P)
+            else:
+                torch.cuda.current_stream().wait_stream(ops.side_stream())
         else:
             assert len(parts) == 1
             res = parts[0][0]
