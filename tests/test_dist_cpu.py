@@ -12,6 +12,21 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def retry_rendezvous(fn):
+    """The multi-process tests rendezvous over 127.0.0.1 on a port that was free a moment ago; on a busy host another
+    process can grab it first (seen right after large file transfers).  One retry with a fresh port."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(*a, **k):
+        try:
+            return fn(*a, **k)
+        except Exception as e:   # noqa: BLE001
+            print(f"first attempt failed ({type(e).__name__}: {e}); retrying once", flush=True)
+            return fn(*a, **k)
+    return wrapped
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -38,6 +53,7 @@ def _worker(rank, world, port, total, q):
 
 
 @pytest.mark.parametrize("total", [8, 5])
+@retry_rendezvous
 def test_sharded_sampling_two_ranks_gloo(total):
     from meshdiffusion_amd.lib.diffusion import parallel
     assert parallel.shard_sizes(5, 2) == [3, 2] and parallel.shard_sizes(8, 8) == [1] * 8
@@ -78,6 +94,7 @@ def _grad_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+@retry_rendezvous
 def test_grad_allreduce_equals_large_batch_gradient_gloo():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -127,6 +144,7 @@ def _replica_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+@retry_rendezvous
 def test_replica_broadcast_and_bucketed_grad_allreduce_gloo():
     """trainer.py's exchange: start-up broadcast makes the replicas identical; the bucketed mean of per-rank
     gradients equals the gradient of the global batch (training.batch_size = sum of the shards)."""
@@ -153,6 +171,7 @@ def test_replica_broadcast_and_bucketed_grad_allreduce_gloo():
         assert torch.allclose(res[0][1][k], p.grad, atol=1e-6) and torch.equal(res[0][1][k], res[1][1][k])
 
 
+@retry_rendezvous
 def test_bench_multi_process_control_flow_dry_run():
     """bench.py under torch.distributed.run with 2 ranks: rendezvous on 127.0.0.1, barrier, MAX over ranks,
     exactly one JSON line from rank 0 (the GPU work itself is covered by the -m gpu suite and `bench.py`)."""
