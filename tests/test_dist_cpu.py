@@ -27,6 +27,13 @@ def retry_rendezvous(fn):
     return wrapped
 
 
+def _reap(procs):
+    for p in procs:
+        if p.is_alive():
+            p.terminate()
+            p.join(timeout=10)
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -69,7 +76,9 @@ def test_sharded_sampling_two_ranks_gloo(total):
         res[rank] = (out, local)
     for p in procs:
         p.join(timeout=60)
-        assert p.exitcode == 0
+    codes = [p.exitcode for p in procs]
+    _reap(procs)
+    assert codes == [0] * len(procs), codes
     sizes = parallel.shard_sizes(total, 2)
     expect = torch.cat([_stub_sampler(sizes[r], 100 + r) for r in range(2)], 0)
     assert res[1][0] is None
@@ -105,7 +114,9 @@ def test_grad_allreduce_equals_large_batch_gradient_gloo():
     res = dict(q.get(timeout=120) for _ in range(2))
     for p in procs:
         p.join(timeout=60)
-        assert p.exitcode == 0
+    codes = [p.exitcode for p in procs]
+    _reap(procs)
+    assert codes == [0] * len(procs), codes
     g = torch.Generator().manual_seed(3)
     full = torch.randn((8, 1000), generator=g).mean(dim=0)
     assert torch.allclose(res[0], full, atol=1e-6) and torch.equal(res[0], res[1])
@@ -160,7 +171,9 @@ def test_replica_broadcast_and_bucketed_grad_allreduce_gloo():
         res[rank] = (start, grads)
     for p in procs:
         p.join(timeout=60)
-        assert p.exitcode == 0
+    codes = [p.exitcode for p in procs]
+    _reap(procs)
+    assert codes == [0] * len(procs), codes
     torch.manual_seed(10)
     net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 3))
     g = torch.Generator().manual_seed(3)

@@ -14,6 +14,13 @@ pytestmark = pytest.mark.gpu
 B_TOTAL = 16
 
 
+def _reap(procs):
+    for p in procs:
+        if p.is_alive():
+            p.terminate()
+            p.join(timeout=10)
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -70,12 +77,15 @@ def test_two_replicas_one_step_equals_full_batch_step(hip_lib):
     for p in procs:
         p.start()
     res = {}
-    for _ in range(2):
-        rank, loss, params, grads = q.get(timeout=300)
-        res[rank] = (loss, [torch.from_numpy(a) for a in params], [torch.from_numpy(a) for a in grads])
-    for p in procs:
-        p.join(timeout=120)
-        assert p.exitcode == 0
+    try:
+        for _ in range(2):
+            rank, loss, params, grads = q.get(timeout=300)
+            res[rank] = (loss, [torch.from_numpy(a) for a in params], [torch.from_numpy(a) for a in grads])
+        for p in procs:
+            p.join(timeout=120)
+            assert p.exitcode == 0
+    finally:
+        _reap(procs)
     # replicas identical after the step (same averaged gradient, same update)
     for a, b in zip(res[0][1], res[1][1]):
         assert torch.equal(a, b)
