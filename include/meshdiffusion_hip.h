@@ -12,7 +12,8 @@
  *     pointers owned by the caller (PyTorch allocator); the library never
  *     allocates, frees or retains device memory.
  *   - every call is asynchronous on `stream` (a hipStream_t passed as void*),
- *     re-entrant and stateless.
+ *     re-entrant and stateless (the one exception is md_wgrad_set_debug, a
+ *     process-wide profiling knob that production code never calls).
  *   - return value: 0 = ok, negative = MD_ERR_*, positive = hipError_t.
  *
  * Device tensor layouts (see DESIGN.md "Data layout in HBM")
@@ -23,6 +24,9 @@
  *                                                   plane 1 = lo = bf16(x - hi))
  *   WPK   : bf16    [rows/NT][K/KC][taps][KC/8][2][NT][8]  packed split-bf16
  *                                                   weight tiles (one tile = one LDS image)
+ *   PB16  : bf16    [guard + Pp + guard][ceil(B/8)][2][C][8 samples]   position-major, sample-blocked
+ *                                                   split-bf16 on the zero-padded grid (Pp positions)
+ *                                                   with zeroed guard positions: operands of md_wgrad
  */
 #ifndef MESHDIFFUSION_HIP_H
 #define MESHDIFFUSION_HIP_H
