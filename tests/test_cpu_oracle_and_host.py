@@ -286,3 +286,31 @@ def test_graft_entry_build_runs_without_a_gpu():
     import __graft_entry__
     path = __graft_entry__.build()
     assert os.path.exists(path) and path.endswith("libmeshdiffusion_hip.so")
+
+
+def test_obj_round_trip_and_tet_to_grid(tmp_path):
+    """Host data formats around the hot path: OBJ writer (eval.py:436-440) and the dmt dict -> grid scatter
+    (data/tets_to_3dgrid.py:7-15), which is the inverse of the gather the mesher / cond_gen do."""
+    from meshdiffusion_amd import mesh_export
+    from meshdiffusion_amd.dmtet import tet_vertices_to_grid_index
+    g = torch.Generator().manual_seed(3)
+    verts = torch.randn((17, 3), generator=g)
+    faces = torch.randint(0, 17, (25, 3), generator=g)
+    p = tmp_path / "m.obj"
+    mesh_export.save_obj(p, verts, faces)
+    v2, f2 = mesh_export.load_obj(p)
+    assert np.array_equal(f2, faces.numpy()) and np.abs(v2 - verts.numpy()).max() < 1e-6
+    assert open(p).read().splitlines()[0].startswith("v ") and "f 0 " not in open(p).read()   # 1-based faces
+    tet = np.load(os.path.join(GOLD, "64_tets_cropped.npz"))
+    idx = tet_vertices_to_grid_index(tet["vertices"])
+    n = idx.shape[0]
+    sdf, deform = torch.randn(n, generator=g), torch.rand((n, 3), generator=g) - 0.5
+    grid = mesh_export.tet_to_grid(idx, sdf.unsqueeze(-1), deform, 64)
+    assert tuple(grid.shape) == (4, 64, 64, 64)
+    assert torch.equal(grid[0, idx[:, 0], idx[:, 1], idx[:, 2]], sdf)
+    assert torch.equal(grid[1:, idx[:, 0], idx[:, 1], idx[:, 2]].transpose(0, 1), deform)
+    assert int((grid[0] != 0).sum()) == n                     # nothing outside the tet-grid vertices
+    d = tmp_path / "dicts"; d.mkdir()
+    torch.save({"sdf": sdf, "deform": deform}, d / "dmt_dict_00003.pt")
+    out = mesh_export.dicts_to_grids(tet["vertices"], str(d), str(tmp_path / "grids"), 64, range(5))
+    assert len(out) == 1 and torch.equal(torch.load(out[0]), grid)
