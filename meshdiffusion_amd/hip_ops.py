@@ -16,7 +16,7 @@ from ._lib import (A_PACKED, A_S16B, PREC_BF16X3, PREC_FP16X2, CFG_C3_128, CFG_C
 
 
 CFG_ABL1, CFG_ABL2, CFG_ABL3, CFG_ABL4, CFG_ABL5 = 101, 102, 103, 104, 105
-CFG_F1, CFG_F3, CFG_F4, CFG_F6, CFG_F7, CFG_F8 = 111, 113, 114, 116, 117, 118   # ablations of the dedicated kernel  # timing-only ablation kernels (tools/bench_conv.py)
+CFG_F1, CFG_F3, CFG_F4, CFG_F6, CFG_F7, CFG_F8 = 111, 113, 114, 116, 117, 118   # timing-only ablations of the dedicated kernel (MD_BUILD_ABLATIONS=1)
 DEBUG_ACT_FP16 = 2 if os.environ.get("MD_DEBUG_ACT_FP16") == "1" else 0   # precision experiment only
 # Arithmetic of the dedicated 3x3x3 conv kernel: "bf16x3" (default; ~1e-5 per U-Net evaluation) or "fp16x2"
 # (weights split fp16, activations one fp16; ~1e-3 per evaluation, 7e-5 after the 999-step sampler).
