@@ -189,6 +189,7 @@ def main():
         cpu = None
         if world == 1 and not a.no_cpu_baseline:
             cpu = cpu_baseline(sd_cpu, cfg, synth)
+        hbm_kernels = hbm_bound_kernels(dev, B) if world == 1 else None
         line = {
             "metric": "denoise steps/sec on 64^3x4 DMTet grids (sample-steps/s = n_gpus*batch*steps/wall)",
             "value": round(value, 3), "unit": "sample-steps/s", "n_gpus": world, "steps": a.steps,
@@ -200,12 +201,47 @@ def main():
                        "batch_per_gpu": B, "grid": [cfg.data.num_channels, R, R, R],
                        "sharding": "independent sample shards per GPU, no data-path collective",
                        "launch": "hipGraph replay" if a.graph else "eager launches through the C ABI"},
-            "roofline": roof, "whole_step": whole, "cpu_baseline": cpu, "fast_mode": fast, "setup_s": round(t_setup, 1),
+            "roofline": roof, "whole_step": whole, "hbm_bound_kernels": hbm_kernels, "cpu_baseline": cpu, "fast_mode": fast,
+            "setup_s": round(t_setup, 1),
         }
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def hbm_bound_kernels(dev, B):
+    """The step's HBM-bound kernels (GroupNorm statistics / apply: ~10 % of the step) timed on their own, outside the
+    timed region, at the dominant shape (128 channels, 64^3, this batch): algorithmic bytes / HIP-event time vs the
+    8 TB/s HBM peak."""
+    import torch
+    from meshdiffusion_amd import hip_ops as ops
+    C_, S_ = 128, 64
+    P_ = S_ ** 3
+    x = torch.randn((B, C_ // 8, P_, 8), device=dev)
+    gamma, beta = torch.ones(C_, device=dev), torch.zeros(C_, device=dev)
+    fuse, ops.FUSE_GN_STATS = ops.FUSE_GN_STATS, False
+    try:
+        prm = ops.gn_params([(x, C_)], gamma, beta, B, P_)
+        out = ops.s16b_empty(B, C_, P_, dev)
+        n = B * C_ * P_
+        res = {}
+        for name, fn, nbytes in (("md_gn_stats", lambda: ops.gn_params([(x, C_)], gamma, beta, B, P_), 4 * n),
+                                 ("md_gn_apply", lambda: ops.gn_apply([(x, C_)], prm, B, P_, out=out), 8 * n)):
+            fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            gbs = nbytes / (e0.elapsed_time(e1) / 10 * 1e-3) / 1e9
+            res[name] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                         "frac": round(gbs / PEAK_HBM_GBS, 3), "algorithmic_bytes_per_launch": nbytes}
+        return res
+    finally:
+        ops.FUSE_GN_STATS = fuse
 
 
 def dry_run(a, rank, world):
