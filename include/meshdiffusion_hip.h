@@ -42,7 +42,7 @@ extern "C" {
 #define MD_ERR_UNSUPPORTED (-2)
 #define MD_ERR_NO_DEVICE (-3)
 
-#define MD_ABI_VERSION 3
+#define MD_ABI_VERSION 4
 
 /* ---- tile configurations of md_gemm_conv (compile-time instantiations) ---- */
 enum {
@@ -282,8 +282,14 @@ int md_adam_ema_step(float* p, const float* g, float* m, float* v, float* ema, i
  */
 int64_t md_pb16_bytes(int32_t batch, int32_t C, int32_t D, int32_t H, int32_t W, int32_t guard, int32_t pad);
 int md_to_pb16(const void* src, void* out, int32_t batch, int32_t C, int32_t c_src, int32_t D, int32_t H, int32_t W,
-               int32_t guard, int32_t pad, int32_t mode, int32_t up, int32_t stuff, void* stream);
-               /* channels >= c_src are zero; pad = halo of the grid: 1 (3x3x3, 1x1x1 consumers) or 2 (5x5x5) */
+               int32_t guard, int32_t pad, int32_t mode, int32_t up, int32_t stuff, int32_t zsplit, int32_t zhalo,
+               void* stream);
+               /* channels >= c_src are zero; pad = halo of the grid: 1 (3x3x3, 1x1x1 consumers) or 2 (5x5x5).
+                * zsplit in {1,2,4,8}: each sample is cut into zsplit z-slabs of D planes (whole depth D*zsplit) and the
+                * slabs become the "samples" of the sample blocks (batch*zsplit virtual samples), so that batches below 8
+                * still fill the 8-sample k-groups of md_wgrad; zhalo = 1 (activation operand): z-halo planes hold the
+                * neighbouring slab's data, zhalo = 0 (dY operand): they are zero.  md_pb16_bytes / md_wgrad then take
+                * batch*zsplit and the slab dims (D, H, W). */
 int md_wgrad_finish(const float* g, float* dw, int32_t rows, int32_t cols, int32_t cols_alloc, int32_t ntap,
                     int32_t tap0, int64_t s_row, int64_t s_k, int64_t s_tap, void* stream);
 /*
@@ -292,7 +298,8 @@ int md_wgrad_finish(const float* g, float* dw, int32_t rows, int32_t cols, int32
  * p = k/2), or the single tap of a 1x1x1 layer (taps = 1, p = 1) -- autograd of nn.Conv3d (layers.py:118-124,
  * ddpm_res128.py:90-92,132) / NIN (layers.py:573-582).
  * dy_pb / act_pb: PB16 tensors from md_to_pb16 (pad = p) with a_ch / b_ch channels (multiples of 8) on the same cubic
- * grid and `guard` >= p((D+2p)^2 + (D+2p) + 1) + 10; rows <= a_ch, cols <= b_ch are the valid co / ci.  bf16x3 MFMA, fp32
+ * grid (H = W; D may be a z-slab depth, see md_to_pb16) and `guard` >= p((H+2p)^2 + (H+2p) + 1) + 10; rows <= a_ch,
+ * cols <= b_ch are the valid co / ci.  bf16x3 MFMA, fp32
  * accumulate; the contraction is split into `ksplit` position ranges whose partial sums live in `workspace`
  * (md_wgrad_workspace_bytes) and are reduced in a fixed order, so results are run-to-run identical.
  */

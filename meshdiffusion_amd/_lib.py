@@ -39,7 +39,7 @@ class MdGemmConvArgs(C.Structure):
     ]
 
 
-ABI_VERSION = 3      # MD_ABI_VERSION of include/meshdiffusion_hip.h this host code was written against
+ABI_VERSION = 4      # MD_ABI_VERSION of include/meshdiffusion_hip.h this host code was written against
 _P, _I32, _I64, _F, _U64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint64
 
 # name -> (restype, argtypes); exactly the entry points of include/meshdiffusion_hip.h
@@ -73,7 +73,7 @@ SIGNATURES = {
     "md_grad_sqnorm": (C.c_int, [_P, _I64, _P, _P]),
     "md_adam_ema_step": (C.c_int, [_P, _P, _P, _P, _P, _I64, _F, _F, _F, _F, _F, _I32, _F, _P, _F, _P]),
     "md_pb16_bytes": (_I64, [_I32, _I32, _I32, _I32, _I32, _I32, _I32]),
-    "md_to_pb16": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P]),
+    "md_to_pb16": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P]),
     "md_wgrad_finish": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _I32, _I64, _I64, _I64, _P]),
     "md_wgrad_set_debug": (None, [_I32]),
     "md_wgrad_workspace_bytes": (_I64, [_I32, _I32, _I32, _I32]),

@@ -18,15 +18,23 @@
 // One thread = one (padded position, sample block, group of 8 channels): consecutive lanes take consecutive positions,
 // so each of the 8 per-sample loads of a wave covers 64 x 32 contiguous bytes of the source, and every lane writes the
 // two full 128-byte lines [8 channels][8 samples] (hi / lo plane) of its position.
+//
+// zsplit > 1 (small batches): every sample is cut into `zsplit` z-slabs of D planes and each slab takes one of the 8
+// slots of a sample block ("virtual samples" v = b * zsplit + slab), so a batch of 1 fills the MFMA k-group with 8
+// slabs instead of 1 sample + 7 zeros.  The weight gradient is a sum over positions, so summing over slabs is exact
+// provided the ACTIVATION operand's z-halo planes hold the neighbouring slab's data (zhalo = 1) while the dY operand's
+// stay zero (zhalo = 0: each output position belongs to exactly one slab).  D is the slab depth, Dfull = D * zsplit.
 __global__ __launch_bounds__(256) void md_to_pb16_kernel(const void* __restrict__ src, uint16_t* __restrict__ out, int B, int C,
                                                          int Cs, int D, int H, int W, int guard, int mode, int up, int stuff,
-                                                         int pad) {
+                                                         int pad, int zsplit, int zhalo) {
   const int Dp = D + 2 * pad, Hp = H + 2 * pad, Wp = W + 2 * pad;
   const int64_t Pp = (int64_t)Dp * Hp * Wp;
-  const int bg_n = (B + 7) / 8;   // a partial last block of 8 samples is zero filled
+  const int VB = B * zsplit;
+  const int bg_n = (VB + 7) / 8;   // a partial last block of 8 (virtual) samples is zero filled
   const int cg_n = C / 8;
   const int64_t total = Pp * bg_n * cg_n;
-  const int Ds = (up || stuff) ? D / 2 : D, Hs = (up || stuff) ? H / 2 : H, Ws = (up || stuff) ? W / 2 : W;
+  const int Dfull = D * zsplit;
+  const int Ds = (up || stuff) ? Dfull / 2 : Dfull, Hs = (up || stuff) ? H / 2 : H, Ws = (up || stuff) ? W / 2 : W;
   const int64_t Ps = (int64_t)Ds * Hs * Ws;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t pp = i % Pp;
@@ -38,16 +46,19 @@ __global__ __launch_bounds__(256) void md_to_pb16_kernel(const void* __restrict_
     for (int k = 0; k < 8; ++k)
 #pragma unroll
       for (int e = 0; e < 8; ++e) { hi[k][e] = 0; lo[k][e] = 0; }
-    bool inb = (px >= 0) & (px < W) & (py >= 0) & (py < H) & (pz >= 0) & (pz < D) & (cg * 8 < Cs);
-    int sx = px, sy = py, sz = pz;
-    if (up) { sx >>= 1; sy >>= 1; sz >>= 1; }
-    if (stuff) { inb = inb & (px & 1) & (py & 1) & (pz & 1); sx >>= 1; sy >>= 1; sz >>= 1; }
-    if (inb) {
-      const int64_t sp = ((int64_t)sz * Hs + sy) * Ws + sx;
+    const bool inxy = (px >= 0) & (px < W) & (py >= 0) & (py < H) & (cg * 8 < Cs) & (zhalo || ((pz >= 0) & (pz < D)));
+    if (inxy) {
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
-        const int b = bg * 8 + k;
-        if (b >= B) break;
+        const int v = bg * 8 + k;
+        if (v >= VB) break;
+        const int b = v / zsplit, gz = (v - b * zsplit) * D + pz;   // plane of the whole sample
+        bool inb = (gz >= 0) & (gz < Dfull);
+        int sx = px, sy = py, sz = gz;
+        if (up) { sx >>= 1; sy >>= 1; sz >>= 1; }
+        if (stuff) { inb = inb & (px & 1) & (py & 1) & (gz & 1); sx >>= 1; sy >>= 1; sz >>= 1; }
+        if (!inb) continue;
+        const int64_t sp = ((int64_t)sz * Hs + sy) * Ws + sx;
         if (mode == 0) {
           const f32x4* s4 = (const f32x4*)((const float*)src + (((int64_t)b * (Cs / 8) + cg) * Ps + sp) * 8);
           const f32x4 v0 = s4[0], v1 = s4[1];
@@ -80,13 +91,15 @@ extern "C" int64_t md_pb16_bytes(int32_t batch, int32_t C, int32_t D, int32_t H,
 }
 
 extern "C" int md_to_pb16(const void* src, void* out, int32_t batch, int32_t C, int32_t c_src, int32_t D, int32_t H,
-                          int32_t W, int32_t guard, int32_t pad, int32_t mode, int32_t up, int32_t stuff, void* stream) {
-  if (!src || !out || md_pb16_bytes(batch, C, D, H, W, guard, pad) < 0 || (C % 8) || (c_src % 8) || c_src <= 0 || c_src > C ||
+                          int32_t W, int32_t guard, int32_t pad, int32_t mode, int32_t up, int32_t stuff, int32_t zsplit,
+                          int32_t zhalo, void* stream) {
+  if (zsplit < 1 || zsplit > 8 || (zsplit & (zsplit - 1))) return MD_ERR_BAD_ARG;
+  if (!src || !out || md_pb16_bytes(batch * zsplit, C, D, H, W, guard, pad) < 0 || (C % 8) || (c_src % 8) || c_src <= 0 || c_src > C ||
       mode < 0 || mode > 1)
     return MD_ERR_BAD_ARG;
-  if ((up || stuff) && ((D | H | W) & 1)) return MD_ERR_BAD_ARG;
+  if ((up || stuff) && (((D * zsplit) | H | W) & 1)) return MD_ERR_BAD_ARG;
   // the kernel writes every position of the padded grid (zeros on the halo); only the two guards need clearing
-  const int64_t pos_bytes = (int64_t)((batch + 7) / 8) * 2 * C * 8 * 2;
+  const int64_t pos_bytes = (int64_t)((batch * zsplit + 7) / 8) * 2 * C * 8 * 2;
   const int64_t Pp = (int64_t)(D + 2 * pad) * (H + 2 * pad) * (W + 2 * pad);
   if (guard > 0) {
     hipError_t e = hipMemsetAsync(out, 0, (size_t)(guard * pos_bytes), (hipStream_t)stream);
@@ -94,12 +107,12 @@ extern "C" int md_to_pb16(const void* src, void* out, int32_t batch, int32_t C, 
       e = hipMemsetAsync((char*)out + (guard + Pp) * pos_bytes, 0, (size_t)(guard * pos_bytes), (hipStream_t)stream);
     if (e != hipSuccess) return (int)e;
   }
-  const int64_t total = Pp * ((batch + 7) / 8) * (C / 8);
+  const int64_t total = Pp * ((batch * zsplit + 7) / 8) * (C / 8);
   int blocks = (int)((total + 255) / 256);
   if (blocks > 65536) blocks = 65536;
   MD_HIP_CLEAR_ERROR();
   hipLaunchKernelGGL(md_to_pb16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, (uint16_t*)out,
-                     batch, C, c_src, D, H, W, guard, mode, up, stuff, pad);
+                     batch, C, c_src, D, H, W, guard, mode, up, stuff, pad, zsplit, zhalo);
   MD_HIP_CHECK_LAUNCH();
   return MD_OK;
 }

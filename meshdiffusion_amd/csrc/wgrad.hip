@@ -33,7 +33,8 @@ struct WgArgs {
   int co_tiles, ci_tiles, ngroups, ksplit;
   int rows, cols;        // valid co / ci (waves whose whole sub-tile lies outside skip their MFMAs)
   int bgn;               // B / 8
-  int S;                 // grid edge; the padded edge is S + 2 pad
+  int S;                 // grid edge in y and x; the padded edge is S + 2 pad
+  int Dz;                // grid depth (z): S, or S / zsplit when samples are cut into z-slabs (md_to_pb16)
   int pad;               // halo of the PB16 grids: 1 (3x3x3, 1x1x1) or 2 (5x5x5)
   int ksz;               // 1, 3 or 5
   int spr;               // stages per grid row = ceil(S / 8)
@@ -43,20 +44,20 @@ struct WgArgs {
 // group bg = row (z, y), x-segment seg -> padded positions p0 .. p0+7, p0 = ((z+1)(S+2) + y+1)(S+2) + 1 + 8 seg.
 struct WgCursor {
   int bg, z, y, seg;
-  __device__ void init(int st, int S, int spr) {
+  __device__ void init(int st, int S, int Dz, int spr) {
     seg = st % spr;
     int row = st / spr;
     y = row % S;
     row /= S;
-    z = row % S;
-    bg = row / S;
+    z = row % Dz;
+    bg = row / Dz;
   }
-  __device__ void next(int S, int spr) {
+  __device__ void next(int S, int Dz, int spr) {
     if (++seg == spr) {
       seg = 0;
       if (++y == S) {
         y = 0;
-        if (++z == S) { z = 0; ++bg; }
+        if (++z == Dz) { z = 0; ++bg; }
       }
     }
   }
@@ -128,7 +129,7 @@ __global__ __launch_bounds__(WG_THREADS) void md_wgrad_kernel(const WgArgs g) {
   const int tci = (u / g.ngroups) % g.ci_tiles, tco = u / (g.ngroups * g.ci_tiles);
   const int co0 = tco * WG_TILE, ci0 = tci * WG_TILE;
   const int S = g.S, sp = S + 2 * g.pad;
-  const int total = g.bgn * S * S * g.spr;
+  const int total = g.bgn * g.Dz * S * g.spr;
   const int per = (total + g.ksplit - 1) / g.ksplit;
   const int st0 = min(total, r * per), st1 = min(total, st0 + per);
   int64_t off = 0;
@@ -160,7 +161,7 @@ __global__ __launch_bounds__(WG_THREADS) void md_wgrad_kernel(const WgArgs g) {
   const int frow = tid & (WG_TILE - 1), fpl = (tid >> 7) & 1, fpos = tid >> 8;   // v = tid + i*512: pos = fpos + 2 i
   const bool a_ok = co0 + frow < g.a_ch, b_ok = ci0 + frow < g.b_ch;
   WgCursor cur;
-  cur.init(st0, S, g.spr);
+  cur.init(st0, S, g.Dz, g.spr);
   auto fetch = [&]() {   // the stage `cur` points at
     const int64_t p0 = cur.p0(S, g.pad);
     const int valid = min(WG_STAGE, S - cur.seg * WG_STAGE);
@@ -203,7 +204,7 @@ __global__ __launch_bounds__(WG_THREADS) void md_wgrad_kernel(const WgArgs g) {
   for (; st + 1 < st1; ++st) {
     const int buf = (st - st0) & 1;
     if (!(DBG & 1)) {
-      cur.next(S, g.spr);
+      cur.next(S, g.Dz, g.spr);
       fetch();
     }
     // keep the requests up here: left alone the scheduler sinks them next to their use (the LDS writes below) to
@@ -291,11 +292,11 @@ extern "C" int md_wgrad(const void* dy_pb, const void* act_pb, float* dw, void* 
                         int32_t W, int32_t guard, int32_t taps, int32_t ksplit, int64_t s_row, int64_t s_k, int64_t s_tap,
                         void* stream) {
   if (!dy_pb || !act_pb || !dw || !workspace || batch <= 0 || a_ch <= 0 || b_ch <= 0 || (a_ch % 8) ||
-      (b_ch % 8) || rows <= 0 || rows > a_ch || cols <= 0 || cols > b_ch || D <= 0 || H != D || W != D ||
+      (b_ch % 8) || rows <= 0 || rows > a_ch || cols <= 0 || cols > b_ch || D <= 0 || H <= 0 || W != H ||
       md_wgrad_slots(taps) < 0 || ksplit <= 0)
     return MD_ERR_BAD_ARG;
   const int pad = taps == 125 ? 2 : 1;
-  const int sp = D + 2 * pad;
+  const int sp = H + 2 * pad;   // y / x padded edge (z only sets the number of rows)
   // a stage may run up to 7 positions past the end of its row (masked dY, but the A window is read): stay in the guard
   if (guard < pad * (sp * sp + sp + 1) + WG_STAGE + 2) return MD_ERR_BAD_ARG;
   if (workspace_bytes < md_wgrad_workspace_bytes(rows, cols, taps, ksplit)) return MD_ERR_BAD_ARG;
@@ -311,14 +312,15 @@ extern "C" int md_wgrad(const void* dy_pb, const void* act_pb, float* dw, void* 
   g.ksz = taps == 27 ? 3 : (taps == 125 ? 5 : 1);
   g.ksplit = ksplit;
   g.rows = rows; g.cols = cols;
-  g.S = D;
-  g.spr = (D + WG_STAGE - 1) / WG_STAGE;
+  g.S = H;
+  g.Dz = D;
+  g.spr = (H + WG_STAGE - 1) / WG_STAGE;
   const int units = g.co_tiles * g.ci_tiles * g.ngroups;
   const int64_t blocks = ((int64_t)ksplit * units + 255) / 256 * 256;
   if (blocks > 0x7fffffff) return MD_ERR_BAD_ARG;
   MD_HIP_CLEAR_ERROR();
   // FULL: no predication anywhere -- whole 128-channel tiles on both operands and whole 8-position stages
-  const bool full = (rows % WG_TILE) == 0 && (cols % WG_TILE) == 0 && (D % WG_STAGE) == 0;
+  const bool full = (rows % WG_TILE) == 0 && (cols % WG_TILE) == 0 && (H % WG_STAGE) == 0;
   const dim3 grid((unsigned)blocks), blk(WG_THREADS);
   const hipStream_t hs = (hipStream_t)stream;
   if (taps != 1 && full) {

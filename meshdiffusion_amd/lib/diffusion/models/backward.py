@@ -9,8 +9,9 @@ FLOP/byte path (slicing a concatenated gradient, adding two gradients, the [B,51
 torch tensor ops on the device.
 
 Gradients are F32B tensors shaped like the forward activations; parameter gradients accumulate into `.grad`.
-Any batch size works; the wgrad contraction blocks 8 samples per MFMA k-group, so a batch that is not a multiple
-of 8 pays for the zero-filled remainder of its last block (B = 6 costs the wgrad time of B = 8).
+Any batch size works.  The wgrad contraction blocks 8 samples per MFMA k-group; batches of 1, 2 or 4 fill the block
+with z-slabs of each sample instead (`zsplit_for`: the sum over positions is a sum over slabs), other batches pay for
+the zero-filled remainder of their last block (B = 6 costs the wgrad time of B = 8).
 """
 import torch
 
@@ -42,18 +43,30 @@ def _guard(S, pad=1):
     return ((g + 3) // 4) * 4
 
 
-def to_pb16(src, B, C, S, mode, up=0, stuff=0, c_src=None, pad=1):
+def zsplit_for(B, S):
+    """z-slabs per sample so that B * zsplit virtual samples fill the 8-sample blocks of the wgrad operands."""
+    zs = 1
+    while B * zs * 2 <= 8 and S % (zs * 2) == 0:
+        zs *= 2
+    return zs
+
+
+def to_pb16(src, B, C, S, mode, up=0, stuff=0, c_src=None, pad=1, zhalo=True):
     """src: F32B (mode 0) or S16B (mode 1) on an S^3 grid (or (S/2)^3 when up/stuff) -> PB16 on the padded S^3 grid.
     c_src: channels actually present in `src` (the PB16 tensor is zero for channels c_src..C-1).
-    pad: halo of the padded grid = kernel size // 2 of the conv whose wgrad consumes it (1 for NIN)."""
+    pad: halo of the padded grid = kernel size // 2 of the conv whose wgrad consumes it (1 for NIN).
+    zhalo: True for an activation operand, False for a dY operand (see md_to_pb16: z-slab virtual samples)."""
     lib = _lib.load()
     g = _guard(S, pad)
-    nbytes = lib.md_pb16_bytes(B, C, S, S, S, g, pad)
+    zs = zsplit_for(B, S)
+    VB, Dz = B * zs, S // zs
+    nbytes = lib.md_pb16_bytes(VB, C, Dz, S, S, g, pad)
     if nbytes <= 0:
         raise _lib.MeshDiffusionHipError("md_pb16_bytes failed")
-    out = torch.empty(nbytes // 2 + 4 * 2 * C * 8 * ((B + 7) // 8), dtype=torch.bfloat16, device=src.device)
+    out = torch.empty(nbytes // 2 + 4 * 2 * C * 8 * ((VB + 7) // 8), dtype=torch.bfloat16, device=src.device)
     out[nbytes // 2:].zero_()      # tail so that K rounded up to 4 positions stays in bounds
-    check(lib.md_to_pb16(_ptr(src), _ptr(out), B, C, C if c_src is None else c_src, S, S, S, g, pad, mode, up, stuff,
+    check(lib.md_to_pb16(_ptr(src), _ptr(out), B, C, C if c_src is None else c_src, Dz, S, S, g, pad, mode, up, stuff,
+                         zs, 1 if zhalo else 0,
                          _stream()), "md_to_pb16")
     return out
 
@@ -65,12 +78,14 @@ def wgrad(dy_pb, act_pb, B, co, ci, S, taps, dw, s_row, s_k, s_tap, a_ch=None, b
     g = _guard(S, 2 if taps == 125 else 1)
     a_ch = co if a_ch is None else a_ch
     b_ch = ci if b_ch is None else b_ch
-    stages = ((B + 7) // 8) * S * S * ((S + 7) // 8)
+    zs = zsplit_for(B, S)
+    VB, Dz = B * zs, S // zs
+    stages = ((VB + 7) // 8) * Dz * S * ((S + 7) // 8)
     units = ((co + 127) // 128) * ((ci + 127) // 128) * {125: 50, 27: 9, 1: 1}[taps]
     ksplit = max(1, min(WGRAD_BLOCKS // units, stages // 4))
     nbytes = lib.md_wgrad_workspace_bytes(co, ci, taps, ksplit)
     ws = torch.empty(nbytes // 4, dtype=torch.float32, device=dy_pb.device)
-    check(lib.md_wgrad(_ptr(dy_pb), _ptr(act_pb), _ptr(dw), _ptr(ws), nbytes, B, a_ch, b_ch, co, ci, S, S, S, g, taps,
+    check(lib.md_wgrad(_ptr(dy_pb), _ptr(act_pb), _ptr(dw), _ptr(ws), nbytes, VB, a_ch, b_ch, co, ci, Dz, S, S, g, taps,
                        ksplit, s_row, s_k, s_tap, _stream()), "md_wgrad")
 
 
@@ -165,9 +180,9 @@ def conv3_backward(layer, name, conv, dy, act_s16, B, S_out, ups=0, stride=1, ne
     # weight gradient
     S_fine = S_out * stride
     if stride == 2:
-        dy_pb = to_pb16(dy, B, co_t, S_fine, 0, stuff=1)
+        dy_pb = to_pb16(dy, B, co_t, S_fine, 0, stuff=1, zhalo=False)
     else:
-        dy_pb = to_pb16(dy, B, co_t, S_out, 0, pad=pad)
+        dy_pb = to_pb16(dy, B, co_t, S_out, 0, pad=pad, zhalo=False)
     c_src = act_channels if act_channels is not None else ci      # channels of the S16B operand tensor
     act_pb = to_pb16(act_s16, B, c_src, S_fine, 1, up=ups, pad=pad)
     wgrad(dy_pb, act_pb, B, co, ci, S_fine, taps, _grad_of(conv.weight), ci * taps, taps, 1, a_ch=co_t, b_ch=c_src)
@@ -238,7 +253,7 @@ def nin_backward(nin, dy, xs_s16, B, P, S, need_dx=True, with_bias=True):
     ci, co = nin.W.shape
     if with_bias:
         _grad_of(nin.b).add_(channel_sums(dy, B, co, P).sum(0))
-    dy_pb = to_pb16(dy, B, co, S, 0)
+    dy_pb = to_pb16(dy, B, co, S, 0, zhalo=False)
     wgrad_nin(dy_pb, xs_s16, B, co, ci, S, _grad_of(nin.W))
     del dy_pb
     if not need_dx:
@@ -280,7 +295,7 @@ def attn_backward(blk, sv, dy):
     bsum = channel_sums(dqk, B, 2 * Cc, P).sum(0)
     _grad_of(blk.NIN_0.b).add_(bsum[:Cc]); _grad_of(blk.NIN_1.b).add_(bsum[Cc:])
     dw = torch.zeros_like(wqk)
-    dqk_pb = to_pb16(dqk, B, 2 * Cc, S, 0)
+    dqk_pb = to_pb16(dqk, B, 2 * Cc, S, 0, zhalo=False)
     wgrad_nin(dqk_pb, hN, B, 2 * Cc, Cc, S, dw)
     _grad_of(blk.NIN_0.W).add_(dw[:, :Cc]); _grad_of(blk.NIN_1.W).add_(dw[:, Cc:])
     del dqk_pb
@@ -288,7 +303,7 @@ def attn_backward(blk, sv, dy):
     pw = ops.PackedWeight(wqk, "rows", cfg, wqk.device)
     d_h = layers.run_gemm(pw, split_f32b(dqk, B, 2 * Cc, P), B, P)
     # v = NIN_2(h) (bias handled above)
-    dv_pb = to_pb16(dV, B, Cc, S, 0)
+    dv_pb = to_pb16(dV, B, Cc, S, 0, zhalo=False)
     wgrad_nin(dv_pb, hN, B, Cc, Cc, S, _grad_of(blk.NIN_2.W))
     del dv_pb
     pw2 = blk.NIN_2._cached(f"dgrad{cfg}", [blk.NIN_2.W], lambda: ops.PackedWeight(blk.NIN_2.W, "rows", cfg, blk.NIN_2.W.device))

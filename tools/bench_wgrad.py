@@ -30,7 +30,7 @@ def main():
         P = S ** 3
         dy = torch.randn((B, co // 8, P, 8), device=dev)
         act = torch.randn((B, ci // 8, P, 8), device=dev)
-        dy_pb = bw.to_pb16(dy, B, co, S, 0)
+        dy_pb = bw.to_pb16(dy, B, co, S, 0, zhalo=False)
         act_pb = bw.to_pb16(act, B, ci, S, 0)
         dw = torch.zeros((co, ci, taps), device=dev)
         bw.wgrad(dy_pb, act_pb, B, co, ci, S, taps, dw, ci * taps, taps, 1)
