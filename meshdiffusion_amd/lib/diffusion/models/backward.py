@@ -9,9 +9,9 @@ FLOP/byte path (slicing a concatenated gradient, adding two gradients, the [B,51
 torch tensor ops on the device.
 
 Gradients are F32B tensors shaped like the forward activations; parameter gradients accumulate into `.grad`.
-Any batch size works.  The wgrad contraction blocks 8 samples per MFMA k-group; batches of 1, 2 or 4 fill the block
-with z-slabs of each sample instead (`zsplit_for`: the sum over positions is a sum over slabs), other batches pay for
-the zero-filled remainder of their last block (B = 6 costs the wgrad time of B = 8).
+Any batch size works.  The wgrad contraction blocks 8 samples per MFMA k-group; a batch that is not a
+multiple of 8 fills its blocks with z-slabs of each sample instead (`zsplit_for`: 8 / gcd(B, 8) slabs; the sum over
+positions is a sum over slabs), so no MFMA work is spent on zero padding.
 """
 import torch
 
@@ -44,10 +44,12 @@ def _guard(S, pad=1):
 
 
 def zsplit_for(B, S):
-    """z-slabs per sample so that B * zsplit virtual samples fill the 8-sample blocks of the wgrad operands."""
-    zs = 1
-    while B * zs * 2 <= 8 and S % (zs * 2) == 0:
-        zs *= 2
+    """z-slabs per sample so that B * zsplit virtual samples fill whole 8-sample blocks of the wgrad operands:
+    8 / gcd(B, 8) (1 for multiples of 8, 4 for B = 6, 8 for odd B), as far as the grid depth S divides."""
+    import math
+    zs = 8 // math.gcd(int(B), 8)
+    while zs > 1 and S % zs:
+        zs //= 2
     return zs
 
 
