@@ -131,3 +131,27 @@ def test_cli_train_mode_runs_checkpoints_and_resumes(hip_lib, tmp_path, monkeypa
     ck2 = torch.load(wd / "checkpoints" / "checkpoint_5.pth", weights_only=False)
     assert ck2["step"] == 6 and not torch.equal(ck2["model"]["module.all_modules.2.weight"], w0)
     assert ck2["ema"]["num_updates"] == 6
+
+
+def test_bench_contract_on_gpu(hip_lib):
+    """`python bench.py` (one GPU): exactly one JSON line with the driver's keys, the roofline of the dominant kernel
+    measured from in-region HIP events, and the HBM-bound kernel figures (short run: no CPU baseline / fast mode)."""
+    import json
+    import subprocess
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+                          "--no-cpu-baseline", "--no-fast-mode"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True
+    assert d["scaling"] == "weak" and d["vs_baseline"] is None and "workload" in d["config"]
+    assert abs(d["value"] - 8 * 2 / (d["ms_per_step"] * 2e-3)) / d["value"] < 1e-3
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and 0.05 < r["frac"] < 1 / 3 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert r["launches"] == 2 * 60            # 60 launches of the dedicated conv kernel per res64 U-Net evaluation
+    h = d["hbm_bound_kernels"]
+    assert h["md_gn_apply"]["bound"] == "hbm" and 0.3 < h["md_gn_apply"]["frac"] < 1.0
