@@ -93,9 +93,16 @@ class PackedWeight:
         nt, kc = CFG_NT_KC[cfg]
         w = w.detach().to(device=device, dtype=torch.float32).contiguous()
         _require_cuda(w, "weight")
+        base_off = 0
         if kind == "conv":  # [Co][Ci][k][k][k]
             rows, kdim, taps = w.shape[0], w.shape[1], w.shape[2] * w.shape[3] * w.shape[4]
             s_row, s_k, s_tap = kdim * taps, taps, 1
+        elif kind == "conv_dgrad":  # the data-gradient conv of [Co][Ci][k][k][k]: W'[ci][co][t] = W[co][ci][T-1-t],
+            # read in place through strides (tap stride -1 from the last tap): no flipped / transposed copy
+            taps = w.shape[2] * w.shape[3] * w.shape[4]
+            rows, kdim = w.shape[1], w.shape[0]
+            s_row, s_k, s_tap = taps, rows * taps, -1
+            base_off = taps - 1
         elif kind == "nin":  # NIN W [Ci][Co]
             rows, kdim, taps = w.shape[1], w.shape[0], 1
             s_row, s_k, s_tap = 1, rows, 0
@@ -110,7 +117,8 @@ class PackedWeight:
         if nbytes <= 0:
             raise _lib.MeshDiffusionHipError("md_packed_weight_bytes failed")
         self.data = torch.empty(nbytes // 2, dtype=torch.bfloat16, device=device)
-        check(lib.md_pack_weights(_ptr(w), _ptr(self.data), rows, kdim, taps, s_row, s_k, s_tap, nt, kc,
+        wp = C.c_void_p(w.data_ptr() + 4 * base_off)
+        check(lib.md_pack_weights(wp, _ptr(self.data), rows, kdim, taps, s_row, s_k, s_tap, nt, kc,
                                   prec, _stream()), "md_pack_weights")
 
 

@@ -158,8 +158,7 @@ def gn_backward(parts, dy, params, gn, B, P, silu, d_into=None, drop=None):
 def dgrad_weight(layer, name, conv, cfg):
     """WPK tiles of the data-gradient conv: W'[ci][co][k] = W[co][ci][flip(k)]."""
     def build():
-        w = conv.weight.detach().flip(2, 3, 4).transpose(0, 1).contiguous()
-        return ops.PackedWeight(w, "conv", cfg, w.device)
+        return ops.PackedWeight(conv.weight, "conv_dgrad", cfg, conv.weight.device)
     return layer._cached(f"{name}/dgrad{cfg}", [conv.weight], build)
 
 
