@@ -1,0 +1,19 @@
+/* A plain C host of libmeshdiffusion_hip.so: proves that include/meshdiffusion_hip.h is valid C99 and that the library
+ * links and answers without Python or torch (argument validation only -- no device work, so it runs without a GPU). */
+#include <stdio.h>
+#include <stddef.h>
+#include "meshdiffusion_hip.h"
+
+int main(void) {
+  MdGemmConvArgs a;
+  int fails = 0;
+  if (md_abi_version() != MD_ABI_VERSION) { printf("abi %d != %d\n", md_abi_version(), MD_ABI_VERSION); ++fails; }
+  if (md_packed_weight_bytes(128, 128, 27, 128, 32) != (int64_t)27 * 4 * 4 * 2 * 128 * 16) { printf("packed bytes\n"); ++fails; }
+  if (md_packed_weight_bytes(0, 128, 27, 128, 32) != MD_ERR_BAD_ARG) { printf("bad arg not rejected\n"); ++fails; }
+  if (md_wgrad_workspace_bytes(128, 128, 27, 28) != (int64_t)28 * 27 * 128 * 128 * 4) { printf("wgrad ws\n"); ++fails; }
+  if (md_pb16_bytes(8, 128, 64, 64, 64, 0, 1) != (int64_t)66 * 66 * 66 * 2 * 128 * 8 * 2) { printf("pb16 bytes\n"); ++fails; }
+  if (md_gemm_conv(NULL, NULL) != MD_ERR_BAD_ARG) { printf("null args\n"); ++fails; }
+  if (md_gn_stats(NULL, NULL, 1, 8, 1, 8, 0, NULL) != MD_ERR_BAD_ARG) { printf("gn_stats null\n"); ++fails; }
+  printf("sizeof(MdGemmConvArgs)=%zu stats@%zu %s\n", sizeof a, offsetof(MdGemmConvArgs, stats), fails ? "FAIL" : "ok");
+  return fails;
+}

@@ -314,3 +314,23 @@ def test_obj_round_trip_and_tet_to_grid(tmp_path):
     torch.save({"sdf": sdf, "deform": deform}, d / "dmt_dict_00003.pt")
     out = mesh_export.dicts_to_grids(tet["vertices"], str(d), str(tmp_path / "grids"), 64, range(5))
     assert len(out) == 1 and torch.equal(torch.load(out[0]), grid)
+
+
+def test_plain_c_host_links_and_runs(tmp_path, hip_lib):
+    """"a C/C++ host links -lmeshdiffusion_hip" -- compile tests/c_abi/host.c as C99 against the header,
+    link it to the built library and run it (argument validation only, no GPU needed)."""
+    import shutil
+    from meshdiffusion_amd import _lib
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no C compiler")
+    exe = str(tmp_path / "host")
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    cmd = [gcc, "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "tests", "c_abi", "host.c"), "-o", exe, "-L", libdir, "-lmeshdiffusion_hip",
+           f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib", "-Wl,--allow-shlib-undefined"]
+    out = subprocess.run(cmd, capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    run = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert run.returncode == 0 and "ok" in run.stdout, run.stdout + run.stderr
+    assert f"sizeof(MdGemmConvArgs)={ctypes.sizeof(_lib.MdGemmConvArgs)}" in run.stdout
