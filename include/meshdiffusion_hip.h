@@ -42,7 +42,7 @@ extern "C" {
 #define MD_ERR_UNSUPPORTED (-2)
 #define MD_ERR_NO_DEVICE (-3)
 
-#define MD_ABI_VERSION 4
+#define MD_ABI_VERSION 5
 
 /* ---- tile configurations of md_gemm_conv (compile-time instantiations) ---- */
 enum {
@@ -315,7 +315,11 @@ int md_gn_bwd_finalize(const double* sums, const float* params, const float* gam
                        float* dbeta, int32_t batch, int32_t c_total, int32_t groups, int64_t P, void* stream);
 int md_gn_bwd_apply(const float* x, const float* dy, const float* params, const float* coef, float* dx, int32_t batch,
                     int32_t C, int64_t P, int32_t c_total, int32_t c_off, int32_t dy_ctotal, int32_t silu,
-                    int32_t accumulate, float drop_p, uint64_t drop_seed, void* stream);
+                    int32_t accumulate, float drop_p, uint64_t drop_seed, const float* residual, float* ch_sums,
+                    void* stream);
+                    /* residual (may be NULL, ignored when accumulate): F32B like dx, dx = residual + gradient (the identity
+                     * shortcut of a ResnetBlock without a separate copy); ch_sums (may be NULL): float [B][c_total],
+                     * += per-(sample, channel) sum of the gradient written for this part (bias / FiLM gradients). */
 int md_channel_sums(const float* x, float* out, int32_t batch, int32_t C, int64_t P, void* stream);
 /* S16B blocked transpose: in [B][R/8][2][Cn][8] -> out [B][Cn/8][2][R][8] (attention backward operands). */
 int md_s16b_transpose(const void* in, void* out, int32_t batch, int32_t R, int32_t Cn, void* stream);

@@ -39,7 +39,7 @@ class MdGemmConvArgs(C.Structure):
     ]
 
 
-ABI_VERSION = 4      # MD_ABI_VERSION of include/meshdiffusion_hip.h this host code was written against
+ABI_VERSION = 5      # MD_ABI_VERSION of include/meshdiffusion_hip.h this host code was written against
 _P, _I32, _I64, _F, _U64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint64
 
 # name -> (restype, argtypes); exactly the entry points of include/meshdiffusion_hip.h
@@ -81,7 +81,7 @@ SIGNATURES = {
                            _I64, _P]),
     "md_gn_bwd_stats": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I64, _I32, _I32, _I32, _I32, _F, _U64, _P]),
     "md_gn_bwd_finalize": (C.c_int, [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I64, _P]),
-    "md_gn_bwd_apply": (C.c_int, [_P, _P, _P, _P, _P, _I32, _I32, _I64, _I32, _I32, _I32, _I32, _I32, _F, _U64, _P]),
+    "md_gn_bwd_apply": (C.c_int, [_P, _P, _P, _P, _P, _I32, _I32, _I64, _I32, _I32, _I32, _I32, _I32, _F, _U64, _P, _P, _P]),
     "md_channel_sums": (C.c_int, [_P, _P, _I32, _I32, _I64, _P]),
     "md_s16b_transpose": (C.c_int, [_P, _P, _I32, _I32, _I32, _P]),
     "md_softmax_keys_bwd": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _F, _P]),

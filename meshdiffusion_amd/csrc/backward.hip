@@ -246,13 +246,16 @@ __global__ __launch_bounds__(GB_BLOCK) void md_gn_bwd_apply_kernel(const float* 
                                                                    const float* __restrict__ params, const float* __restrict__ coef,
                                                                    float* __restrict__ dx, int C, int64_t P, int c_total,
                                                                    int c_off, int dy_ctotal, int silu, int accumulate,
-                                                                   uint32_t thr16, float drop_scale, uint64_t seed) {
+                                                                   uint32_t thr16, float drop_scale, uint64_t seed,
+                                                                   const float* __restrict__ residual, float* __restrict__ ch_sums) {
   const int cg = blockIdx.y, b = blockIdx.z;
   const int tid = threadIdx.x, half = tid & 1;
   const int64_t p0 = (int64_t)blockIdx.x * GB_CHUNK;
   const int64_t xo = (((int64_t)b * (C / 8) + cg) * P) * 8;
   const f32x4* xp = (const f32x4*)(x + xo);
   f32x4* op = (f32x4*)(dx + xo);
+  const f32x4* rp = residual ? (const f32x4*)(residual + xo) : nullptr;
+  float cs[4] = {0.f, 0.f, 0.f, 0.f};
   const f32x4* dp = (const f32x4*)(dy + (((int64_t)b * (dy_ctotal / 8) + (c_off / 8) + cg) * P) * 8);
   float mu[4], a[4], bt[4], r[4], k1[4], k2[4], k3[4];
 #pragma unroll
@@ -274,14 +277,27 @@ __global__ __launch_bounds__(GB_BLOCK) void md_gn_bwd_apply_kernel(const float* 
       }
       f32x4 o = {0.f, 0.f, 0.f, 0.f};
       if (accumulate) o = op[pos * 2 + half];
+      else if (rp) o = rp[pos * 2 + half];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const float xc = xv[e] - mu[e];
         const float z = xc * a[e] + bt[e];
         const float dz = silu ? dv[e] * md_silu_grad(z) : dv[e];
-        o[e] += k1[e] * dz - k2[e] - (xc * r[e]) * k3[e];
+        const float g = k1[e] * dz - k2[e] - (xc * r[e]) * k3[e];
+        o[e] += g;
+        cs[e] += g;
       }
       op[pos * 2 + half] = o;
+    }
+  }
+  if (ch_sums) {   // per-(sample, channel) sums of the GroupNorm input gradient (bias / FiLM gradients of the producer)
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int o = 32; o > 1; o >>= 1) cs[e] += __shfl_xor(cs[e], o, 64);
+    if ((tid & 63) < 2) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) atomicAdd(&ch_sums[(int64_t)b * c_total + c_off + cg * 8 + half * 4 + e], cs[e]);
     }
   }
 }
@@ -311,13 +327,15 @@ extern "C" int md_gn_bwd_finalize(const double* sums, const float* params, const
 
 extern "C" int md_gn_bwd_apply(const float* x, const float* dy, const float* params, const float* coef, float* dx, int32_t batch,
                                int32_t C, int64_t P, int32_t c_total, int32_t c_off, int32_t dy_ctotal, int32_t silu,
-                               int32_t accumulate, float drop_p, uint64_t drop_seed, void* stream) {
+                               int32_t accumulate, float drop_p, uint64_t drop_seed, const float* residual, float* ch_sums,
+                               void* stream) {
   if (!(drop_p >= 0.f && drop_p < 1.f)) return MD_ERR_BAD_ARG;
   if (!x || !dy || !params || !coef || !dx || batch <= 0 || C <= 0 || (C % 8) || (c_off % 8) || c_off + C > c_total) return MD_ERR_BAD_ARG;
   dim3 grid((unsigned)((P + GB_CHUNK - 1) / GB_CHUNK), (unsigned)(C / 8), (unsigned)batch);
   MD_HIP_CLEAR_ERROR();
   hipLaunchKernelGGL(md_gn_bwd_apply_kernel, grid, dim3(GB_BLOCK), 0, (hipStream_t)stream, x, dy, params, coef, dx, C, P, c_total,
-                     c_off, dy_ctotal, silu, accumulate, md_drop_thr16(drop_p), 1.0f / (1.0f - drop_p), (uint64_t)drop_seed);
+                     c_off, dy_ctotal, silu, accumulate, md_drop_thr16(drop_p), 1.0f / (1.0f - drop_p), (uint64_t)drop_seed, residual,
+                     ch_sums);
   MD_HIP_CHECK_LAUNCH();
   return MD_OK;
 }

@@ -114,10 +114,12 @@ def resample(t, B, C, Sc, mode, accumulate_into=None):
 # ---------------------------------------------------------------------------------------------------------
 # GroupNorm (+SiLU) backward over concatenated parts
 # ---------------------------------------------------------------------------------------------------------
-def gn_backward(parts, dy, params, gn, B, P, silu, d_into=None, drop=None):
+def gn_backward(parts, dy, params, gn, B, P, silu, d_into=None, drop=None, residual=None, sums_out=None):
     """parts: forward inputs [(F32B, C)]; dy: F32B [B][Ctot][P]; returns one F32B [B][Ctot][P] gradient
     (written into / accumulated onto `d_into` when given) and accumulates gn.weight/.bias grads.
-    drop=(p, seed): the forward applied dropout after the activation (same mask regenerated here)."""
+    drop=(p, seed): the forward applied dropout after the activation (same mask regenerated here).
+    Single-part extras: residual (F32B): result = residual + gradient (identity shortcut, no separate copy);
+    sums_out (zeroed float [B, Ctot]): += per-(sample, channel) sums of the gradient (bias / FiLM gradients)."""
     lib = _lib.load()
     dp, dseed = (float(drop[0]), int(drop[1])) if drop else (0.0, 0)
     dev = dy.device
@@ -132,6 +134,7 @@ def gn_backward(parts, dy, params, gn, B, P, silu, d_into=None, drop=None):
     check(lib.md_gn_bwd_finalize(_ptr(sums), _ptr(params), _ptr(gn.weight), _ptr(coef), _ptr(_grad_of(gn.weight)),
                                  _ptr(_grad_of(gn.bias)), B, ctot, gn.num_groups, P, _stream()), "md_gn_bwd_finalize")
     acc = d_into is not None
+    assert (residual is None and sums_out is None) or (len(parts) == 1 and not acc)
     outs = []
     off = 0
     dxcat = d_into if acc else ops.f32b_empty(B, ctot, P, dev)
@@ -140,11 +143,13 @@ def gn_backward(parts, dy, params, gn, B, P, silu, d_into=None, drop=None):
         dx_view = dxcat.view(B, ctot // 8, P, 8)[:, off // 8:(off + c) // 8]
         if len(parts) == 1:
             check(lib.md_gn_bwd_apply(_ptr(t), _ptr(dy), _ptr(params), _ptr(coef), _ptr(dxcat), B, c, P, ctot, 0, ctot,
-                                      1 if silu else 0, 1 if acc else 0, dp, dseed, _stream()), "md_gn_bwd_apply")
+                                      1 if silu else 0, 1 if acc else 0, dp, dseed, _ptr(residual), _ptr(sums_out),
+                                      _stream()), "md_gn_bwd_apply")
         else:
             tmp = dx_view.contiguous() if acc else ops.f32b_empty(B, c, P, dev)
             check(lib.md_gn_bwd_apply(_ptr(t), _ptr(dy), _ptr(params), _ptr(coef), _ptr(tmp), B, c, P, ctot, off, ctot,
-                                      1 if silu else 0, 1 if acc else 0, dp, dseed, _stream()), "md_gn_bwd_apply")
+                                      1 if silu else 0, 1 if acc else 0, dp, dseed, None, None, _stream()),
+                  "md_gn_bwd_apply")
             outs.append(tmp)
         off += c
     if len(parts) == 1:

@@ -382,10 +382,10 @@ class ResnetBlockDDPM(HipLayer):
         from . import backward as bw
         B, P, S, parts = sv["B"], sv["P"], sv["S"], sv["parts"]
         d_a1 = bw.conv3_backward(self, "w1", self.Conv_1, dy, sv["a1"], B, S)
+        dbias0 = torch.zeros((B, self.out_ch), dtype=torch.float32, device=dy.device)
         d_h = bw.gn_backward([(sv["h"], self.out_ch)], d_a1, sv["prm1"], self.GroupNorm_1, B, P, silu=True,
-                             drop=sv.get("drop"))[0]
+                             drop=sv.get("drop"), sums_out=dbias0)[0]     # d(bias0) = channel sums of d_h, same pass
         del d_a1
-        dbias0 = bw.channel_sums(d_h, B, self.out_ch, P)
         # Conv_0.bias gradient = batch sum of dbias0: the FiLM caller adds it once together with Dense_0's
         d_a0 = bw.conv3_backward(self, "w0", self.Conv_0, d_h, sv["a0"], B, S, bias_sums=False)
         del d_h
@@ -402,8 +402,7 @@ class ResnetBlockDDPM(HipLayer):
                 outs.append(g)
                 off += c
             return outs, dbias0
-        d_x = dy.clone()
-        bw.gn_backward(parts, d_a0, sv["prm0"], self.GroupNorm_0, B, P, silu=True, d_into=d_x)
+        d_x = bw.gn_backward(parts, d_a0, sv["prm0"], self.GroupNorm_0, B, P, silu=True, residual=dy)[0]
         return [d_x], dbias0
 
     def forward(self, x, temb=None):
