@@ -127,7 +127,7 @@ __global__ __launch_bounds__(GN_BLOCK) void md_gn_apply_kernel(const float* __re
         if (norm) y = (y - mean[e]) * a[e] + bt[e];
         if (silu & 1) y = md_silu(y);
         if (thr16) y = md_drop_keep(bits[e >> 2], e & 3, thr16) ? y * drop_scale : 0.f;   // nn.Dropout (layers.py:682)
-        // experiment hook (tools/longrun_parity.py --act-fp16): round the operand to fp16 first, which is
+        // experiment hook (tests/longrun_parity.py, MD_DEBUG_ACT_FP16=1): round the operand to fp16 first, which is
         // what a weights-split-only fp16 scheme (2 MFMAs per product) would feed the matrix cores
         if (silu & 2) y = __half2float(__float2half_rn(y));
         if (silu & 4) { hi[e] = md_f2h(y); lo[e] = 0; } else md_split(y, hi[e], lo[e]);

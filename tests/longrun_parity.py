@@ -1,4 +1,5 @@
-"""End-to-end check of the BASELINE target: "sampled SDF+deform grids matching the reference within 1e-3
+"""Parity checker script (test infrastructure: it imports the oracle; ~4 GPU-minutes, so not part of `pytest -m gpu`).
+End-to-end check of the BASELINE target: "sampled SDF+deform grids matching the reference within 1e-3
 rel-L2 under fixed seed", over the full ancestral schedule, on the GPU box.
 
 The reference tree is not available on the GPU box, so the comparison partner is the oracle restatement
@@ -6,7 +7,7 @@ The reference tree is not available on the GPU box, so the comparison partner is
 same GPU.  Both trajectories consume the SAME noise tensors (drawn once per step from the device
 generator), so the difference isolates the arithmetic of the HIP path.
 
-    python tools/longrun_parity.py [--steps 999] [--config res64|small] [--batch 1]
+    python tests/longrun_parity.py [--steps 999] [--config res64|small] [--batch 1]
 """
 import argparse
 import json

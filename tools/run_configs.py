@@ -1,7 +1,7 @@
 """Short measured runs of the other BASELINE.json configs on one MI355X (bench.py covers configs[1]).
 
   #4  res128 4-ch grid, batch=2, ancestral sampling steps        -> sample-steps/s, peak HBM
-  #5  marching tets, 32 meshes per launch (res64 tet grid)        -> meshes/s (+ CPU oracle time for one mesh)
+  #5  marching tets, 32 meshes per launch (res64 tet grid)        -> meshes/s
       cond_gen inpainting sampler, res64, batch=32, a few iterations -> ms/iteration, peak HBM
   #1  res64 uncond, batch=1, first 10 steps                        -> ms/step
 Prints one JSON object.
@@ -101,12 +101,8 @@ def main():
     for _ in range(5):
         meshes = mesher(gd)
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 5
-    from oracle import dmtet_oracle
-    pos, sdf = dmtet_oracle.grid_to_tet_inputs(grids[0].numpy(), tet["vertices"])
-    t0 = time.perf_counter(); dmtet_oracle.marching_tets(pos, sdf, tet["indices"]); tc = time.perf_counter() - t0
     res["config5_marching_tets_b32"] = {"ms_per_call_32_meshes": round(dt * 1e3, 2), "meshes_per_s": round(32 / dt, 1),
-                                        "verts_faces_mesh0": [int(meshes[0][0].shape[0]), int(meshes[0][1].shape[0])],
-                                        "cpu_oracle_s_per_mesh": round(tc, 3)}
+                                        "verts_faces_mesh0": [int(meshes[0][0].shape[0]), int(meshes[0][1].shape[0])]}
     if not a.skip_res128:
         cfg = get_config_res128()
         model = build(cfg, 128, 99)
