@@ -61,8 +61,9 @@ def masked_sq_err(eps_hat, noise, mask_flat, want_grad=False, gscale=1.0):
     lib = _lib.load()
     B, Cc, P = eps_hat.shape[0], eps_hat.shape[1], eps_hat[0, 0].numel()
     sums = torch.zeros(B, dtype=torch.float64, device=eps_hat.device)
+    eps_hat, noise = eps_hat.contiguous(), noise.contiguous()   # named: the copies must outlive the launch
     grad = torch.empty_like(eps_hat) if want_grad else None
-    _lib.check(lib.md_masked_sq_err(ops._ptr(eps_hat.contiguous()), ops._ptr(noise.contiguous()), ops._ptr(mask_flat),
+    _lib.check(lib.md_masked_sq_err(ops._ptr(eps_hat), ops._ptr(noise), ops._ptr(mask_flat),
                                     ops._ptr(sums), ops._ptr(grad), float(gscale), B, Cc, P, ops._stream()),
                "md_masked_sq_err")
     return sums, grad
@@ -114,14 +115,21 @@ def get_step_fn(sde, train, optimize_fn=None, mask=None, loss_type="l2"):
         model = state["model"]
         if train:
             optimizer = state["optimizer"]
+            net = getattr(model, "module", model)
+            # gradients live in ONE flat buffer laid out in backward-completion order (parallel.FlatGrads): the
+            # exchange below all-reduces slices of it in place, Adam and the clip read the views
+            fg = parallel.flat_grads_for(net) if hasattr(net, "grad_completion_order") else None
             if clear_grad:
                 optimizer.zero_grad()
+                if fg is not None:
+                    fg.zero_()
+            if fg is not None:
+                fg.attach()
             loss = loss_fn(model, batch)
             # one process per GPU: the replicas' gradients meet here.  On the step that updates the parameters the
             # U-Net backward announces finished layers to the reducer, whose bucket all-reduces overlap the rest of
             # the backward (no-op for a single process).
-            reducer = parallel.GradReducer() if update_param else None
-            net = getattr(model, "module", model)
+            reducer = parallel.GradReducer(flat=fg) if update_param else None
             if reducer is not None and reducer.active:
                 net._grad_ready_hook = reducer.ready
             try:
@@ -131,6 +139,7 @@ def get_step_fn(sde, train, optimize_fn=None, mask=None, loss_type="l2"):
                     del net._grad_ready_hook
             if update_param:
                 reducer.finish(model.parameters())
+                state["exchange"] = reducer.stats      # buckets / bytes of this step's all-reduces (bench.py reports them)
                 optimize_fn(optimizer, model.parameters(), step=state["step"])
             state["step"] += 1
             state["ema"].update(model.parameters())
@@ -199,6 +208,46 @@ class FusedAdamEMA:
                                         self.opt_steps, d, ops._ptr(sq), float(self.grad_clip), ops._stream()),
                    "md_adam_ema_step")
         ops.bump_param_epoch()   # packed-weight caches must be rebuilt: raw-pointer updates do not bump _version
+
+    def _views(self, flat):
+        out, off = [], 0
+        for p, n in zip(self.params, self.sizes):
+            out.append(flat[off:off + n].view_as(p))
+            off += n
+        return out
+
+    def state_dict(self):
+        """`torch.optim.Adam.state_dict()`-compatible (state[i] = {step, exp_avg, exp_avg_sq} per parameter, one param
+        group), so a checkpoint written from this optimizer restores into the reference's `optim.Adam` and back."""
+        m, v = self._views(self.m), self._views(self.v)
+        state = {i: dict(step=torch.tensor(float(self.opt_steps)), exp_avg=m[i].clone(), exp_avg_sq=v[i].clone())
+                 for i in range(len(self.params))} if self.opt_steps > 0 else {}
+        group = dict(lr=self.lr, betas=(self.b1, self.b2), eps=self.eps, weight_decay=self.wd, amsgrad=False,
+                     maximize=False, foreach=None, capturable=False, differentiable=False, fused=None,
+                     params=list(range(len(self.params))))
+        return dict(state=state, param_groups=[group])
+
+    def load_state_dict(self, sd):
+        g = sd["param_groups"][0]
+        self.lr, (self.b1, self.b2), self.eps, self.wd = g["lr"], g["betas"], g["eps"], g["weight_decay"]
+        st = sd["state"]
+        self.opt_steps = 0
+        self.m.zero_(); self.v.zero_()
+        for i, (mv, vv) in enumerate(zip(self._views(self.m), self._views(self.v))):
+            e = st.get(i, st.get(str(i)))
+            if e is None:
+                continue
+            mv.copy_(e["exp_avg"]); vv.copy_(e["exp_avg_sq"])
+            self.opt_steps = int(float(e["step"]))
+
+    def ema_state_dict(self):
+        """The reference EMA's state dict {decay, num_updates, shadow_params} (models/ema.py:91-97)."""
+        return dict(decay=self.ema_decay, num_updates=self.ema_updates, shadow_params=[t.clone() for t in self.ema_shadow_params()])
+
+    def load_ema_state_dict(self, sd):
+        self.ema_decay, self.ema_updates = sd["decay"], int(sd["num_updates"] or 0)
+        for dst, src in zip(self.ema_shadow_params(), sd["shadow_params"]):
+            dst.copy_(src)
 
     def ema_shadow_params(self):
         """List of views in parameters() order == the reference EMA's `shadow_params` (checkpoint format)."""

@@ -152,6 +152,11 @@ class DDPMUNet3D(layers.HipLayer):
 
     def forward_train(self, x, labels):
         """Forward pass that records what `backward` needs.  Returns (eps_hat NCDHW, ctx)."""
+        if self.scale_by_sigma:
+            # the inference forward divides by sigma[labels] (ddpm_res64.py:196-198 of the reference); neither registered
+            # config enables it, and the HIP backward does not carry the 1/sigma factor
+            raise NotImplementedError("training with model.scale_by_sigma=True is not implemented on the HIP path")
+        assert tuple(x.shape[1:]) == (self.out_channels, self.img_size, self.img_size, self.img_size)
         ops.set_precision("bf16x3")
         mods = self.all_modules
         B, R = x.shape[0], self.img_size
@@ -316,6 +321,28 @@ class DDPMUNet3D(layers.HipLayer):
         bw._grad_of(mods[0].bias).add_(d_t1.sum(0))
         ops.bump_param_epoch()   # nothing cached depends on grads, but keep caches honest if an optimizer steps next
 
+    def grad_completion_order(self):
+        """Trainable parameters in the order `backward` finishes (and announces) their gradients: final GroupNorm + head,
+        then the layers of the tape in reverse; last the ones that are only complete when the backward returns (every
+        ResnetBlock's Dense_0 / Conv_0.bias -- FiLM algebra --, the timestep MLP, stem, mask_layer, pos_layer).  This is
+        the layout of parallel.FlatGrads, so that finished gradients are a contiguous prefix of the flat buffer."""
+        mods = list(self.all_modules)
+        order, late, seen = [], [], set()
+
+        def put(dst, ps):
+            for p in ps:
+                if p.requires_grad and id(p) not in seen:
+                    seen.add(id(p))
+                    dst.append(p)
+
+        put(order, list(mods[-2].parameters()) + list(mods[-1].parameters()))
+        for m in reversed(mods[3:-2]):
+            if isinstance(m, ResnetBlockDDPM):
+                put(late, [m.Dense_0.weight, m.Dense_0.bias, m.Conv_0.bias])
+            put(order, m.parameters())
+        put(late, self.parameters())
+        return order + late
+
     def _stem_cfg(self):
         return ops.CFG_C3_128_K16 if self.KSIZE == 3 else ops.CFG_C5_128_K16
 
@@ -431,7 +458,8 @@ class DDPMRes64(DDPMUNet3D):
 
 class _UNetTrainFn(torch.autograd.Function):
     """One opaque autograd node around the HIP forward/backward.  Parameter gradients are accumulated straight
-    into `.grad` by `DDPMUNet3D.backward`; the `anchor` input only makes autograd schedule this node."""
+    into `.grad` by `DDPMUNet3D.backward`; the `anchor` input only makes autograd schedule this node.
+    The gradient w.r.t. the input `x` is NOT produced (the DDPM loss never needs it): `x.grad` stays None."""
 
     @staticmethod
     def forward(ctx, x, labels, model, anchor):

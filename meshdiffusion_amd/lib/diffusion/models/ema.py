@@ -4,6 +4,8 @@ state_dict :91-97).  Same state-dict format {decay, num_updates, shadow_params}.
 """
 import torch
 
+from .... import hip_ops as ops
+
 
 class ExponentialMovingAverage:
     def __init__(self, parameters, decay, use_num_updates=True):
@@ -37,6 +39,9 @@ class ExponentialMovingAverage:
     def copy_to(self, parameters):
         for s, p in zip(self.shadow_params, [q for q in parameters if q.requires_grad]):
             p.data.copy_(s.data)
+        # `p.data.copy_` does not bump `p._version`: the packed-weight caches of the HIP layers (keyed on
+        # data_ptr + _version + PARAM_EPOCH) would keep serving the previous weights
+        ops.bump_param_epoch()
 
     def store(self, parameters):
         self.collected_params = [p.clone() for p in parameters]
@@ -44,6 +49,7 @@ class ExponentialMovingAverage:
     def restore(self, parameters):
         for c, p in zip(self.collected_params, parameters):
             p.data.copy_(c.data)
+        ops.bump_param_epoch()
 
     def state_dict(self):
         return dict(decay=self.decay, num_updates=self.num_updates, shadow_params=self.shadow_params)

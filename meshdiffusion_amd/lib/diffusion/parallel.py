@@ -11,6 +11,8 @@ import os
 import torch
 import torch.distributed as dist
 
+from ... import hip_ops as ops
+
 
 def shard_sizes(total, world):
     """Split `total` samples over `world` ranks as evenly as possible (first ranks get the remainder)."""
@@ -88,6 +90,7 @@ def broadcast_params_(params, src=0, cap_bytes=256 << 20):
         dist.broadcast(flat, src=src)
         for t, f in zip(bucket, torch._utils._unflatten_dense_tensors(flat, bucket)):
             t.copy_(f)
+    ops.bump_param_epoch()   # `.data.copy_` does not bump `_version`: packed-weight caches must not survive the broadcast
 
 
 def _buckets(tensors, cap_bytes=256 << 20):
@@ -124,25 +127,99 @@ def allreduce_param_grads_(params, cap_bytes=256 << 20):
             g.copy_(f)
 
 
+class FlatGrads:
+    """Every trainable parameter's `.grad` as a view of ONE flat fp32 buffer, laid out in the order the backward pass
+    finishes them (`DDPMUNet3D.grad_completion_order`).  A finished prefix of the buffer is then a contiguous slice that
+    `GradReducer` all-reduces IN PLACE: no flatten copy, no copy-back, and (RCCL: `ReduceOp.AVG`) no division pass --
+    the exchange touches the 1.456 GB of res64 gradients exactly once.  `torch.optim.Adam` / `clip_grad_norm_` work on
+    the views unchanged."""
+
+    def __init__(self, ordered_params):
+        self.params = [p for p in ordered_params if p.requires_grad]
+        if not self.params:
+            raise ValueError("no trainable parameters")
+        dev = self.params[0].device
+        self.slices, off = {}, 0
+        for i, p in enumerate(self.params):
+            if id(p) in self.slices:
+                raise ValueError("parameter listed twice")
+            self.slices[id(p)] = (i, off, p.numel())
+            off += p.numel()
+        self.n = off
+        self.flat = torch.zeros(self.n, dtype=torch.float32, device=dev)
+        self.views = [self.flat[o:o + n].view_as(p) for p, (_, o, n) in ((p, self.slices[id(p)]) for p in self.params)]
+
+    def matches(self, params):
+        ps = [p for p in params if p.requires_grad]
+        return (len(ps) == len(self.params) and all(id(p) in self.slices and self.slices[id(p)][2] == p.numel() for p in ps)
+                and ps[0].device == self.flat.device)
+
+    def attach(self):
+        """(Re-)point every `.grad` at its view (optimizer.zero_grad() sets them to None)."""
+        for p, v in zip(self.params, self.views):
+            if p.grad is None or p.grad.data_ptr() != v.data_ptr():
+                p.grad = v
+
+    def zero_(self):
+        self.flat.zero_()
+
+
+def flat_grads_for(net):
+    """The FlatGrads of a network that knows its gradient completion order (cached on the module; rebuilt when the
+    parameters were re-created or moved)."""
+    params = list(net.parameters())
+    fg = net.__dict__.get("_md_flat_grads")
+    if fg is None or not fg.matches(params):
+        fg = FlatGrads(net.grad_completion_order())
+        assert fg.matches(params), "grad_completion_order() must list every trainable parameter exactly once"
+        net.__dict__["_md_flat_grads"] = fg
+    return fg
+
+
 class GradReducer:
     """Bucket-wise gradient averaging that overlaps with the backward pass.
 
     The HIP backward (`DDPMUNet3D.backward`) walks the layers in reverse and calls `ready(params)` as soon as a
-    layer's parameter gradients are final; parameters accumulate into a bucket and every `cap_bytes` the bucket is
-    flattened and sent off as ONE asynchronous all-reduce (RCCL runs it on its own stream behind the kernels already
-    queued, so it rides under the remaining backward).  `finish(all_params)` reduces whatever was not announced
-    (FiLM / timestep-MLP gradients are only complete at the very end), waits, divides by the world size and copies
-    the means back into `.grad`.  xGMI rings are per-link bound, so buckets are large (default 128 MB, 12 messages
-    for res64) rather than DDP's 25 MB.  World size 1: every call is a no-op.
+    layer's parameter gradients are final.  With `flat` (a FlatGrads whose layout IS that completion order) the
+    finished gradients form a growing prefix of one buffer: every `cap_bytes` the new part of the prefix goes out as
+    ONE asynchronous in-place all-reduce (RCCL runs it on its own stream behind the kernels already queued, so it rides
+    under the remaining backward; `ReduceOp.AVG` on RCCL, SUM + one in-place division on gloo).  `finish(all_params)`
+    sends the rest (FiLM / timestep-MLP / stem gradients are only complete at the very end) and waits.  Without `flat`
+    (gradients allocated separately) buckets are flattened copies that are copied back after the wait.  xGMI rings are
+    per-link bound, so buckets are large (default 128 MB, 12 messages for res64) rather than DDP's 25 MB.
+    World size 1: every call is a no-op (set `force=True` to run the collectives anyway: world-1 RCCL self-test).
     """
 
-    def __init__(self, cap_bytes=128 << 20):
+    def __init__(self, cap_bytes=128 << 20, flat=None, force=False):
         self.cap = int(cap_bytes)
-        self.active = dist.is_initialized() and dist.get_world_size() > 1
+        self.active = dist.is_initialized() and (dist.get_world_size() > 1 or force)
+        self.flat = flat
         self.cur, self.cur_bytes, self.pending, self.done = [], 0, [], set()
+        self.frontier = self.sent = 0          # flat mode: params [0, frontier) are final, elements [0, sent) are on the wire
+        self.sent_idx = 0
+        self.stats = dict(buckets=0, bytes=0)
+        self.avg = None
+        if self.active:
+            self.avg = dist.ReduceOp.AVG if dist.get_backend() == "nccl" else None   # gloo has no AVG
+
+    def _allreduce(self, t):
+        self.stats["buckets"] += 1
+        self.stats["bytes"] += t.numel() * t.element_size()
+        return dist.all_reduce(t, op=self.avg if self.avg is not None else dist.ReduceOp.SUM, async_op=True)
 
     def ready(self, params):
         if not self.active:
+            return
+        if self.flat is not None:
+            fl = self.flat
+            for p in params:
+                if id(p) in fl.slices:
+                    self.done.add(id(p))
+            while self.frontier < len(fl.params) and id(fl.params[self.frontier]) in self.done:
+                self.frontier += 1
+            end = fl.n if self.frontier == len(fl.params) else fl.slices[id(fl.params[self.frontier])][1]
+            if (end - self.sent) * 4 >= self.cap:
+                self._launch_flat(end)
             return
         for p in params:
             if p.requires_grad and p.grad is not None and id(p) not in self.done:
@@ -152,22 +229,36 @@ class GradReducer:
         if self.cur_bytes >= self.cap:
             self._launch()
 
+    def _launch_flat(self, end):
+        if end > self.sent:
+            sl = self.flat.flat[self.sent:end]
+            self.pending.append((self._allreduce(sl), sl, None))
+            self.sent = end
+
     def _launch(self):
         if not self.cur:
             return
         flat = torch._utils._flatten_dense_tensors(self.cur)
-        self.pending.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True), flat, self.cur))
+        self.pending.append((self._allreduce(flat), flat, self.cur))
         self.cur, self.cur_bytes = [], 0
 
     def finish(self, all_params):
         if not self.active:
             return
-        self.ready(list(all_params))
-        self._launch()
         world = dist.get_world_size()
+        if self.flat is not None:
+            self._launch_flat(self.flat.n)
+            # parameters outside the flat buffer (none for the registered models) take the copying path
+            self.flat, rest = None, [p for p in all_params if id(p) not in self.flat.slices]
+            self.ready(rest)
+        else:
+            self.ready(list(all_params))
+        self._launch()
         for work, flat, bucket in self.pending:
             work.wait()
-            flat.div_(world)
-            for g, f in zip(bucket, torch._utils._unflatten_dense_tensors(flat, bucket)):
-                g.copy_(f)
+            if self.avg is None:
+                flat.div_(world)
+            if bucket is not None:
+                for g, f in zip(bucket, torch._utils._unflatten_dense_tensors(flat, bucket)):
+                    g.copy_(f)
         self.pending = []

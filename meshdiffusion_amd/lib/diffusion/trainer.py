@@ -33,7 +33,9 @@ from ..dataset.shapenet_dmtet_dataset import ShapeNetDMTetDataset
 class RankShardSampler(torch.utils.data.Sampler):
     """Epoch-shuffled indices, rank r of W takes positions r, r+W, ... of the common permutation (tail dropped
     so all ranks see the same number of items).  The permutation is seeded by (seed, epoch) so every rank
-    draws the same one without communicating."""
+    draws the same one without communicating.  Deviation from the reference loader (shuffle=True, drop_last=False on
+    one process): up to W-1 items per epoch and the last partial batch are skipped, i.e. an epoch is
+    floor(floor(n / W) / local_batch) steps -- every step then has the full global batch on every rank."""
 
     def __init__(self, n, rank, world, seed):
         self.n, self.rank, self.world, self.seed, self.epoch = int(n), int(rank), int(world), int(seed), 0
@@ -64,6 +66,9 @@ def train(config):
         raise RuntimeError("training runs on the HIP path only: no GPU is visible")
     torch.cuda.set_device(local)
     config.device = torch.device("cuda", local)
+    # the reference never consumes config.seed; here it pins, per rank, the noise / timestep draws,
+    # the dropout mask seeds and the DataLoader workers' base seed, so multi-rank runs are reproducible
+    torch.manual_seed(int(config.seed) + rank)
     workdir = config.training.train_dir
     logging.info("working dir: {:s}".format(workdir))
     writer = _summary_writer(os.path.join(workdir, "tensorboard")) if rank == 0 else None
@@ -100,6 +105,9 @@ def train(config):
     if len(loader) == 0:
         raise ValueError(f"dataset of {len(dataset)} grids is smaller than one global batch "
                          f"({config.training.batch_size})")
+    # a resumed run continues the permutation sequence where the checkpoint left it (state["step"] counts consumed
+    # local batches) instead of replaying epoch 0, 1, ...; the position inside the interrupted epoch is not restored
+    sampler.epoch = initial_step // len(loader)
     data_iter = iter(loader)
 
     sde = sde_lib.VPSDE(beta_min=config.model.beta_min, beta_max=config.model.beta_max, N=config.model.num_scales)

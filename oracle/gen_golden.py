@@ -9,7 +9,9 @@ outputs are stored):
   unet_small.npz     reference DDPMRes64 (small config) eps_hat, full tensor
   unet_res64.npz     reference DDPMRes64 (res64, B=1) eps_hat: ::4 subsample + statistics
   sampler_small.npz  unmodified reference pc_sampler, first K iterations, uncond + inpainting
-  sampler_res64.npz  BASELINE config #1: res64, B=1, first 10 of 1000 ancestral steps
+  sampler_res64.npz  BASELINE config #1: res64, B=1, first 10 of 1000 ancestral steps (live cells + statistics)
+  sampler_cond_res64_b32.npz  BASELINE config #5: cond_gen res64, B=32, first 5 iterations of the inpainting sampler
+  sampler_res128_b2.npz       BASELINE config #4: res128, B=2, first 2 ancestral steps
   train_grads.npz    reference loss function (train mode): loss + per-parameter gradient norms / samples
   dataset.npz        reference ShapeNetDMTetDataset items (augmentation on/off) for seeded on-disk grids
   dmtet.npz          reference DMTet.__call__ on the shipped 64-grid: counts, hashes, samples
@@ -182,8 +184,84 @@ def gen_unet_and_sampler(skip_res64):
         t0 = time.time()
         xm = run_ref_sampler(rsampling, rsde, cfg, model, (1, 4, R, R, R), mask, 10, seed=42)
         print(f"[res64] reference 10-step sampler {time.time() - t0:.1f}s")
-        np.savez_compressed(os.path.join(GOLD, "sampler_res64.npz"), xm_sub=xm[:, :, ::4, ::4, ::4].numpy(),
-                            xm_norm=float(xm.double().norm()), xm_row=xm[0, :, 33, 17, :].numpy(), K=10, seed=42)
+        np.savez_compressed(os.path.join(GOLD, "sampler_res64.npz"), xm_norm=float(xm.double().norm()),
+                            xm_row=xm[0, :, 33, 17, :].numpy(), K=10, seed=42,
+                            **sample_stats(xm, synth.synthetic_grid_mask(R), 4))
+
+
+def live_cells(mask, stride):
+    """Flat indices of every `stride`-th LIVE cell of a [R,R,R] grid mask.  The sampler multiplies its state by the
+    mask, and the lattice has no live cell on a ::4 sub-grid, so fixtures of sampled grids record live cells."""
+    idx = torch.nonzero(torch.as_tensor(mask).reshape(-1) > 0).reshape(-1)
+    return idx[::stride]
+
+
+def sample_stats(x, mask, stride):
+    """What a sampled-grid fixture stores: values at every `stride`-th live cell (all samples, all channels), the
+    per-sample norms and the per-(sample, channel) sums."""
+    x = torch.as_tensor(x)
+    B, C = x.shape[:2]
+    li = live_cells(mask, stride)
+    flat = x.reshape(B, C, -1)
+    return dict(live=flat[:, :, li].numpy().copy(), norms=flat.double().reshape(B, -1).norm(dim=1).numpy(),
+                sums=flat.double().sum(dim=2).numpy(), stride=np.int64(stride))
+
+
+def cond_inputs(R, mask, seed=5):
+    """BASELINE config #5 conditioning: `partial` = sign of a smooth SDF (channel 0 of a held-out grid),
+    `partial_mask` = half-space x < R/2 intersected with the grid mask; both [1,1,R,R,R].  Shared with tests/."""
+    g = torch.Generator().manual_seed(seed)
+    ax = torch.linspace(-1, 1, R)
+    X, Y, Z = torch.meshgrid(ax, ax, ax, indexing="ij")
+    c = torch.rand(3, generator=g) * 0.3 - 0.15
+    sdf = 0.55 - ((X - c[0]) ** 2 + (Y - c[1]) ** 2 + (Z - c[2]) ** 2).sqrt() + 0.08 * torch.sin(7 * X + 3 * Y)
+    m5 = torch.as_tensor(mask).reshape(1, 1, R, R, R).float()
+    partial = torch.where(sdf > 0, torch.ones(()), -torch.ones(())).reshape(1, 1, R, R, R)
+    half = (torch.arange(R).view(R, 1, 1) < R // 2).float().expand(R, R, R).reshape(1, 1, R, R, R)
+    return partial, half * m5
+
+
+def gen_graded(which):
+    """Sampler fixtures at the BASELINE batch sizes, from the UNMODIFIED reference sampler on the CPU:
+      cond32  : configs[4] cond_gen res64, B=32, first 5 iterations (freeze_iters 950: blend + re-noise every iteration)
+      res128  : configs[3] res128, B=2, first 2 ancestral steps (synthetic 128 mask: the asset is missing upstream)
+      config1 : configs[0] res64 B=1 first 10 steps, re-recorded on live cells"""
+    rsampling, rsde, rmutils = import_reference()
+    from meshdiffusion_amd.config import get_config_res64, get_config_res128
+    with torch.no_grad():
+        if "config1" in which or "cond32" in which:
+            cfg = get_config_res64(); cfg.device = torch.device("cpu")
+            R = 64
+            sd = make_sd(cfg, R)
+            model = ref_model(rmutils, cfg, sd)
+            del sd
+            mask = synth.synthetic_grid_mask(R)
+        if "config1" in which:
+            t0 = time.time()
+            xm = run_ref_sampler(rsampling, rsde, cfg, model, (1, 4, R, R, R), mask.view(1, R, R, R), 10, seed=42)
+            print(f"[res64] reference 10-step sampler {time.time() - t0:.1f}s", flush=True)
+            np.savez_compressed(os.path.join(GOLD, "sampler_res64.npz"), xm_norm=float(xm.double().norm()),
+                                xm_row=xm[0, :, 33, 17, :].numpy(), K=10, seed=42, **sample_stats(xm, mask, 4))
+        if "cond32" in which:
+            B, K = 32, 5
+            partial, pmask = cond_inputs(R, mask)
+            t0 = time.time()
+            xc = run_ref_sampler(rsampling, rsde, cfg, model, (B, 4, R, R, R), mask.view(1, 1, R, R, R), K, seed=91,
+                                 cond=(partial, pmask, 950))
+            print(f"[res64 cond_gen B={B}] reference {K} iterations {time.time() - t0:.1f}s", flush=True)
+            np.savez_compressed(os.path.join(GOLD, "sampler_cond_res64_b32.npz"), B=B, K=K, seed=91, cond_seed=5,
+                                freeze_iters=950, **sample_stats(xc, mask, 32))
+        if "res128" in which:
+            cfg = get_config_res128(); cfg.device = torch.device("cpu")
+            sd = make_sd(cfg, 128, seed=99)
+            model = ref_model(rmutils, cfg, sd)
+            del sd
+            mask = synth.synthetic_grid_mask(128)
+            t0 = time.time()
+            xm = run_ref_sampler(rsampling, rsde, cfg, model, (2, 4, 128, 128, 128), mask.view(1, 128, 128, 128), 2, seed=17)
+            print(f"[res128 B=2] reference 2-step sampler {time.time() - t0:.1f}s", flush=True)
+            np.savez_compressed(os.path.join(GOLD, "sampler_res128_b2.npz"), B=2, K=2, seed=17, sd_seed=99,
+                                **sample_stats(xm, mask, 32))
 
 
 def gen_res128_full(rmutils):
@@ -283,6 +361,9 @@ def gen_dmtet():
             out[f"{name}_verts_sha"] = sha(v.numpy().astype(np.float32))
             out[f"{name}_uv_idx_sha"] = sha(uv_idx.numpy().astype(np.int64))
             out[f"{name}_vvi_sha"] = sha(vvi.numpy().astype(np.int64))
+            out[f"{name}_uvs_sha"] = sha(uvs.numpy().astype(np.float32))
+            out[f"{name}_ftet_sha"] = sha(ftet.numpy().astype(np.int64))
+            out[f"{name}_uvs_shape"] = np.array(uvs.shape)
             out[f"{name}_faces_head"] = f.numpy()[:64]
             out[f"{name}_faces_tail"] = f.numpy()[-64:]
             out[f"{name}_verts_head"] = v.numpy()[:64]
@@ -398,7 +479,8 @@ def gen_dataset():
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-res64", action="store_true")
-    ap.add_argument("--only", choices=["unet", "dmtet", "dataset", "train"], default=None)
+    ap.add_argument("--only", choices=["unet", "dmtet", "dataset", "train", "graded"], default=None)
+    ap.add_argument("--graded", default="config1,cond32,res128", help="which graded-size sampler fixtures to (re)generate")
     a = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(os.cpu_count())
@@ -410,4 +492,6 @@ if __name__ == "__main__":
         gen_train(full=not a.skip_res64)
     if a.only in (None, "unet"):
         gen_unet_and_sampler(a.skip_res64)
+    if a.only == "graded" or (a.only is None and not a.skip_res64):
+        gen_graded(a.graded.split(","))
     print("golden fixtures written to", GOLD)

@@ -150,6 +150,26 @@ def _replica_worker(rank, world, port, q):
     red.finish(net.parameters())
     for p, g in zip(net.parameters(), reduced):
         assert torch.allclose(p.grad, g, atol=1e-7)
+    # the same exchange IN PLACE on one flat gradient buffer laid out in completion order (what losses.get_step_fn does):
+    # finished layers are a growing prefix whose new part goes out once it reaches the bucket size
+    order = list(net[2].parameters()) + [net[0].weight, net[0].bias]
+    fg = parallel.FlatGrads(order)
+    assert fg.matches(net.parameters()) and fg.n == sum(p.numel() for p in net.parameters())
+    for p in net.parameters():
+        p.grad = None
+    fg.attach()
+    for p, g in zip(net.parameters(), local):
+        assert p.grad.data_ptr() == fg.views[fg.slices[id(p)][0]].data_ptr()
+        p.grad.copy_(g)
+    red = parallel.GradReducer(cap_bytes=48, flat=fg)
+    red.ready([net[0].weight])                      # announced out of order: nothing contiguous is final yet
+    assert red.sent == 0 and not red.pending
+    red.ready(list(net[2].parameters()))            # prefix = Linear(5,3) (18 floats) + net[0].weight (30): one bucket
+    assert red.sent == 48 and len(red.pending) == 1
+    red.finish(net.parameters())
+    assert red.stats["buckets"] == 2 and red.stats["bytes"] == 4 * fg.n
+    for p, g in zip(net.parameters(), reduced):
+        assert torch.allclose(p.grad, g, atol=1e-7)
     q.put((rank, start, reduced))
     dist.barrier()
     dist.destroy_process_group()
