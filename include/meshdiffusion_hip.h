@@ -42,7 +42,7 @@ extern "C" {
 #define MD_ERR_UNSUPPORTED (-2)
 #define MD_ERR_NO_DEVICE (-3)
 
-#define MD_ABI_VERSION 5
+#define MD_ABI_VERSION 6
 
 /* ---- tile configurations of md_gemm_conv (compile-time instantiations) ---- */
 enum {
@@ -121,6 +121,9 @@ typedef struct MdGemmConvArgs {
                          /* squares of the values written to `out`, ADDED with fp64 atomics (caller    */
                          /* zeroes) -- the GroupNorm statistics of the consumer without another pass   */
                          /* over the tensor.  MD_CFG_C3_128_FAST, F32B output, no split-K; else error  */
+  int32_t stagger;       /* MD_CFG_C3_128_FAST: shader cycles over which the start of the first workgroup */
+                         /* of each CU is spread (0 = off), so the CUs' epilogue bursts do not coincide   */
+  int32_t reserved0;
 } MdGemmConvArgs;
 
 int md_abi_version(void);

@@ -23,7 +23,7 @@ CFG_NT_KC = {
     CFG_C3_S2: (128, 32), CFG_G1_128: (128, 32), CFG_G1_128_LOW: (128, 32), CFG_G1_64_LOW: (64, 32),
     CFG_C3_128_V2: (128, 32), CFG_C3_128_SW: (128, 32), CFG_C3_128_PIPE: (128, 32),
     CFG_C3_128_V3: (128, 32), CFG_C3_128_V3B: (128, 32), CFG_C3_128_V4: (128, 32), CFG_C3_128_FAST: (128, 32), CFG_C5_128_K16: (128, 16), CFG_C5_32_K16: (32, 16), CFG_C3_128_W4: (128, 32), CFG_C3X_32: (32, 32), CFG_C5X_32_K16: (32, 16), CFG_C3X_128_K16: (128, 16), CFG_C5X_128: (128, 32),
-    101: (128, 32), 102: (128, 32), 103: (128, 32), 104: (128, 32), 105: (128, 32), 111: (128, 32), 113: (128, 32), 114: (128, 32), 116: (128, 32), 117: (128, 32), 118: (128, 32),   # timing-only ablations of C3_128_V2
+    101: (128, 32), 102: (128, 32), 103: (128, 32), 104: (128, 32), 105: (128, 32), 111: (128, 32), 113: (128, 32), 114: (128, 32), 116: (128, 32), 117: (128, 32), 118: (128, 32), 122: (128, 32),   # timing-only ablations of C3_128_V2
 }
 
 
@@ -35,11 +35,11 @@ class MdGemmConvArgs(C.Structure):
         ("H", C.c_int32), ("W", C.c_int32), ("ups", C.c_int32), ("a_src", C.c_int32),
         ("out_mode", C.c_int32), ("a_rows", C.c_int32), ("a_bstride", C.c_int64),
         ("bias_bstride", C.c_int64), ("res_bstride", C.c_int64), ("b_bstride", C.c_int64), ("partial", C.c_void_p), ("ksplit", C.c_int32), ("prec", C.c_int32),
-        ("stats", C.c_void_p),
+        ("stats", C.c_void_p), ("stagger", C.c_int32), ("reserved0", C.c_int32),
     ]
 
 
-ABI_VERSION = 5      # MD_ABI_VERSION of include/meshdiffusion_hip.h this host code was written against
+ABI_VERSION = 6      # MD_ABI_VERSION of include/meshdiffusion_hip.h this host code was written against
 _P, _I32, _I64, _F, _U64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint64
 
 # name -> (restype, argtypes); exactly the entry points of include/meshdiffusion_hip.h

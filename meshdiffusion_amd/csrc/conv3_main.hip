@@ -44,7 +44,12 @@ __device__ __forceinline__ int slot_of(int hz, int hy, int hx) {
 // 4 = no weight global loads, 6 = no barriers only; 7 = (valid results) no MFMA/DS interleave hint
 // PREC: MD_PREC_BF16X3 (both operands split bf16, 3 MFMAs/product) or MD_PREC_FP16X2 (weights split fp16,
 // activations one fp16 plane, 2 MFMAs/product; the halo tile then has one plane and half the LDS/L2 traffic).
-template <int ABL, int PREC>
+// A.stagger > 0 phase-staggers the first workgroup of every CU by up to that many shader cycles (all 256 CUs otherwise
+// reach their epilogues -- 256 KB of residual reads + output stores per workgroup -- at the same moment, tile after tile:
+// an HBM burst during which no matrix core works).
+// VAR (A/B switch, valid results): bit 1 = commit the next tap's weight tile to LDS at the TOP of the tap (behind it 12
+// MFMAs cover the ds_write latency) instead of right before the barrier.
+template <int ABL, int PREC, int VAR = 0>
 __global__ __launch_bounds__(NTHREADS) void md_conv3_main_kernel(const MdGemmConvArgs A) {
   constexpr int PL = (PREC == MD_PREC_FP16X2) ? 1 : 2;        // activation planes staged in LDS
   constexpr int A_ITEMS_P = KG * PL * HPOS;
@@ -57,6 +62,17 @@ __global__ __launch_bounds__(NTHREADS) void md_conv3_main_kernel(const MdGemmCon
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform => SALU
   const int wr = wid >> 2, wc = wid & 3;
   const int j = lane & 31, h = lane >> 5;
+
+  {
+    // One workgroup per CU (122 KB of LDS): the first 256 workgroups of the grid land on the 256 CUs, and every later one
+    // starts when its CU's predecessor retires, so a start-up delay of the first generation persists as that CU's phase.
+    const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    if (A.stagger > 0 && lin < 256u) {
+      const unsigned ph = (lin * 0x9E3779B1u) >> 24;                       // 0..255, decorrelated from the dispatch order
+      const uint64_t t_end = __builtin_amdgcn_s_memtime() + ((uint64_t)ph * (uint64_t)A.stagger >> 8);
+      while (__builtin_amdgcn_s_memtime() < t_end) __builtin_amdgcn_s_sleep(16);
+    }
+  }
 
   // ---- tile coordinates (scalar) ----------------------------------------------------------------
   const int D = A.D, H = A.H, W = A.W;
@@ -239,7 +255,20 @@ __global__ __launch_bounds__(NTHREADS) void md_conv3_main_kernel(const MdGemmCon
       const int tn = (tap + 1) % TAPS;                 // next step's tap (same offsets in the next chunk)
       const int ndz = tn / 9, ndy = (tn / 3) % 3, ndx = tn % 3;
       const int nxt = cur ^ (W_ITEMS * 16);
-      {
+      if constexpr ((VAR & 2) == 0) {
+        const unsigned char* pa = lds + cur + vA;
+        const unsigned char* pb = lds + vB[dz] + (dy * 24 + dx) * 16;
+        MD_LOAD_FRAGS(F1, pa, pb, 1)
+      }
+      if constexpr ((VAR & 2) != 0) {
+        // W(s+1) goes to LDS first: the buffer's last readers passed the barrier of tap s-1, its data was requested a
+        // whole tap ago, and the 12 MFMAs below run while the LDS store path (13 cycles per ds_write_b128) drains
+        *(uint4*)(lds + nxt + tid * 16) = wreg0;
+        *(uint4*)(lds + nxt + (tid + NTHREADS) * 16) = wreg1;
+        const int ts = (s + 2 < last_tile) ? s + 2 : last_tile;
+        const uint4* wt = wbase + (int64_t)ts * W_ITEMS;
+        wreg0 = wt[tid]; wreg1 = wt[tid + NTHREADS];
+        __builtin_amdgcn_sched_barrier(0);   // keep the store ahead of this tap's fragment reads and MFMAs
         const unsigned char* pa = lds + cur + vA;
         const unsigned char* pb = lds + vB[dz] + (dy * 24 + dx) * 16;
         MD_LOAD_FRAGS(F1, pa, pb, 1)
@@ -248,11 +277,11 @@ __global__ __launch_bounds__(NTHREADS) void md_conv3_main_kernel(const MdGemmCon
       MD_MMA(F0)
       if constexpr (MD_SETPRIO) __builtin_amdgcn_s_setprio(0);
       MD_INTERLEAVE()
-      if constexpr (ABL != 3) {  // W(s+1): registers -> LDS (the other buffer; its last readers passed a barrier)
+      if constexpr (ABL != 3 && (VAR & 2) == 0) {  // W(s+1): registers -> LDS (the other buffer; its last readers passed a barrier)
         *(uint4*)(lds + nxt + tid * 16) = wreg0;
         *(uint4*)(lds + nxt + (tid + NTHREADS) * 16) = wreg1;
       }
-      if constexpr (ABL != 4) {
+      if constexpr (ABL != 4 && (VAR & 2) == 0) {
         const int ts = (s + 2 < last_tile) ? s + 2 : last_tile;
         const uint4* wt = wbase + (int64_t)ts * W_ITEMS;
         wreg0 = wt[tid]; wreg1 = wt[tid + NTHREADS];
@@ -426,6 +455,7 @@ int md_launch_conv3_main(const MdGemmConvArgs& a, hipStream_t stream) {
 #else
       case 111: case 113: case 114: case 116: case 117: case 118: return MD_ERR_UNSUPPORTED;   // MD_BUILD_ABLATIONS=1 python -m meshdiffusion_amd.build --force
 #endif
+      case 122: hipLaunchKernelGGL((md_conv3_main_kernel<0, 0, 2>), grid, dim3(NTHREADS), 0, stream, a); break;
       default: hipLaunchKernelGGL((md_conv3_main_kernel<0, 0>), grid, dim3(NTHREADS), 0, stream, a); break;
     }
   }

@@ -656,8 +656,9 @@ static void cfg_info(int32_t* nt, int32_t* kc, int32_t* cols, int32_t* taps, int
   if (thr) *thr = C::NTHREADS;
 }
 
-#define MD_CFG_SWITCH(cfg, F, ...)                                  \
-  switch (cfg) {                                                    \
+// Production configurations; the A/B baselines of tools/bench_conv.py (V2/SW/PIPE/V3/V3B/V4/W4 and the timing-only ABL
+// variants) are instantiated only with -DMD_BUILD_ABLATIONS (MD_BUILD_ABLATIONS=1 python -m meshdiffusion_amd.build --force).
+#define MD_CFG_CASES_PROD(F, ...)                                   \
     case MD_CFG_C3_128: F<Cfg_C3_128>(__VA_ARGS__); break;          \
     case MD_CFG_C3_128_K16: F<Cfg_C3_128_K16>(__VA_ARGS__); break;  \
     case MD_CFG_C3_32: F<Cfg_C3_32>(__VA_ARGS__); break;            \
@@ -666,26 +667,35 @@ static void cfg_info(int32_t* nt, int32_t* kc, int32_t* cols, int32_t* taps, int
     case MD_CFG_C3X_128_K16: F<Cfg_C3X_128_K16>(__VA_ARGS__); break; \
     case MD_CFG_C5X_128: F<Cfg_C5X_128>(__VA_ARGS__); break;        \
     case MD_CFG_C3_LOW: F<Cfg_C3_LOW>(__VA_ARGS__); break;          \
-    case MD_CFG_C3_128_W4: F<Cfg_C3_128_W4>(__VA_ARGS__); break;    \
     case MD_CFG_C3_S2: F<Cfg_C3_S2>(__VA_ARGS__); break;            \
     case MD_CFG_G1_128: F<Cfg_G1_128>(__VA_ARGS__); break;          \
     case MD_CFG_G1_128_LOW: F<Cfg_G1_128_LOW>(__VA_ARGS__); break;  \
     case MD_CFG_G1_64_LOW: F<Cfg_G1_64_LOW>(__VA_ARGS__); break;    \
+    case MD_CFG_C5_128_K16: F<Cfg_C5_128_K16>(__VA_ARGS__); break;  \
+    case MD_CFG_C5_32_K16: F<Cfg_C5_32_K16>(__VA_ARGS__); break;
+#define MD_CFG_CASES_ABL(F, ...)                                    \
+    case MD_CFG_C3_128_W4: F<Cfg_C3_128_W4>(__VA_ARGS__); break;    \
     case MD_CFG_C3_128_V2: F<Cfg_C3_128_V2>(__VA_ARGS__); break;    \
     case MD_CFG_C3_128_SW: F<Cfg_C3_128_SW>(__VA_ARGS__); break;    \
     case MD_CFG_C3_128_PIPE: F<Cfg_C3_128_PIPE>(__VA_ARGS__); break; \
-    case MD_CFG_C3_128_V3: F<Cfg_C3_128_V3>(__VA_ARGS__); break; \
-    case MD_CFG_C3_128_V3B: F<Cfg_C3_128_V3B>(__VA_ARGS__); break; \
-    case MD_CFG_C3_128_V4: F<Cfg_C3_128_V4>(__VA_ARGS__); break; \
-    case MD_CFG_C5_128_K16: F<Cfg_C5_128_K16>(__VA_ARGS__); break; \
-    case MD_CFG_C5_32_K16: F<Cfg_C5_32_K16>(__VA_ARGS__); break; \
-    case 101: F<Cfg_ABL1>(__VA_ARGS__); break; \
-    case 102: F<Cfg_ABL2>(__VA_ARGS__); break; \
-    case 103: F<Cfg_ABL3>(__VA_ARGS__); break; \
-    case 104: F<Cfg_ABL4>(__VA_ARGS__); break; \
-    case 105: F<Cfg_ABL5>(__VA_ARGS__); break; \
-    default: return MD_ERR_UNSUPPORTED;                             \
-  }
+    case MD_CFG_C3_128_V3: F<Cfg_C3_128_V3>(__VA_ARGS__); break;    \
+    case MD_CFG_C3_128_V3B: F<Cfg_C3_128_V3B>(__VA_ARGS__); break;  \
+    case MD_CFG_C3_128_V4: F<Cfg_C3_128_V4>(__VA_ARGS__); break;    \
+    case 101: F<Cfg_ABL1>(__VA_ARGS__); break;                      \
+    case 102: F<Cfg_ABL2>(__VA_ARGS__); break;                      \
+    case 103: F<Cfg_ABL3>(__VA_ARGS__); break;                      \
+    case 104: F<Cfg_ABL4>(__VA_ARGS__); break;                      \
+    case 105: F<Cfg_ABL5>(__VA_ARGS__); break;
+#ifdef MD_BUILD_ABLATIONS
+#define MD_CFG_SWITCH_LAUNCH(cfg, F, ...) \
+  switch (cfg) { MD_CFG_CASES_PROD(F, __VA_ARGS__) MD_CFG_CASES_ABL(F, __VA_ARGS__) default: return MD_ERR_UNSUPPORTED; }
+#else
+#define MD_CFG_SWITCH_LAUNCH(cfg, F, ...) \
+  switch (cfg) { MD_CFG_CASES_PROD(F, __VA_ARGS__) default: return MD_ERR_UNSUPPORTED; }
+#endif
+// geometry queries never instantiate a kernel: every configuration answers
+#define MD_CFG_SWITCH_INFO(cfg, F, ...) \
+  switch (cfg) { MD_CFG_CASES_PROD(F, __VA_ARGS__) MD_CFG_CASES_ABL(F, __VA_ARGS__) default: return MD_ERR_UNSUPPORTED; }
 
 int md_launch_conv3_main(const MdGemmConvArgs& a, hipStream_t stream);  // conv3_main.hip
 
@@ -694,16 +704,16 @@ extern "C" int md_gemm_conv(const MdGemmConvArgs* args, void* stream) {
     return MD_ERR_BAD_ARG;
   int rc = MD_OK;
   hipStream_t st = (hipStream_t)stream;
-  if (args->cfg == MD_CFG_C3_128_FAST || (args->cfg >= 111 && args->cfg <= 118)) return md_launch_conv3_main(*args, st);
+  if (args->cfg == MD_CFG_C3_128_FAST || (args->cfg >= 111 && args->cfg <= 127)) return md_launch_conv3_main(*args, st);
   if (args->stats != nullptr) return MD_ERR_UNSUPPORTED;   // epilogue statistics: dedicated 3x3x3 kernel only
-  MD_CFG_SWITCH(args->cfg, rc = launch_cfg, *args, st);
+  MD_CFG_SWITCH_LAUNCH(args->cfg, rc = launch_cfg, *args, st);
   return rc;
 }
 
 extern "C" int md_gemm_conv_cfg_info(int32_t cfg, int32_t* nt, int32_t* kc, int32_t* cols,
                                      int32_t* taps, int32_t* lds_bytes, int32_t* threads) {
-  if (cfg == MD_CFG_C3_128_FAST || (cfg >= 111 && cfg <= 118)) cfg = MD_CFG_C3_128_V2;  // same tile geometry and LDS image
-  MD_CFG_SWITCH(cfg, cfg_info, nt, kc, cols, taps, lds_bytes, threads);
+  if (cfg == MD_CFG_C3_128_FAST || (cfg >= 111 && cfg <= 127)) cfg = MD_CFG_C3_128_V2;  // same tile geometry and LDS image  // same tile geometry and LDS image
+  MD_CFG_SWITCH_INFO(cfg, cfg_info, nt, kc, cols, taps, lds_bytes, threads);
   return MD_OK;
 }
 

@@ -17,6 +17,9 @@ from ._lib import (A_PACKED, A_S16B, PREC_BF16X3, PREC_FP16X2, CFG_C3_128, CFG_C
 
 CFG_ABL1, CFG_ABL2, CFG_ABL3, CFG_ABL4, CFG_ABL5 = 101, 102, 103, 104, 105
 CFG_F1, CFG_F3, CFG_F4, CFG_F6, CFG_F7, CFG_F8 = 111, 113, 114, 116, 117, 118   # timing-only ablations of the dedicated kernel (MD_BUILD_ABLATIONS=1)
+CFG_FAST_EC = 122   # A/B variant of the dedicated kernel (valid results): early weight commit
+# shader cycles over which the dedicated conv kernel spreads the start of each CU's first workgroup (0 = off)
+CONV_STAGGER = int(os.environ.get("MD_CONV_STAGGER", "0"))
 DEBUG_ACT_FP16 = 2 if os.environ.get("MD_DEBUG_ACT_FP16") == "1" else 0   # precision experiment only
 # Arithmetic of the dedicated 3x3x3 conv kernel: "bf16x3" (default; ~1e-5 per U-Net evaluation) or "fp16x2"
 # (weights split fp16, activations one fp16; ~1e-3 per evaluation, 7e-5 after the 999-step sampler).
@@ -137,7 +140,7 @@ def pack_s16b_from_matrix(w_kp, device):
 # ---------------------------------------------------------------------------------------------
 def gemm_conv(*, cfg, a, b, out, batch, rows, rows_alloc, kdim, dims, bias=None, bias_bstride=0,
               residual=None, res_bstride=0, alpha=1.0, ups=0, a_src=A_PACKED, a_rows=0, a_bstride=0,
-              b_bstride=None, out_mode=OUT_F32B, ksplit=1, prec=PREC_BF16X3, stats=None):
+              b_bstride=None, out_mode=OUT_F32B, ksplit=1, prec=PREC_BF16X3, stats=None, stagger=None):
     """stats: optional zeroed float64 [batch][rows_alloc][2] receiving per-(sample, channel) sum / sum of squares of
     the output (CFG_C3_128_FAST without split-K only)."""
     lib = _lib.load()
@@ -161,6 +164,7 @@ def gemm_conv(*, cfg, a, b, out, batch, rows, rows_alloc, kdim, dims, bias=None,
     args.b_bstride = b_bstride
     args.prec = prec
     args.stats = stats.data_ptr() if stats is not None else None
+    args.stagger = CONV_STAGGER if stagger is None else int(stagger)
     part = None
     if ksplit > 1:
         if out_mode != OUT_F32B:

@@ -113,6 +113,18 @@ def get_step_fn(sde, train, optimize_fn=None, mask=None, loss_type="l2"):
 
     def step_fn(state, batch, clear_grad=True, update_param=True):
         model = state["model"]
+        tm = state.get("timers")              # bench.py: a dict -> device-synchronised phase times of this step (ms)
+        clock = [0.0]
+
+        def mark(name):
+            if tm is not None:
+                import time
+                torch.cuda.synchronize()
+                now = time.perf_counter()
+                if name is not None:
+                    tm[name] = (now - clock[0]) * 1e3
+                clock[0] = now
+        mark(None)
         if train:
             optimizer = state["optimizer"]
             net = getattr(model, "module", model)
@@ -126,6 +138,7 @@ def get_step_fn(sde, train, optimize_fn=None, mask=None, loss_type="l2"):
             if fg is not None:
                 fg.attach()
             loss = loss_fn(model, batch)
+            mark("fwd_loss")
             # one process per GPU: the replicas' gradients meet here.  On the step that updates the parameters the
             # U-Net backward announces finished layers to the reducer, whose bucket all-reduces overlap the rest of
             # the backward (no-op for a single process).
@@ -137,12 +150,15 @@ def get_step_fn(sde, train, optimize_fn=None, mask=None, loss_type="l2"):
             finally:
                 if hasattr(net, "_grad_ready_hook"):
                     del net._grad_ready_hook
+            mark("bwd")                                # includes the bucket all-reduces that ran under it
             if update_param:
                 reducer.finish(model.parameters())
+                mark("exchange_exposed")               # what the backward did not hide
                 state["exchange"] = reducer.stats      # buckets / bytes of this step's all-reduces (bench.py reports them)
                 optimize_fn(optimizer, model.parameters(), step=state["step"])
             state["step"] += 1
             state["ema"].update(model.parameters())
+            mark("clip_adam_ema")
         else:
             with torch.no_grad():
                 ema = state["ema"]

@@ -20,18 +20,24 @@ def shard_sizes(total, world):
     return [base + (1 if r < rem else 0) for r in range(world)]
 
 
-def init_distributed(backend=None):
-    """Initialise from the torchrun environment; returns (rank, world, local_rank).  No-op for world 1."""
+# Self-test switch: run the gradient exchange's collectives even in a world of one rank (RCCL all-reduce of every
+# bucket onto itself) -- tests/test_gpu_dist.py uses it to execute the "nccl" code path on a single-GPU box.
+FORCE_EXCHANGE = False
+
+
+def init_distributed(backend=None, force=False):
+    """Initialise from the torchrun environment; returns (rank, world, local_rank).  No-op for world 1 unless `force`."""
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend, rank=rank, world_size=world)
+        kw = dict(device_id=torch.device("cuda", local_rank)) if backend == "nccl" else {}
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
     return rank, world, local_rank
 
 
@@ -192,7 +198,7 @@ class GradReducer:
 
     def __init__(self, cap_bytes=128 << 20, flat=None, force=False):
         self.cap = int(cap_bytes)
-        self.active = dist.is_initialized() and (dist.get_world_size() > 1 or force)
+        self.active = dist.is_initialized() and (dist.get_world_size() > 1 or force or FORCE_EXCHANGE)
         self.flat = flat
         self.cur, self.cur_bytes, self.pending, self.done = [], 0, [], set()
         self.frontier = self.sent = 0          # flat mode: params [0, frontier) are final, elements [0, sent) are on the wire

@@ -116,9 +116,10 @@ def test_c_abi_exports_every_declared_symbol(hip_lib):
 
 def test_struct_layout_matches_header():
     from meshdiffusion_amd._lib import MdGemmConvArgs
-    # 5 pointers, 1 float + 12 int32 (+pad), 4 int64, 1 pointer, 2 int32, 1 pointer -> natural alignment, no surprises
-    assert ctypes.sizeof(MdGemmConvArgs) == 5 * 8 + 13 * 4 + 4 + 4 * 8 + 8 + 2 * 4 + 8
-    assert MdGemmConvArgs.stats.offset == ctypes.sizeof(MdGemmConvArgs) - 8
+    # 5 pointers, 1 float + 12 int32 (+pad), 4 int64, 1 pointer, 2 int32, 1 pointer, 2 int32 -> natural alignment, no surprises
+    assert ctypes.sizeof(MdGemmConvArgs) == 5 * 8 + 13 * 4 + 4 + 4 * 8 + 8 + 2 * 4 + 8 + 2 * 4
+    assert MdGemmConvArgs.stats.offset == ctypes.sizeof(MdGemmConvArgs) - 16
+    assert MdGemmConvArgs.stagger.offset == ctypes.sizeof(MdGemmConvArgs) - 8
     assert MdGemmConvArgs.a_bstride.offset % 8 == 0
 
 

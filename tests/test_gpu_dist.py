@@ -100,3 +100,60 @@ def test_two_replicas_one_step_equals_full_batch_step(hip_lib):
     assert len(res[0][2]) == len(grads_full) and rel(res[0][2], grads_full) < 1e-5
     # ... and so is the update, up to Adam's first step turning 1e-7 differences of near-zero gradients into +-lr
     assert rel(res[0][1], params_full) < 1e-4
+
+
+def _nccl_world1_worker(port, q):
+    """RCCL ("nccl" backend) in a world of ONE rank on the one GPU of this box: the backend branch of
+    parallel.init_distributed, GradReducer's in-place AVG bucket all-reduces on the flat gradient buffer (launched from
+    the HIP backward) and the copying fallback all execute on RCCL; averaging over one rank must change nothing."""
+    os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from meshdiffusion_amd.lib.diffusion import parallel
+    rank, world, _ = parallel.init_distributed(backend="nccl", force=True)
+    assert (rank, world) == (0, 1) and dist.get_backend() == "nccl"
+    # plain buffers through both reducer modes
+    g = torch.Generator().manual_seed(1)
+    ps = [torch.nn.Parameter(torch.randn(s, generator=g).cuda()) for s in ((300, 7), (5,), (64, 64, 3))]
+    grads = [torch.randn(p.shape, generator=g).cuda() for p in ps]
+    fg = parallel.FlatGrads(ps)
+    fg.attach()
+    for p, gr in zip(ps, grads):
+        p.grad.copy_(gr)
+    red = parallel.GradReducer(cap_bytes=4096, flat=fg, force=True)
+    assert red.active and red.avg is not None
+    red.ready(ps[:2]); red.finish(ps)
+    torch.cuda.synchronize()
+    assert red.stats["buckets"] == 2 and all(torch.equal(p.grad, gr) for p, gr in zip(ps, grads))
+    for p, gr in zip(ps, grads):
+        p.grad = gr.clone()
+    red = parallel.GradReducer(cap_bytes=4096, force=True)
+    red.ready(ps[2:]); red.finish(ps)
+    torch.cuda.synchronize()
+    assert all(torch.equal(p.grad, gr) for p, gr in zip(ps, grads))
+    # one real training step with the exchange forced on == the same step without it
+    plain = _one_step(0, 1, slice(0, B_TOTAL))
+    parallel.FORCE_EXCHANGE = True
+    forced = _one_step(0, 1, slice(0, B_TOTAL))
+    def rel(xs, ys):
+        num = sum(float((a.double() - b.double()).pow(2).sum()) for a, b in zip(xs, ys))
+        return (num / sum(float(b.double().pow(2).sum()) for b in ys)) ** 0.5
+    # (two runs of the step differ by the order of the fp64 GroupNorm-statistics atomics: compare to 1e-6, not bitwise)
+    q.put(("ok", plain[0], forced[0], max(rel(forced[2], plain[2]), rel(forced[1], plain[1]))))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rccl_world_size_1_gradient_exchange(hip_lib):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_nccl_world1_worker, args=(_free_port(), q))
+    p.start()
+    try:
+        tag, l0, l1, same = q.get(timeout=300)
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    finally:
+        _reap([p])
+    # gradients through RCCL AVG over one rank are unchanged; so are the updated parameters
+    assert tag == "ok" and abs(l0 - l1) <= 1e-6 * abs(l0) and same < 1e-6, (l0, l1, same)

@@ -38,6 +38,9 @@ def test_dmtet_bit_exact_vs_reference_golden(hip_lib, tet):
         assert _sha(v.cpu().numpy()) == str(gold[f"{name}_verts_sha"]), f"{name}: verts differ"
         assert _sha(uv_idx.cpu().numpy()) == str(gold[f"{name}_uv_idx_sha"]), name
         assert _sha(vvi.cpu().numpy()) == str(gold[f"{name}_vvi_sha"]), name
+        assert uvs.dtype == torch.float32 and tuple(uvs.shape) == tuple(gold[f"{name}_uvs_shape"]), name
+        assert _sha(uvs.cpu().numpy()) == str(gold[f"{name}_uvs_sha"]), f"{name}: uvs differ"
+        assert ftet.dtype == torch.int64 and _sha(ftet.cpu().numpy()) == str(gold[f"{name}_ftet_sha"]), f"{name}: face_to_valid_tet differs"
 
 
 def test_dmtet_batch32_vs_oracle(hip_lib, tet):

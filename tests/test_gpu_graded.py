@@ -1,0 +1,188 @@
+"""K-step sampler parity at the BASELINE.json batch sizes (the sizes bench.py / tools/run_configs.py time):
+
+  configs[1]  res64 uncond, B = 8     25 ancestral steps vs the oracle evaluated with PyTorch fp32 ops on the same GPU
+  configs[3]  res128 uncond, B = 2    2 steps vs the UNMODIFIED reference sampler (CPU fixture, oracle/gen_golden.py)
+  configs[4]  cond_gen res64, B = 32  5 inpainting iterations (blend + re-noise each) vs the unmodified reference sampler
+plus the EMA swap-in / swap-out of the packed-weight caches around a training step.
+
+Fixtures hold every `stride`-th LIVE cell (the sampler zeroes masked cells, and the lattice has no live cell on a ::4
+sub-grid), per-sample norms and per-(sample, channel) sums.  Tolerance: 1e-3 rel-L2 (BASELINE.json north_star)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLD, rel_l2
+
+pytestmark = pytest.mark.gpu
+TOL_SAMPLE = 1e-3
+
+
+def _check_stats(out, gold, mask, tag):
+    """`out` [B,C,R,R,R] on the CPU against a sample_stats() fixture."""
+    from oracle.gen_golden import sample_stats
+    mine = sample_stats(out, mask, int(gold["stride"]))
+    assert float(np.abs(gold["live"]).max()) > 0.1, "blind fixture"
+    e_live = rel_l2(mine["live"], gold["live"])
+    e_per = max(rel_l2(mine["live"][b], gold["live"][b]) for b in range(out.shape[0]))     # worst single sample
+    e_norm = float(np.abs(mine["norms"] - gold["norms"]).max() / gold["norms"].max())
+    e_sum = float(np.abs(mine["sums"] - gold["sums"]).max() / np.abs(gold["norms"]).max())
+    print(f"{tag}: live cells {e_live:.3e} (worst sample {e_per:.3e}), norms {e_norm:.3e}, sums {e_sum:.3e}")
+    assert e_live < TOL_SAMPLE and e_per < TOL_SAMPLE and e_norm < TOL_SAMPLE and e_sum < TOL_SAMPLE
+    assert float((out * (1 - torch.as_tensor(mask).view(1, 1, *out.shape[2:]))).abs().max()) == 0.0
+
+
+def _model(cfg_fn, seed, R):
+    from meshdiffusion_amd import synth
+    from meshdiffusion_amd.lib.diffusion.models import ddpm_res64, ddpm_res128, utils as mutils  # noqa: F401
+    cfg = cfg_fn(); cfg.device = torch.device("cuda")
+    model = mutils.create_model(cfg).eval()
+    sd = synth.sensitised_state_dict(model.module.state_dict(), seed=seed, grid_mask=synth.synthetic_grid_mask(R))
+    model.module.load_state_dict(sd, strict=True)
+    return cfg, model, sd
+
+
+def _cpu_noise(x):   # replay the reference's CPU generator stream on the host, ship to the GPU
+    return torch.randn(x.shape).to(x.device)
+
+
+def test_res64_batch8_25_steps_vs_oracle_fp32_on_gpu(hip_lib):
+    """configs[1] at the bench batch: 25 of the 1000 ancestral steps, B = 8, same per-step noise for both trajectories."""
+    from meshdiffusion_amd import synth
+    from meshdiffusion_amd.config import get_config_res64
+    from meshdiffusion_amd.lib.diffusion import sampling, sde_lib
+    from meshdiffusion_amd.lib.diffusion.models import utils as mutils
+    from oracle import unet_oracle as uo
+    cfg, model, sd = _model(get_config_res64, 1234, 64)
+    sd_gpu = {k: v.cuda() for k, v in sd.items()}
+    del sd
+    B, K, R = 8, 25, 64
+    sde = sde_lib.VPSDE(cfg.model.beta_min, cfg.model.beta_max, cfg.model.num_scales, device="cuda")
+    mask = synth.synthetic_grid_mask(R).view(1, R, R, R).cuda()
+    st = sampling.AncestralStepper(sde, (B, 4, R, R, R), device="cuda", grid_mask=mask)
+    model_fn = mutils.get_model_fn(model, train=False)
+    ocfg = synth.oracle_cfg(cfg)
+    torch.backends.cudnn.allow_tf32 = False
+    torch.backends.cuda.matmul.allow_tf32 = False
+    torch.manual_seed(42)
+    x_h = st.prior()
+    x_o = x_h.clone()
+    worst_eval = 0.0
+    with torch.no_grad():
+        for i in range(K):
+            z = torch.randn((B, 4, R, R, R), device="cuda")
+            x_h, xm_h = st.step(model_fn, x_h, i, draw=lambda _t: z)
+            e = torch.cat([uo.unet_res64_forward(sd_gpu, ocfg, x_o[b:b + 1], st.labels[i][b:b + 1]) for b in range(B)])
+            if i in (0, K - 1):
+                worst_eval = max(worst_eval, rel_l2(model_fn(x_o, st.labels[i]).cpu(), e.cpu()))
+            c = st.coef[i][0]
+            xm_o = ((x_o - c[0] / c[1] * e) / torch.sqrt(1.0 - c[0])) * mask
+            x_o = (((x_o - c[0] / c[1] * e) / torch.sqrt(1.0 - c[0])) + torch.sqrt(c[0]) * z) * mask
+    e_x, e_xm = rel_l2(x_h.cpu(), x_o.cpu()), rel_l2(xm_h.cpu(), xm_o.cpu())
+    per = max(rel_l2(xm_h[b].cpu(), xm_o[b].cpu()) for b in range(B))
+    print(f"res64 B=8, {K} steps vs fp32 oracle on the GPU: x {e_x:.3e} x_mean {e_xm:.3e} (worst sample {per:.3e}); "
+          f"U-Net evaluation {worst_eval:.3e}")
+    assert e_x < 1e-4 and e_xm < 1e-4 and per < 1e-4 and worst_eval < 1e-4
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(GOLD, "sampler_cond_res64_b32.npz")), reason="fixture not generated")
+def test_cond_gen_res64_batch32_vs_reference_golden(hip_lib):
+    """configs[4]: partial-grid inpainting at B = 32, first 5 iterations incl. the initial conditioning (whose
+    [B,B,...] broadcasting quirk makes the batch size matter) and the per-iteration blend + re-noise."""
+    from meshdiffusion_amd import synth
+    from meshdiffusion_amd.config import get_config_res64
+    from meshdiffusion_amd.lib.diffusion import sampling, sde_lib
+    from oracle.gen_golden import cond_inputs
+    gold = np.load(os.path.join(GOLD, "sampler_cond_res64_b32.npz"))
+    cfg, model, sd = _model(get_config_res64, 1234, 64)
+    del sd
+    B, K, R = int(gold["B"]), int(gold["K"]), 64
+    mask = synth.synthetic_grid_mask(R)
+    partial, pmask = cond_inputs(R, mask, seed=int(gold["cond_seed"]))
+    sde = sde_lib.VPSDE(cfg.model.beta_min, cfg.model.beta_max, cfg.model.num_scales, device="cuda")
+    fn = sampling.get_sampling_fn(cfg, sde, (B, 4, R, R, R), lambda x: x, 1e-3, grid_mask=mask.view(1, 1, R, R, R).cuda())
+    torch.manual_seed(int(gold["seed"]))
+    torch.cuda.reset_peak_memory_stats()
+    out, _ = fn(model, partial=partial.cuda(), partial_mask=pmask.cuda(), freeze_iters=int(gold["freeze_iters"]),
+                n_iters=K, noise_fn=_cpu_noise)
+    print(f"peak HBM {torch.cuda.max_memory_allocated() / 2 ** 30:.1f} GiB")
+    _check_stats(out.cpu(), gold, mask, f"cond_gen res64 B={B}, {K} iterations vs reference")
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(GOLD, "sampler_res128_b2.npz")), reason="fixture not generated")
+def test_res128_batch2_2_steps_vs_reference_golden(hip_lib):
+    """configs[3]: ddpm_res128 at 128^3, B = 2, first 2 ancestral steps (synthetic mask: the asset is missing upstream)."""
+    from meshdiffusion_amd import synth
+    from meshdiffusion_amd.config import get_config_res128
+    from meshdiffusion_amd.lib.diffusion import sampling, sde_lib
+    gold = np.load(os.path.join(GOLD, "sampler_res128_b2.npz"))
+    cfg, model, sd = _model(get_config_res128, int(gold["sd_seed"]), 128)
+    del sd
+    B, K, R = int(gold["B"]), int(gold["K"]), 128
+    mask = synth.synthetic_grid_mask(R)
+    sde = sde_lib.VPSDE(cfg.model.beta_min, cfg.model.beta_max, cfg.model.num_scales, device="cuda")
+    fn = sampling.get_sampling_fn(cfg, sde, (B, 4, R, R, R), lambda x: x, 1e-3, grid_mask=mask.view(1, R, R, R).cuda())
+    torch.manual_seed(int(gold["seed"]))
+    out, _ = fn(model, n_iters=K, noise_fn=_cpu_noise)
+    _check_stats(out.cpu(), gold, mask, f"res128 B={B}, {K} steps vs reference")
+
+
+def test_ema_swap_invalidates_packed_weights_around_train_steps(hip_lib):
+    """train step -> eval step (EMA weights swapped in and out) -> train step: every forward must see the weights that
+    are live at that moment (the packed conv/NIN/FiLM caches key on data_ptr/_version, which `p.data.copy_` leaves
+    unchanged).  The EMA is perturbed so that EMA != live weights."""
+    from meshdiffusion_amd import synth
+    from meshdiffusion_amd.lib.diffusion import losses, sde_lib
+    from meshdiffusion_amd.lib.diffusion.models import ddpm_res64, utils as mutils  # noqa: F401
+    from meshdiffusion_amd.lib.diffusion.models.ema import ExponentialMovingAverage
+    from oracle import unet_oracle as uo
+    cfg = synth.small_config(); cfg.device = torch.device("cuda")
+    cfg.optim.lr, cfg.optim.warmup = 0.0, 0          # the optimizer step leaves the weights where they are
+    model = mutils.create_model(cfg)
+    R = cfg.data.image_size
+    sd = synth.sensitised_state_dict(model.module.state_dict(), seed=1234, grid_mask=synth.synthetic_grid_mask(R))
+    model.module.load_state_dict(sd, strict=True)
+    ema = ExponentialMovingAverage(model.parameters(), decay=0.999)
+    g = torch.Generator().manual_seed(9)
+    for s in ema.shadow_params:                      # EMA = live * (1 + 5 % noise): a clearly different network
+        s.mul_(1.0 + 0.05 * torch.randn(s.shape, generator=g).to(s.device))
+    ema.update = lambda params: None                 # keep the perturbed EMA fixed across the train steps
+    sd_ema = dict(sd)
+    names = [n for n, p in model.module.named_parameters() if p.requires_grad]
+    for n, s in zip(names, ema.shadow_params):
+        sd_ema[n] = s.detach().cpu().clone()
+    opt = losses.get_optimizer(cfg, model.parameters())
+    sde = sde_lib.VPSDE(0.1, 20.0, 1000, device="cuda")
+    mask = synth.synthetic_grid_mask(R).view(1, 1, R, R, R).cuda()
+    train_fn = losses.get_step_fn(sde, train=True, optimize_fn=losses.optimization_manager(cfg), mask=mask)
+    eval_fn = losses.get_step_fn(sde, train=False, mask=mask)
+    batch = (synth.synthetic_inputs(2, 4, R, seed=8) * mask.cpu()).cuda()
+    state = dict(model=model, ema=ema, optimizer=opt, step=1)
+    model.train()
+
+    def oracle_loss(weights, seed):
+        torch.manual_seed(seed)
+        labels = torch.randint(0, 1000, (2,), device="cuda").cpu()
+        noise = torch.randn_like(batch).cpu()
+        b, m = batch.cpu(), mask.cpu()
+        _, sa, s1 = uo.vpsde_tables()
+        xt = (sa[labels, None, None, None, None] * b + s1[labels, None, None, None, None] * noise) * m
+        with torch.no_grad():
+            e = uo.unet_res64_forward(weights, synth.oracle_cfg(cfg), xt, labels)
+        ls = (torch.square(e - noise) * m).reshape(2, -1).mean(-1)
+        return float(ls.mean() / m.sum() * m.numel())
+
+    got = []
+    # step 3 catches "restore left EMA-packed weights behind" (no optimizer step between the eval and the forward that
+    # follows it touches the key); steps 5-6 catch the other order: a forward on live weights WITHOUT an optimizer step
+    # (gradient accumulation, update_param=False) followed by the EMA swap-in
+    for fn, seed, kw in ((train_fn, 1, {}), (eval_fn, 2, {}), (train_fn, 3, {}), (eval_fn, 4, {}),
+                         (train_fn, 5, dict(update_param=False)), (eval_fn, 6, {})):
+        torch.manual_seed(seed)
+        got.append(float(fn(state, batch, **kw)["loss"].detach()))
+    want = [oracle_loss(w, i + 1) for i, w in enumerate((sd, sd_ema, sd, sd_ema, sd, sd_ema))]
+    print("losses (train, eval/EMA, train, eval/EMA, train w/o update, eval/EMA):", got, want)
+    assert abs(want[0] - want[1]) / want[0] > 1e-3, "EMA perturbation too small to tell the two networks apart"
+    for a, b in zip(got, want):
+        assert abs(a - b) / abs(b) < 1e-4

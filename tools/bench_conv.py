@@ -25,8 +25,11 @@ def main():
     ap.add_argument("--cfgs", default="C3_128,C3_128_SW,C3_128_PIPE,C3_128_V2")
     ap.add_argument("--rounds", type=int, default=4)
     ap.add_argument("--shapes", default="0,1,2,3,4")
+    ap.add_argument("--stagger", type=int, default=0, help="A.stagger (shader cycles) for the *_STAG variants")
+    ap.add_argument("--no-residual", action="store_true", help="launch without the residual operand (Conv_0 shape of work)")
     a = ap.parse_args()
-    cfgs = [(n, getattr(ops, "CFG_" + n)) for n in a.cfgs.split(",")]
+    cfgs = [(n, getattr(ops, "CFG_" + n.replace("_STAG", ""))) for n in a.cfgs.split(",")]   # NAME_STAG = NAME with --stagger
+    print(f"# cfgs {a.cfgs} stagger {a.stagger} residual {not a.no_residual}")
     dev = "cuda"
     for si in [int(i) for i in a.shapes.split(",")]:
         B, cin, cout, S = SHAPES[si]
@@ -44,7 +47,8 @@ def main():
         def run(n, c):
             out = ops.f32b_empty(B, cout, P, dev)
             ops.gemm_conv(cfg=c, a=pws[n].data, b=act, out=out, batch=B, rows=cout, rows_alloc=cout, kdim=cin,
-                          dims=(S, S, S), bias=bias, bias_bstride=cout, residual=res, res_bstride=cout * P)
+                          dims=(S, S, S), bias=bias, bias_bstride=cout, residual=None if a.no_residual else res,
+                          res_bstride=cout * P, stagger=a.stagger if "STAG" in n else 0)
             return out
 
         for n, c in cfgs:
