@@ -233,6 +233,17 @@ int md_ancestral_step(const float* x, const float* eps, const float* z, const fl
                       const float* coef, float* x_out, float* x_mean_out, int32_t batch,
                       int32_t C, int64_t P, void* stream);
 /*
+ * One deterministic DDIM update (sde_lib.py:113-140 `discretize_ddim` + the mask / inpainting lines of
+ * `ddim_sampler`, sampling.py:556-565).  State in float64 like the reference:
+ *   x0s = x - a2*eps ; x0_pred = x0s/a1 ; x_new = r1*x + (r2-r1)*(x - x0s) ; both *= mask[P] (mask may be NULL);
+ *   channel `ch`: v = v*(1-pmask) + partial*pmask when partial/pmask ([P] each) are given.
+ * coef[b][4] = {a1 = sqrt(abar_t), a2 = sqrt(1-abar_t), r1 = a1_prev/a1, r2 = a2_prev/a2} as doubles;
+ * x_f32 receives float(x_new): the next U-Net input.
+ */
+int md_ddim_step(const double* x, const float* eps, const float* mask, const double* coef, const float* partial,
+                 const float* pmask, int32_t ch, double* x_out, double* x0_out, float* x_f32, int32_t batch,
+                 int32_t C, int64_t P, void* stream);
+/*
  * Inpainting blend of one channel (sampling.py:443-467):
  *   v = (x*(1-m) + src*m) * gm     applied in place to channel `ch` of x [B][C][P];
  *   src has batch stride src_bstride (0 = shared partial grid).

@@ -66,6 +66,7 @@ SIGNATURES = {
     "md_s16b_to_ncdhw": (C.c_int, [_P, _P, _I32, _I32, _I64, _P]),
     "md_softmax_keys": (C.c_int, [_P, _P, _I32, _I32, _I32, _P]),
     "md_ancestral_step": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I64, _P]),
+    "md_ddim_step": (C.c_int, [_P, _P, _P, _P, _P, _P, _I32, _P, _P, _P, _I32, _I32, _I64, _P]),
     "md_inpaint_blend": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _I64, _I64, _P]),
     "md_inpaint_renoise": (C.c_int, [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I64, _P]),
     "md_ddpm_perturb": (C.c_int, [_P, _P, _P, _P, _P, _I32, _I32, _I64, _P]),

@@ -199,6 +199,55 @@ extern "C" int md_ancestral_step(const float* x, const float* eps, const float* 
   return MD_OK;
 }
 
+// ---- deterministic DDIM update (reference sde_lib.py:113-140 `discretize_ddim`, sampling.py:556-565) ----
+// The reference keeps the state in float64 from the first update on (x.double() arithmetic, float32 only for the U-Net
+// input); so does this kernel.  Same operation order, no FMA contraction:
+//   x0s = x - a2*eps ; sst = x - x0s ; x0_pred = x0s / a1 ; x_new = r1*x + (r2 - r1)*sst   (r1 = a1p/a1, r2 = a2p/a2)
+// then both results times the grid mask, and the optional channel-`ch` inpainting blend v*(1-pm) + partial*pm
+// (sampling.py:562-564).  coef[b] = {a1, a2, r1, r2} as doubles (a1, a2 are float32 table entries widened).
+__global__ void md_ddim_step_kernel(const double* __restrict__ x, const float* __restrict__ eps,
+                                    const float* __restrict__ mask, const double* __restrict__ coef,
+                                    const float* __restrict__ partial, const float* __restrict__ pmask, int ch,
+                                    double* __restrict__ x_out, double* __restrict__ x0_out, float* __restrict__ x_f32,
+                                    int64_t CP, int64_t P) {
+  const int b = blockIdx.y;
+  const double a1 = coef[b * 4 + 0], a2 = coef[b * 4 + 1], r1 = coef[b * 4 + 2], r2 = coef[b * 4 + 3];
+  const double r21 = (-r1) + r2;
+  const int64_t base = (int64_t)b * CP;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < CP; i += (int64_t)gridDim.x * blockDim.x) {
+    const double xv = x[base + i];
+    const double x0s = xv - a2 * (double)eps[base + i];
+    const double sst = xv - x0s;
+    double x0p = x0s / a1;
+    double xn = r1 * xv + r21 * sst;
+    const int64_t pos = i % P;
+    if (mask) { const double m = (double)mask[pos]; xn = xn * m; x0p = x0p * m; }
+    if (partial != nullptr && i / P == ch) {
+      const double pm = (double)pmask[pos], pv = (double)partial[pos];
+      xn = xn * (1.0 - pm) + pv * pm;
+      x0p = x0p * (1.0 - pm) + pv * pm;
+    }
+    x_out[base + i] = xn;
+    x0_out[base + i] = x0p;
+    x_f32[base + i] = (float)xn;
+  }
+}
+
+extern "C" int md_ddim_step(const double* x, const float* eps, const float* mask, const double* coef, const float* partial,
+                            const float* pmask, int32_t ch, double* x_out, double* x0_out, float* x_f32, int32_t batch,
+                            int32_t C, int64_t P, void* stream) {
+  if (!x || !eps || !coef || !x_out || !x0_out || !x_f32 || batch <= 0 || C <= 0 || P <= 0) return MD_ERR_BAD_ARG;
+  if ((partial != nullptr) != (pmask != nullptr) || (partial != nullptr && (ch < 0 || ch >= C))) return MD_ERR_BAD_ARG;
+  const int64_t CP = (int64_t)C * P;
+  int blocks = (int)((CP + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  MD_HIP_CLEAR_ERROR();
+  hipLaunchKernelGGL(md_ddim_step_kernel, dim3((unsigned)blocks, (unsigned)batch), dim3(256), 0, (hipStream_t)stream, x, eps,
+                     mask, coef, partial, pmask, ch, x_out, x0_out, x_f32, CP, P);
+  MD_HIP_CHECK_LAUNCH();
+  return MD_OK;
+}
+
 // ---- inpainting blend of one channel (reference sampling.py:455-466) -----------------------
 __global__ void md_inpaint_blend_kernel(float* __restrict__ x, const float* __restrict__ src,
                                         const float* __restrict__ pmask, const float* __restrict__ gmask,

@@ -355,6 +355,23 @@ def ancestral_step(x, eps, z, mask, coef):
     return x_out, xm_out
 
 
+def ddim_step(x64, eps, mask, coef, partial=None, pmask=None, ch=0):
+    """x64 [B,C,D,H,W] float64 state, eps float32 U-Net output, mask [P] or None, coef [B,4] float64 = a1, a2, r1, r2;
+    partial / pmask: [P] float32 each or None.  Returns (x_new f64, x0_pred f64, x_new as f32)."""
+    lib = _lib.load()
+    for name, t in (("x", x64), ("eps", eps)):
+        _require_cuda(t, name)
+    assert x64.dtype == torch.float64 and eps.dtype == torch.float32 and coef.dtype == torch.float64
+    x64, eps, coef = x64.contiguous(), eps.contiguous(), coef.contiguous()
+    B, Cc = x64.shape[0], x64.shape[1]
+    P = x64[0, 0].numel()
+    x_out, x0_out = torch.empty_like(x64), torch.empty_like(x64)
+    x_f32 = torch.empty_like(eps)
+    check(lib.md_ddim_step(_ptr(x64), _ptr(eps), _ptr(mask), _ptr(coef), _ptr(partial), _ptr(pmask), int(ch), _ptr(x_out),
+                           _ptr(x0_out), _ptr(x_f32), B, Cc, P, _stream()), "md_ddim_step")
+    return x_out, x0_out, x_f32
+
+
 def inpaint_blend_(x, src, pmask, gmask, ch, src_bstride=0):
     """In place on channel `ch` of x: (x*(1-pmask) + src*pmask) * gmask."""
     lib = _lib.load()

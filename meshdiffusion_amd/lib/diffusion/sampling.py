@@ -2,7 +2,8 @@
 
 Host-side mirror of the reference's lib/diffusion/sampling.py: `get_sampling_fn` :83-117,
 `AncestralSamplingPredictor.vpsde_update_fn` :222-230, `NoneCorrector` :324-332,
-`get_pc_sampler`/`pc_sampler` :357-487 (unconditional loop :471-481, inpainting :429-467).
+`get_pc_sampler`/`pc_sampler` :357-487 (unconditional loop :471-481, inpainting :429-467), `DDIMPredictor` :249-257,
+`get_ddim_sampler`/`ddim_sampler` :500-570 (with sde_lib.py:113-140 `discretize_ddim`).
 
 Same call surface:
     fn = get_sampling_fn(config, sde, shape, inverse_scaler, eps, grid_mask=None)
@@ -14,6 +15,7 @@ numbers is the reference's.  Two optional keyword extensions used by tests/bench
     n_iters  -- run only the first n iterations of the N-step schedule
     noise_fn -- callable(x) -> z replacing torch.randn_like (to replay recorded noise)
 """
+import numpy as np
 import torch
 
 from . import sde_lib
@@ -82,6 +84,26 @@ class AncestralSamplingPredictor(Predictor):
         return ops.ancestral_step(x, eps_hat, z, mask, coef)
 
 
+@register_predictor(name="ddim")
+class DDIMPredictor(Predictor):
+    """Deterministic DDIM update between two (not necessarily adjacent) time levels; state in float64 like the
+    reference's `discretize_ddim` (sde_lib.py:113-140): one U-Net evaluation + one md_ddim_step launch."""
+
+    def coefficients(self, t, tprev):
+        """[B,4] float64 rows {a1, a2, a1_prev/a1, a2_prev/a2} for batch time vectors t, tprev (sde_lib.py:115-127)."""
+        sde = self.sde
+        k = (t * (sde.N - 1) / sde.T).long()
+        kp = (tprev * (sde.N - 1) / sde.T).long()
+        sa, s1 = sde.sqrt_alphas_cumprod.to(t.device), sde.sqrt_1m_alphas_cumprod.to(t.device)
+        a1, a2 = sa[k].double(), s1[k].double()
+        return torch.stack([a1, a2, sa[kp].double() / a1, s1[kp].double() / a2], dim=1).contiguous()
+
+    def update_fn(self, x, t, tprev=None, model=None, mask=None, partial=None, pmask=None, ch=0):
+        eps_hat = mutils.get_model_fn(model, train=False)(x.float(), t.float() * (self.sde.N - 1))
+        xn, x0p, _ = ops.ddim_step(x.double(), eps_hat, mask, self.coefficients(t, tprev), partial, pmask, ch)
+        return xn, x0p
+
+
 @register_predictor(name="none")
 class NonePredictor(Predictor):
     def update_fn(self, x, t, **_):
@@ -99,9 +121,12 @@ class NoneCorrector(Corrector):
 
 def get_sampling_fn(config, sde, shape, inverse_scaler, eps, grid_mask=None, return_traj=False):
     name = config.sampling.method.lower()
+    if name == "ddim":
+        return get_ddim_sampler(sde=sde, shape=shape, predictor=get_predictor("ddim"), inverse_scaler=inverse_scaler,
+                                n_steps=config.sampling.n_steps_each, denoise=config.sampling.noise_removal, eps=eps,
+                                device=config.device, grid_mask=grid_mask)
     if name != "pc":
-        raise ValueError(f"Sampler name {config.sampling.method} unknown / not implemented on the HIP path "
-                         "(the reference's 'ddim' branch is itself broken: sampling.py:569)")
+        raise ValueError(f"Sampler name {config.sampling.method} unknown.")
     return get_pc_sampler(sde=sde, shape=shape,
                           predictor=get_predictor(config.sampling.predictor.lower()),
                           corrector=get_corrector(config.sampling.corrector.lower()),
@@ -258,3 +283,67 @@ def get_pc_sampler(sde, shape, predictor, corrector, inverse_scaler, snr, n_step
             return inverse_scaler(x_mean if denoise else x), sde.N * (n_steps + 1)
 
     return pc_sampler
+
+
+def ddim_schedule(N, schedule="quad", num_steps=100):
+    """The sub-sequence of the N levels visited by the DDIM sampler (sampling.py:545-557), as fractional times seq/N.
+    'quad' is hard-wired to 100 points in the reference (`num_steps` only drives 'uniform'); kept."""
+    if schedule == "uniform":
+        seq = list(range(0, N, N // num_steps))
+    elif schedule == "quad":
+        seq = [int(v) for v in list(np.linspace(0, np.sqrt(N * 0.8), 100) ** 2)]
+    else:
+        raise ValueError(f"unknown DDIM schedule {schedule!r}")
+    return torch.tensor(seq) / N
+
+
+def get_ddim_sampler(sde, shape, predictor, inverse_scaler, n_steps=1, denoise=False, eps=1e-3, device="cuda",
+                     grid_mask=None):
+    """Deterministic DDIM sampler on a sub-sequence of the N levels (100-point quadratic schedule by default: 99 U-Net
+    evaluations instead of 999).  Mirrors `get_ddim_sampler` (sampling.py:500-570) with one repair: the reference's
+    return statement reads an undefined name (`encode`, sampling.py:569), so it raises NameError whenever
+    `config.sampling.noise_removal` is true; here `encode` is taken as False, i.e. noise_removal=True returns the last
+    x0 prediction and noise_removal=False returns the last state (the path the unmodified reference can run, pinned by
+    tests/golden/ddim_small.npz).  The state is float64 from the first update on, as in the reference."""
+    if predictor is not DDIMPredictor:
+        raise NotImplementedError("the DDIM sampler runs with the 'ddim' predictor")
+    B = shape[0]
+    P = int(shape[2] * shape[3] * shape[4])
+    dev = torch.device(device)
+
+    def ddim_sampler(model, schedule="quad", num_steps=100, x0=None, partial=None, partial_mask=None, partial_channel=0,
+                     n_iters=None):
+        with torch.no_grad():
+            gm = grid_mask.to(dev) if grid_mask is not None else None
+            gm_flat = None
+            if gm is not None:
+                gm_flat = gm.reshape(-1).to(torch.float32).contiguous()
+                assert gm_flat.numel() == P, "grid_mask must broadcast over batch and channels"
+            x = (x0.to(dev) if x0 is not None else sde.prior_sampling(shape).to(dev))
+            if gm is not None:
+                x = x * gm
+            part = pm = None
+            ch = partial_channel
+            if partial is not None:
+                part = partial.to(dev, torch.float32).reshape(-1).contiguous()
+                pm = partial_mask.to(dev, torch.float32).reshape(-1).contiguous()
+                assert part.numel() == P and pm.numel() == P, "partial / partial_mask: one grid shared by the batch"
+                x[:, ch] = x[:, ch] * (1 - pm.view(shape[2:])) + part.view(shape[2:]) * pm.view(shape[2:])
+            timesteps = ddim_schedule(sde.N, schedule, num_steps)
+            pred = predictor(sde, None)
+            model_fn = mutils.get_model_fn(model, train=False)
+            x64, x32, x0_pred = x.double(), x.float().contiguous(), x.double()
+            order = list(reversed(range(1, len(timesteps))))
+            if n_iters is not None:
+                order = order[:int(n_iters)]
+            for i in order:
+                vec_t = torch.ones(B, device=dev) * timesteps[i]
+                vec_tprev = torch.ones(B, device=dev) * timesteps[i - 1]
+                eps_hat = model_fn(x32, vec_t.float() * (sde.N - 1))
+                x64, x0_pred, x32 = ops.ddim_step(x64, eps_hat, gm_flat, pred.coefficients(vec_t, vec_tprev), part, pm, ch)
+            out = x0_pred if denoise else x64
+            if gm is not None:
+                out = out * gm
+            return inverse_scaler(out), sde.N * (n_steps + 1)
+
+    return ddim_sampler

@@ -9,6 +9,7 @@ outputs are stored):
   unet_small.npz     reference DDPMRes64 (small config) eps_hat, full tensor
   unet_res64.npz     reference DDPMRes64 (res64, B=1) eps_hat: ::4 subsample + statistics
   sampler_small.npz  unmodified reference pc_sampler, first K iterations, uncond + inpainting
+  ddim.npz           reference discretize_ddim on seeded inputs, the quad schedule, the whole DDIM sampler (small config)
   sampler_res64.npz  BASELINE config #1: res64, B=1, first 10 of 1000 ancestral steps (live cells + statistics)
   sampler_cond_res64_b32.npz  BASELINE config #5: cond_gen res64, B=32, first 5 iterations of the inpainting sampler
   sampler_res128_b2.npz       BASELINE config #4: res128, B=2, first 2 ancestral steps
@@ -264,6 +265,62 @@ def gen_graded(which):
                                 **sample_stats(xm, mask, 32))
 
 
+def gen_ddim():
+    """DDIM.  Pinned against the unmodified reference:
+      * `discretize_ddim` (sde_lib.py:113-140) on seeded x / eps for three (t, tprev) pairs of the quad schedule;
+      * the whole `ddim_sampler` (sampling.py:522-569) on the small config with config.sampling.noise_removal = False --
+        the only setting the reference can run: with noise_removal True its return statement reads the undefined name
+        `encode` (sampling.py:569) and raises NameError, which is asserted here.
+    The oracle restatement (unet_oracle.ddim_step / ddim_sample) is asserted equal to both."""
+    rsampling, rsde, rmutils = import_reference()
+    out = {}
+    with torch.no_grad():
+        cfg = synth.small_config(); cfg.device = torch.device("cpu")
+        R = cfg.data.image_size
+        sde = rsde.VPSDE(beta_min=cfg.model.beta_min, beta_max=cfg.model.beta_max, N=cfg.model.num_scales)
+        g = torch.Generator().manual_seed(31)
+        x = torch.randn((2, 4, 4, 4, 4), generator=g)
+        eps_fix = torch.randn((2, 4, 4, 4, 4), generator=g)
+        rs = sde.reverse(lambda xx, tt: eps_fix, probability_flow=False)
+        seq = [int(v) for v in list(np.linspace(0, np.sqrt(sde.N * 0.8), 100) ** 2)]
+        ts = torch.tensor(seq) / sde.N
+        out["seq"] = np.array(seq, dtype=np.int64)
+        for n, i in enumerate((99, 50, 5)):
+            vt, vp = torch.ones(2) * ts[i], torch.ones(2) * ts[i - 1]
+            xin = x if n == 0 else x.double() * 0.7          # float32 state (first update) and float64 states (later ones)
+            xn, x0p = rs.discretize_ddim(xin, vt, tprev=vp)
+            assert xn.dtype == torch.float64 and x0p.dtype == torch.float64
+            xo, x0o = unet_oracle.ddim_step(xin, eps_fix, vt, vp, sde.N)
+            assert torch.equal(xo, xn) and torch.equal(x0o, x0p), "oracle ddim_step != reference discretize_ddim"
+            out[f"step{n}_x_new"], out[f"step{n}_x0_pred"], out[f"step{n}_i"] = xn.numpy(), x0p.numpy(), np.int64(i)
+        out["step_seed"] = np.int64(31)
+        # ---- whole sampler, small config ----
+        sd = make_sd(cfg, R)
+        model = ref_model(rmutils, cfg, sd)
+        mask = synth.synthetic_grid_mask(R).view(1, R, R, R)
+        cfg.sampling.method = "ddim"
+        for nr, expect_error in ((True, True), (False, False)):
+            cfg.sampling.noise_removal = nr
+            fn = rsampling.get_sampling_fn(cfg, sde, (2, 4, R, R, R), lambda v: v, 1e-3, grid_mask=mask)
+            torch.manual_seed(55)
+            try:
+                res, _ = fn(model)
+                failed = False
+            except NameError as e:
+                failed = True
+                print(f"[ddim] reference with noise_removal={nr}: NameError({e})")
+            assert failed == expect_error
+        torch.manual_seed(55)
+        x_init = torch.randn(2, 4, R, R, R)
+        xo = unet_oracle.ddim_sample(lambda xx, lb: unet_oracle.unet_res64_forward(sd, synth.oracle_cfg(cfg), xx, lb), x_init,
+                                     mask, sde.N, denoise=False)
+        e = rel_l2(xo, res)
+        print(f"[ddim] oracle vs reference 99-evaluation DDIM sampler (small config) rel-L2 = {e:.3e}; out std {float(res.std()):.3f}")
+        assert e < 1e-6 and res.dtype == torch.float64
+        out["sampler_small"], out["sampler_seed"] = res.numpy().astype(np.float64), np.int64(55)
+    np.savez_compressed(os.path.join(GOLD, "ddim.npz"), **out)
+
+
 def gen_res128_full(rmutils):
     """Reference DDPMRes128 at 128^3 (BASELINE config #4 shape), one evaluation: ::8 subsample + statistics."""
     from meshdiffusion_amd.config import get_config_res128
@@ -479,7 +536,7 @@ def gen_dataset():
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-res64", action="store_true")
-    ap.add_argument("--only", choices=["unet", "dmtet", "dataset", "train", "graded"], default=None)
+    ap.add_argument("--only", choices=["unet", "dmtet", "dataset", "train", "graded", "ddim"], default=None)
     ap.add_argument("--graded", default="config1,cond32,res128", help="which graded-size sampler fixtures to (re)generate")
     a = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
@@ -492,6 +549,8 @@ if __name__ == "__main__":
         gen_train(full=not a.skip_res64)
     if a.only in (None, "unet"):
         gen_unet_and_sampler(a.skip_res64)
+    if a.only in (None, "ddim"):
+        gen_ddim()
     if a.only == "graded" or (a.only is None and not a.skip_res64):
         gen_graded(a.graded.split(","))
     print("golden fixtures written to", GOLD)

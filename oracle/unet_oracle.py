@@ -179,3 +179,38 @@ def marginal_prob_coef(t, beta_0=0.1, beta_1=20.0):
     """sde_lib.py:210-214."""
     lmc = -0.25 * t ** 2 * (beta_1 - beta_0) - 0.5 * t * beta_0
     return torch.exp(lmc), torch.sqrt(1.0 - torch.exp(2.0 * lmc))
+
+
+def ddim_step(x, eps_hat, t, tprev, N=1000):
+    """lib/diffusion/sde_lib.py:113-140 (`discretize_ddim`, use_clip False) for batch time vectors t, tprev; `eps_hat` is
+    the network output (the reference builds this sampler's score_fn with std_scale=False, models/utils.py:185-189).
+    Returns (x_new, x0_pred), both float64 like the reference."""
+    _, sa, s1 = vpsde_tables(N)
+    k, kp = (t * (N - 1) / 1).long(), (tprev * (N - 1) / 1).long()
+    a1, a2 = sa[k][:, None, None, None, None], s1[k][:, None, None, None, None]
+    a1p, a2p = sa[kp][:, None, None, None, None], s1[kp][:, None, None, None, None]
+    r1, r2 = a1p.double() / a1.double(), a2p.double() / a2.double()
+    x0s = x.double() - a2.double() * eps_hat.double()
+    sst = x - x0s
+    x0_pred = x0s / a1
+    x_new = r1.double() * x + (-r1 + r2.double()) * sst.double()
+    return x_new, x0_pred
+
+
+def ddim_sample(eps_fn, x_init, mask, N=1000, denoise=True, n_iters=None):
+    """lib/diffusion/sampling.py:522-569 (`ddim_sampler`, 'quad' schedule, no partial grid) with `encode` read as False."""
+    import numpy as np
+    seq = [int(v) for v in list(np.linspace(0, np.sqrt(N * 0.8), 100) ** 2)]
+    timesteps = torch.tensor(seq) / N
+    x = x_init * mask
+    x0_pred = x
+    order = list(reversed(range(1, len(timesteps))))
+    if n_iters is not None:
+        order = order[:n_iters]
+    for i in order:
+        vec_t = torch.ones(x.shape[0]) * timesteps[i]
+        vec_tprev = torch.ones(x.shape[0]) * timesteps[i - 1]
+        e = eps_fn(x.float(), vec_t.float() * (N - 1))
+        x, x0_pred = ddim_step(x, e, vec_t, vec_tprev, N)
+        x, x0_pred = x * mask, x0_pred * mask
+    return (x0_pred if denoise else x) * mask

@@ -335,3 +335,22 @@ def test_plain_c_host_links_and_runs(tmp_path, hip_lib):
     run = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert run.returncode == 0 and "ok" in run.stdout, run.stdout + run.stderr
     assert f"sizeof(MdGemmConvArgs)={ctypes.sizeof(_lib.MdGemmConvArgs)}" in run.stdout
+
+
+def test_ddim_oracle_and_schedule_vs_reference_golden():
+    """oracle ddim_step == the unmodified reference's discretize_ddim (float64, bit for bit) on the recorded inputs,
+    and the host sampler's 100-point quadratic schedule == sampling.py:548-557."""
+    from meshdiffusion_amd.lib.diffusion import sampling
+    from oracle import unet_oracle as uo
+    gold = np.load(os.path.join(GOLD, "ddim.npz"))
+    ts = sampling.ddim_schedule(1000)
+    assert len(ts) == 100 and np.array_equal((ts * 1000).round().long().numpy(), gold["seq"])
+    assert np.array_equal(sampling.ddim_schedule(1000, "uniform", 100).numpy(), (np.arange(0, 1000, 10) / 1000).astype(np.float32))
+    g = torch.Generator().manual_seed(int(gold["step_seed"]))
+    x = torch.randn((2, 4, 4, 4, 4), generator=g)
+    eps = torch.randn((2, 4, 4, 4, 4), generator=g)
+    for n in range(3):
+        i = int(gold[f"step{n}_i"])
+        xin = x if n == 0 else x.double() * 0.7
+        xn, x0p = uo.ddim_step(xin, eps, torch.ones(2) * ts[i], torch.ones(2) * ts[i - 1])
+        assert np.array_equal(xn.numpy(), gold[f"step{n}_x_new"]) and np.array_equal(x0p.numpy(), gold[f"step{n}_x0_pred"])
