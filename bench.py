@@ -239,10 +239,19 @@ def conv_source_key():
 
 def roofline(events, hip_ops, a, B, wall_prof):
     """Dominant kernel from the HIP events of the untimed second pass (events on the launch stream)."""
-    main = [(f, s.elapsed_time(e) * 1e-3, ab) for (c, f, s, e, ab) in events if c == hip_ops.CFG_C3_128_FAST]
+    main = [(f, s.elapsed_time(e) * 1e-3, ab) for (c, f, s, e, ab, _) in events if c == hip_ops.CFG_C3_128_FAST]
     tot_f, tot_t = sum(f for f, _, _ in main), sum(t for _, t, _ in main)
     alg_bytes = sum(ab for _, _, ab in main) / max(len(main), 1)
-    allt = sum(s.elapsed_time(e) * 1e-3 for (_, _, s, e, _) in events)
+    allt = sum(s.elapsed_time(e) * 1e-3 for (_, _, s, e, _, _) in events)
+    # per-shape breakdown of every GEMM / conv launch of one step: count, ms per step, algorithmic TFLOP/s
+    shapes = {}
+    for (c, f, s, e, _, tag) in events:
+        k = f"cfg{c}:{tag}"
+        v = shapes.setdefault(k, [0, 0.0, 0.0])
+        v[0] += 1; v[1] += s.elapsed_time(e); v[2] += f
+    ns = min(a.steps, 5)
+    per_shape = {k: {"n_per_step": v[0] // ns, "ms_per_step": round(v[1] / ns, 3), "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 1)}
+                 for k, v in sorted(shapes.items(), key=lambda kv: -kv[1][1])}
     n_steps = min(a.steps, 5)
     ach = tot_f / tot_t / 1e12
     traffic, traffic_src = None, None
@@ -267,6 +276,7 @@ def roofline(events, hip_ops, a, B, wall_prof):
             "launches": len(main), "avg_launch_ms": round(tot_t / max(len(main), 1) * 1e3, 4),
             "kernel_time_share_of_step": round(tot_t / n_steps / wall_prof, 4),
             "all_gemm_conv_time_share_of_step": round(allt / n_steps / wall_prof, 4),
+            "per_shape": per_shape,
             "note": "achieved = algorithmic 2*M*N*K flops (1x, not the 3 bf16 MFMAs issued per product) / HIP-event "
                     "time of every launch of this kernel in an untimed pass right after the timed region (the timed "
                     "region itself carries no events); ceiling of the bf16x3 scheme is 1/3 of peak"}

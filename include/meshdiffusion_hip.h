@@ -42,7 +42,7 @@ extern "C" {
 #define MD_ERR_UNSUPPORTED (-2)
 #define MD_ERR_NO_DEVICE (-3)
 
-#define MD_ABI_VERSION 6
+#define MD_ABI_VERSION 7
 
 /* ---- tile configurations of md_gemm_conv (compile-time instantiations) ---- */
 enum {
@@ -73,6 +73,7 @@ enum {
 
 enum { MD_OUT_F32B = 0, MD_OUT_S16B = 1, MD_OUT_NCDHW = 2 };
 enum { MD_A_PACKED = 0, MD_A_S16B = 1 };
+enum { MD_B_S16B = 0, MD_B_F32B_GN = 1 };
 /* MD_PREC_BF16X3: both operands split bf16 (hi, lo), 3 MFMAs per product (default, ~1e-5 per U-Net eval).
  * MD_PREC_FP16X2: weights split fp16 (hi, lo), activations ONE fp16 (plane 0 only), 2 MFMAs per product
  *                 (~1e-3 per eval, 7e-5 after 999 sampler steps; MD_CFG_C3_128_FAST only). */
@@ -122,8 +123,20 @@ typedef struct MdGemmConvArgs {
                          /* zeroes) -- the GroupNorm statistics of the consumer without another pass   */
                          /* over the tensor.  MD_CFG_C3_128_FAST, F32B output, no split-K; else error  */
   int32_t stagger;       /* MD_CFG_C3_128_FAST: shader cycles over which the start of the first workgroup */
-                         /* of each CU is spread (0 = off), so the CUs' epilogue bursts do not coincide   */
-  int32_t reserved0;
+                         /* of each CU is spread (0 = off); measured neutral on MI355X, kept as A/B switch */
+  int32_t b_mode;        /* MD_B_S16B (0) or MD_B_F32B_GN (MD_CFG_C3_128_FAST, MD_PREC_BF16X3 only): `b` (and  */
+                         /* `b2`) are fp32 F32B tensors [B][C/8][P_in][8]; the kernel applies                 */
+                         /* y = x*ac[c][0] + ac[c][1] (GroupNorm affine), SiLU (b_silu) and the bf16 hi/lo    */
+                         /* split while it stages the halo tile in LDS -- nn.GroupNorm + nn.SiLU              */
+                         /* (layers.py:676-681) without a pass of their own; positions outside the grid are   */
+                         /* zero AFTER the transform (the conv pads the activated tensor)                     */
+  const void* b2;        /* MD_B_F32B_GN: second part of a channel-concatenated input (torch.cat([h, skip], 1), */
+                         /* ddpm_res64.py:174-176): K channels [b_split, kdim); NULL when b_split >= kdim    */
+  const float* b_ac;     /* MD_B_F32B_GN: [B][kdim][2] = (rstd*gamma, beta - mean*rstd*gamma) from            */
+                         /* md_gn_finalize, or NULL: no affine, no SiLU (plain split: Upsample's conv)        */
+  int64_t b2_bstride;    /* floats between batches of b2 (b_bstride: floats between batches of b in this mode) */
+  int32_t b_split;       /* channels taken from `b` (multiple of 8)                                           */
+  int32_t b_silu;        /* apply SiLU after the affine                                                      */
 } MdGemmConvArgs;
 
 int md_abi_version(void);
@@ -159,7 +172,7 @@ int64_t md_packed_weight_bytes(int32_t rows, int32_t kdim, int32_t taps, int32_t
  *               F32B tensor x[B][C/8][P][8] into sums[B][c_total][2] at channel
  *               offset c_off.  `sums` must be zeroed by the caller (md_zero).
  * md_gn_finalize: per-(b,c) params float4 = (mean(group), rstd(group)*gamma[c], beta[c], rstd(group))
- *               (biased variance, as torch's GroupNorm).
+ *               (biased variance, as torch's GroupNorm); optionally also the folded affine `ac`.
  * md_gn_apply : y = (x-mean)*rstd*gamma + beta (norm=1) ; y = silu(y) (silu=1); writes the
  *               split-bf16 S16B tensor out[B][c_total/8][2][P][8] at c_off.
  *               norm=0 copies/splits raw x (used for the NIN shortcut input).
@@ -176,7 +189,9 @@ int md_gn_stats(const float* x, double* sums, int32_t batch, int32_t C, int64_t 
                 int32_t c_total, int32_t c_off, void* stream);
 int md_gn_finalize(const double* sums, const float* gamma, const float* beta,
                    float* params, int32_t batch, int32_t c_total, int32_t groups,
-                   int64_t P, float eps, void* stream);
+                   int64_t P, float eps, float* ac, void* stream);
+                   /* ac (may be NULL): float [B][c_total][2] = (rstd*gamma, beta - mean*rstd*gamma), the affine
+                    * form consumed by md_gemm_conv's MD_B_F32B_GN operand mode */
 int md_gn_apply(const float* x, const float* params, void* out, void* out_raw, int32_t batch,
                 int32_t C, int64_t P, int32_t c_total, int32_t c_off, int32_t norm,
                 int32_t silu, float drop_p, uint64_t drop_seed, void* stream);

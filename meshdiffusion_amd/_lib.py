@@ -16,6 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libmeshdiffusion_hip.so")
 OUT_F32B, OUT_S16B, OUT_NCDHW = 0, 1, 2
 PREC_BF16X3, PREC_FP16X2 = 0, 1
 A_PACKED, A_S16B = 0, 1
+B_S16B, B_F32B_GN = 0, 1
 
 # (NT, KC) of each cfg -- must match csrc/gemm_conv.hip; checked against the library at load.
 CFG_NT_KC = {
@@ -35,11 +36,12 @@ class MdGemmConvArgs(C.Structure):
         ("H", C.c_int32), ("W", C.c_int32), ("ups", C.c_int32), ("a_src", C.c_int32),
         ("out_mode", C.c_int32), ("a_rows", C.c_int32), ("a_bstride", C.c_int64),
         ("bias_bstride", C.c_int64), ("res_bstride", C.c_int64), ("b_bstride", C.c_int64), ("partial", C.c_void_p), ("ksplit", C.c_int32), ("prec", C.c_int32),
-        ("stats", C.c_void_p), ("stagger", C.c_int32), ("reserved0", C.c_int32),
+        ("stats", C.c_void_p), ("stagger", C.c_int32), ("b_mode", C.c_int32), ("b2", C.c_void_p), ("b_ac", C.c_void_p),
+        ("b2_bstride", C.c_int64), ("b_split", C.c_int32), ("b_silu", C.c_int32),
     ]
 
 
-ABI_VERSION = 6      # MD_ABI_VERSION of include/meshdiffusion_hip.h this host code was written against
+ABI_VERSION = 7      # MD_ABI_VERSION of include/meshdiffusion_hip.h this host code was written against
 _P, _I32, _I64, _F, _U64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint64
 
 # name -> (restype, argtypes); exactly the entry points of include/meshdiffusion_hip.h
@@ -52,7 +54,7 @@ SIGNATURES = {
     "md_pack_weights": (C.c_int, [_P, _P, _I32, _I32, _I32, _I64, _I64, _I64, _I32, _I32, _I32, _P]),
     "md_packed_weight_bytes": (_I64, [_I32, _I32, _I32, _I32, _I32]),
     "md_gn_stats": (C.c_int, [_P, _P, _I32, _I32, _I64, _I32, _I32, _P]),
-    "md_gn_finalize": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _I64, _F, _P]),
+    "md_gn_finalize": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _I64, _F, _P, _P]),
     "md_gn_apply": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I64, _I32, _I32, _I32, _I32, _F, _U64, _P]),
     "md_dropout_scale": (C.c_int, [_P, _I32, _I32, _I64, _I32, _I32, _F, _U64, _P]),
     "md_zero": (C.c_int, [_P, _I64, _P]),

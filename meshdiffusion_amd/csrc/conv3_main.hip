@@ -49,11 +49,16 @@ __device__ __forceinline__ int slot_of(int hz, int hy, int hx) {
 // an HBM burst during which no matrix core works).
 // VAR (A/B switch, valid results): bit 1 = commit the next tap's weight tile to LDS at the TOP of the tap (behind it 12
 // MFMAs cover the ds_write latency) instead of right before the barrier.
-template <int ABL, int PREC, int VAR = 0>
+// BF = 1 (MD_B_F32B_GN): the B operand is read as fp32 (F32B, up to two channel-concatenated parts) and GroupNorm affine
+// + SiLU + the bf16 hi/lo split are applied while the halo tile is staged: one thread = one 8-channel group (kg = tid / 128,
+// wave-uniform) x 5 halo positions; the transform of item i runs at tap PF_TAP+1+i of the chunk before, between MFMAs.
+template <int ABL, int PREC, int VAR = 0, int BF = 0>
 __global__ __launch_bounds__(NTHREADS) void md_conv3_main_kernel(const MdGemmConvArgs A) {
   constexpr int PL = (PREC == MD_PREC_FP16X2) ? 1 : 2;        // activation planes staged in LDS
+  static_assert(BF == 0 || PL == 2, "the fused operand transform produces the bf16x3 format");
   constexpr int A_ITEMS_P = KG * PL * HPOS;
-  constexpr int A_PT = (A_ITEMS_P + NTHREADS - 1) / NTHREADS;  // halo items per thread (10 or 5)
+  constexpr int BF_IT = (HPOS + 127) / 128;                    // 5 (kg, position) items per thread in BF mode
+  constexpr int A_PT = BF ? 2 * BF_IT : (A_ITEMS_P + NTHREADS - 1) / NTHREADS;  // uint4 registers of the halo prefetch (10 / 5)
   __shared__ __attribute__((aligned(16))) uint4 smem[2 * W_ITEMS + KG * PL * HS];
   unsigned char* lds = (unsigned char*)smem;
 
@@ -95,18 +100,24 @@ __global__ __launch_bounds__(NTHREADS) void md_conv3_main_kernel(const MdGemmCon
   const int nsteps = ncc * TAPS;
 
   const uint4* bptr = (const uint4*)A.b + (int64_t)b * (A.b_bstride / 8) + (int64_t)cc_lo * (KG * 2) * Pin;
+  // BF: fp32 parts, 4 floats per uint4; channel group g8 (8 channels) of part p starts at p_base + g8 * Pin * 2 uint4
+  const int bf_kg = __builtin_amdgcn_readfirstlane(tid >> 7);
+  const uint4* bf_p1 = (const uint4*)A.b + (int64_t)b * (A.b_bstride / 4);
+  const uint4* bf_p2 = (const uint4*)A.b2 + (int64_t)b * (A.b2_bstride / 4);
+  const int bf_split8 = A.b_split >> 3;
   // tiles are contiguous in step order
   const uint4* wbase = (const uint4*)A.a + ((int64_t)rt * ncc_total + cc_lo) * TAPS * W_ITEMS;
 
   // ---- halo prefetch descriptors: computed ONCE (source offset in uint4 units relative to the chunk
   //      base, -1 = outside the grid => zero fill; LDS destination byte offset) ---------------------
-  int hsrc[A_PT], hdst[A_PT];
+  constexpr int N_DESC = BF ? BF_IT : A_PT;
+  int hsrc[N_DESC], hdst[N_DESC];
 #pragma unroll
-  for (int i = 0; i < A_PT; ++i) {
-    const int item = tid + i * NTHREADS;
+  for (int i = 0; i < N_DESC; ++i) {
+    const int item = BF ? (bf_kg * 2 * HPOS + (tid & 127) + i * 128) : (tid + i * NTHREADS);
     hsrc[i] = -1; hdst[i] = -1;
-    if (item < A_ITEMS_P) {
-      const int gl = item / HPOS, r = item % HPOS;      // LDS plane index: (g*PL + part)
+    if (BF ? ((tid & 127) + i * 128 < HPOS) : (item < A_ITEMS_P)) {
+      const int gl = item / HPOS, r = item % HPOS;      // LDS plane index: (g*PL + part); BF: the hi plane of group bf_kg
       const int gp = (PL == 2) ? gl : gl * 2;            // global plane index: (g*2 + part); fp16x2 reads hi only
       const int hx = r % XH, hy = (r / XH) % YH, hz = r / (XH * YH);
       int uz = z0 + hz - 1, uy = y0 + hy - 1, ux = x0 + hx - 1;
@@ -118,23 +129,76 @@ __global__ __launch_bounds__(NTHREADS) void md_conv3_main_kernel(const MdGemmCon
         inb = (uz >= 0) & (uz < Di) & (uy >= 0) & (uy < Hi) & (ux >= 0) & (ux < Wi);
       }
       hdst[i] = W_LDS_BYTES + (gl * HS + slot_of(hz, hy, hx)) * 16;
-      if (inb) hsrc[i] = (int)(gp * Pin + ((int64_t)uz * Hi + uy) * Wi + ux);
+      if (inb) hsrc[i] = BF ? (int)((((int64_t)uz * Hi + uy) * Wi + ux) * 2) : (int)(gp * Pin + ((int64_t)uz * Hi + uy) * Wi + ux);
     }
   }
   uint4 hreg[A_PT];
+  f32x4 bf_ac[BF ? 4 : 1];    // BF: (a, c) of this thread's 8 channels for the chunk being prefetched: a0 c0 a1 c1 | ...
   auto act_issue = [&](int cc) {
-    const uint4* cb = bptr + (int64_t)cc * (KG * 2) * Pin;  // scalar chunk base
+    if constexpr (BF) {
+      const int g8 = (cc_lo + cc) * KG + bf_kg;                       // 8-channel group in the concatenated input (scalar)
+      const uint4* cb = (g8 < bf_split8) ? bf_p1 + (int64_t)g8 * Pin * 2 : bf_p2 + (int64_t)(g8 - bf_split8) * Pin * 2;
 #pragma unroll
-    for (int i = 0; i < A_PT; ++i) {
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (hsrc[i] >= 0) v = cb[hsrc[i]];
-      hreg[i] = v;
+      for (int i = 0; i < BF_IT; ++i) {
+        uint4 v0 = make_uint4(0, 0, 0, 0), v1 = v0;
+        if (hsrc[i] >= 0) { v0 = cb[hsrc[i]]; v1 = cb[hsrc[i] + 1]; }
+        hreg[2 * i] = v0; hreg[2 * i + 1] = v1;
+      }
+      if (A.b_ac != nullptr) {
+        const f32x4* ap = (const f32x4*)(A.b_ac + ((int64_t)b * A.kdim + (int64_t)g8 * 8) * 2);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bf_ac[q] = ap[q];
+      }
+    } else {
+      const uint4* cb = bptr + (int64_t)cc * (KG * 2) * Pin;  // scalar chunk base
+#pragma unroll
+      for (int i = 0; i < A_PT; ++i) {
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (hsrc[i] >= 0) v = cb[hsrc[i]];
+        hreg[i] = v;
+      }
+    }
+  };
+  // BF: fp32 x 8 channels of item i -> (hi plane uint4, lo plane uint4) in place.  y = x*a + c, SiLU = y / (1 + 2^(-y log2 e))
+  // with the hardware exp2 / rcp (1 ulp each), hi = bf16(y) (v_cvt_pk_bf16_f32, RNE), lo = bf16(y - hi).
+  auto act_transform = [&](int i) {
+    if constexpr (BF) {
+      float v[8];
+      const uint4 r0 = hreg[2 * i], r1 = hreg[2 * i + 1];
+      v[0] = __uint_as_float(r0.x); v[1] = __uint_as_float(r0.y); v[2] = __uint_as_float(r0.z); v[3] = __uint_as_float(r0.w);
+      v[4] = __uint_as_float(r1.x); v[5] = __uint_as_float(r1.y); v[6] = __uint_as_float(r1.z); v[7] = __uint_as_float(r1.w);
+      uint32_t hi[8], lo[8];
+      const bool live = hsrc[i] >= 0;                     // outside the grid the ACTIVATED tensor is zero padded
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float y = v[e];
+        if (A.b_ac != nullptr) {
+          y = y * bf_ac[e >> 1][(e & 1) * 2] + bf_ac[e >> 1][(e & 1) * 2 + 1];
+          if (A.b_silu) y = y * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(y * -1.4426950408889634f));
+        }
+        if (!live) y = 0.f;
+        const __bf16 h = (__bf16)y;
+        const __bf16 l = (__bf16)(y - (float)h);
+        hi[e] = __builtin_bit_cast(unsigned short, h);
+        lo[e] = __builtin_bit_cast(unsigned short, l);
+      }
+      hreg[2 * i] = make_uint4(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16), hi[4] | (hi[5] << 16), hi[6] | (hi[7] << 16));
+      hreg[2 * i + 1] = make_uint4(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16), lo[4] | (lo[5] << 16), lo[6] | (lo[7] << 16));
     }
   };
   auto act_commit = [&]() {
+    if constexpr (BF) {
 #pragma unroll
-    for (int i = 0; i < A_PT; ++i)
-      if (hdst[i] >= 0) *(uint4*)(lds + hdst[i]) = hreg[i];
+      for (int i = 0; i < BF_IT; ++i)
+        if (hdst[i] >= 0) {
+          *(uint4*)(lds + hdst[i]) = hreg[2 * i];
+          *(uint4*)(lds + hdst[i] + HS * 16) = hreg[2 * i + 1];
+        }
+    } else {
+#pragma unroll
+      for (int i = 0; i < A_PT; ++i)
+        if (hdst[i] >= 0) *(uint4*)(lds + hdst[i]) = hreg[i];
+    }
   };
 
   // ---- fragment addresses: one VGPR each, everything else is an immediate ------------------------
@@ -171,6 +235,10 @@ __global__ __launch_bounds__(NTHREADS) void md_conv3_main_kernel(const MdGemmCon
   {
     wreg0 = wbase[tid]; wreg1 = wbase[tid + NTHREADS];
     act_issue(0);
+    if constexpr (BF) {
+#pragma unroll
+      for (int i = 0; i < BF_IT; ++i) act_transform(i);
+    }
     act_commit();
     *(uint4*)(lds + tid * 16) = wreg0;
     *(uint4*)(lds + (tid + NTHREADS) * 16) = wreg1;
@@ -287,6 +355,9 @@ __global__ __launch_bounds__(NTHREADS) void md_conv3_main_kernel(const MdGemmCon
         wreg0 = wt[tid]; wreg1 = wt[tid + NTHREADS];
       }
       if (tap == PF_TAP) act_issue(cpre);
+      if constexpr (BF) {
+        if (tap > PF_TAP && tap <= PF_TAP + BF_IT) act_transform(tap - PF_TAP - 1);   // one item per tap, beside the MFMAs
+      }
       if (tap == TAPS - 1) {
         __syncthreads();  // every wave has issued and completed its reads of this chunk's halo tile
         act_commit();
@@ -433,6 +504,10 @@ int md_launch_conv3_main(const MdGemmConvArgs& a, hipStream_t stream) {
   if (a.D % TZ || a.H % TY || a.W % TX) return MD_ERR_BAD_ARG;
   if (a.ups && ((a.D | a.H | a.W) & 1)) return MD_ERR_BAD_ARG;
   if (a.a_src != MD_A_PACKED || a.out_mode != MD_OUT_F32B) return MD_ERR_UNSUPPORTED;
+  if (a.b_mode != MD_B_S16B && a.b_mode != MD_B_F32B_GN) return MD_ERR_BAD_ARG;
+  if (a.b_mode == MD_B_F32B_GN) {
+    if (a.prec != MD_PREC_BF16X3 || (a.b_split & 7) || a.b_split <= 0 || (a.b_split < a.kdim && a.b2 == nullptr)) return MD_ERR_BAD_ARG;
+  }
   if (a.stats != nullptr && a.ksplit > 1) return MD_ERR_UNSUPPORTED;
   const int tiles = (a.D / TZ) * (a.H / TY) * (a.W / TX);
   const int ks = a.ksplit > 1 ? a.ksplit : 1;
@@ -446,7 +521,8 @@ int md_launch_conv3_main(const MdGemmConvArgs& a, hipStream_t stream) {
   } else {
     switch (a.cfg) {
 #ifdef MD_BUILD_ABLATIONS   // timing-only variants for tools/bench_conv.py: each costs ~35 s of compile time
-      case 111: hipLaunchKernelGGL((md_conv3_main_kernel<1, 0>), grid, dim3(NTHREADS), 0, stream, a); break;
+      case 111: if (a.b_mode != MD_B_S16B) return MD_ERR_UNSUPPORTED;
+                hipLaunchKernelGGL((md_conv3_main_kernel<1, 0>), grid, dim3(NTHREADS), 0, stream, a); break;
       case 113: hipLaunchKernelGGL((md_conv3_main_kernel<3, 0>), grid, dim3(NTHREADS), 0, stream, a); break;
       case 114: hipLaunchKernelGGL((md_conv3_main_kernel<4, 0>), grid, dim3(NTHREADS), 0, stream, a); break;
       case 116: hipLaunchKernelGGL((md_conv3_main_kernel<6, 0>), grid, dim3(NTHREADS), 0, stream, a); break;
@@ -455,8 +531,12 @@ int md_launch_conv3_main(const MdGemmConvArgs& a, hipStream_t stream) {
 #else
       case 111: case 113: case 114: case 116: case 117: case 118: return MD_ERR_UNSUPPORTED;   // MD_BUILD_ABLATIONS=1 python -m meshdiffusion_amd.build --force
 #endif
-      case 122: hipLaunchKernelGGL((md_conv3_main_kernel<0, 0, 2>), grid, dim3(NTHREADS), 0, stream, a); break;
-      default: hipLaunchKernelGGL((md_conv3_main_kernel<0, 0>), grid, dim3(NTHREADS), 0, stream, a); break;
+      case 122: if (a.b_mode != MD_B_S16B) return MD_ERR_UNSUPPORTED;
+                hipLaunchKernelGGL((md_conv3_main_kernel<0, 0, 2>), grid, dim3(NTHREADS), 0, stream, a); break;
+      default:
+        if (a.b_mode == MD_B_F32B_GN) hipLaunchKernelGGL((md_conv3_main_kernel<0, 0, 0, 1>), grid, dim3(NTHREADS), 0, stream, a);
+        else hipLaunchKernelGGL((md_conv3_main_kernel<0, 0>), grid, dim3(NTHREADS), 0, stream, a);
+        break;
     }
   }
   MD_HIP_CHECK_LAUNCH();

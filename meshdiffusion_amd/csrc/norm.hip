@@ -52,7 +52,7 @@ __global__ __launch_bounds__(GN_BLOCK) void md_gn_stats_kernel(const float* __re
 // params: float4 [B][c_total] = (mean, rstd*gamma, beta, rstd)
 __global__ void md_gn_finalize_kernel(const double* __restrict__ sums, const float* __restrict__ gamma,
                                       const float* __restrict__ beta, float* __restrict__ params,
-                                      int c_total, int groups, int64_t P, float eps) {
+                                      int c_total, int groups, int64_t P, float eps, float* __restrict__ ac) {
   const int b = blockIdx.x / groups, g = blockIdx.x % groups;
   const int cpg = c_total / groups;
   const int lane = threadIdx.x;
@@ -73,6 +73,11 @@ __global__ void md_gn_finalize_kernel(const double* __restrict__ sums, const flo
     const int ch = g * cpg + c;
     f32x4 o4 = {(float)mean, rstd * gamma[ch], beta[ch], rstd};  // [3] = rstd: used by the backward pass
     *(f32x4*)(params + ((int64_t)b * c_total + ch) * 4) = o4;
+    if (ac != nullptr) {   // y = x*a + c, the form the conv's fused halo loader applies
+      const float a_ = rstd * gamma[ch];
+      ac[((int64_t)b * c_total + ch) * 2] = a_;
+      ac[((int64_t)b * c_total + ch) * 2 + 1] = (float)((double)beta[ch] - mean * (double)a_);
+    }
   }
 }
 
@@ -153,12 +158,12 @@ extern "C" int md_gn_stats(const float* x, double* sums, int32_t batch, int32_t 
 
 extern "C" int md_gn_finalize(const double* sums, const float* gamma, const float* beta,
                               float* params, int32_t batch, int32_t c_total, int32_t groups,
-                              int64_t P, float eps, void* stream) {
+                              int64_t P, float eps, float* ac, void* stream) {
   if (!sums || !gamma || !beta || !params || batch <= 0 || groups <= 0 || (c_total % groups))
     return MD_ERR_BAD_ARG;
   MD_HIP_CLEAR_ERROR();
   hipLaunchKernelGGL(md_gn_finalize_kernel, dim3((unsigned)(batch * groups)), dim3(64), 0,
-                     (hipStream_t)stream, sums, gamma, beta, params, c_total, groups, P, eps);
+                     (hipStream_t)stream, sums, gamma, beta, params, c_total, groups, P, eps, ac);
   MD_HIP_CHECK_LAUNCH();
   return MD_OK;
 }

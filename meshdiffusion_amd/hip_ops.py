@@ -140,13 +140,30 @@ def pack_s16b_from_matrix(w_kp, device):
 # ---------------------------------------------------------------------------------------------
 def gemm_conv(*, cfg, a, b, out, batch, rows, rows_alloc, kdim, dims, bias=None, bias_bstride=0,
               residual=None, res_bstride=0, alpha=1.0, ups=0, a_src=A_PACKED, a_rows=0, a_bstride=0,
-              b_bstride=None, out_mode=OUT_F32B, ksplit=1, prec=PREC_BF16X3, stats=None, stagger=None):
+              b_bstride=None, out_mode=OUT_F32B, ksplit=1, prec=PREC_BF16X3, stats=None, stagger=None,
+              b_f32=None):
     """stats: optional zeroed float64 [batch][rows_alloc][2] receiving per-(sample, channel) sum / sum of squares of
-    the output (CFG_C3_128_FAST without split-K only)."""
+    the output (CFG_C3_128_FAST without split-K only).
+    b_f32: dict(parts=[(F32B tensor, C), ...] (1 or 2), ac=[B][K][2] or None, silu=bool): the B operand is read as fp32
+    and GroupNorm affine + SiLU + the bf16 split happen in the kernel's halo loader (MD_B_F32B_GN; `b` is ignored)."""
     lib = _lib.load()
     D, H, W = dims
     args = MdGemmConvArgs()
-    args.a, args.b, args.out = a.data_ptr(), b.data_ptr(), out.data_ptr()
+    args.a, args.out = a.data_ptr(), out.data_ptr()
+    if b_f32 is not None:
+        parts = b_f32["parts"]
+        assert 1 <= len(parts) <= 2 and sum(c for _, c in parts) == kdim and all(c % 8 == 0 for _, c in parts)
+        pin = D * H * W // (8 if ups else 1)
+        args.b, args.b_split = parts[0][0].data_ptr(), parts[0][1]
+        b_bstride = parts[0][1] * pin                       # floats between batches of part 1
+        if len(parts) == 2:
+            args.b2, args.b2_bstride = parts[1][0].data_ptr(), parts[1][1] * pin
+        ac = b_f32.get("ac")
+        args.b_ac = ac.data_ptr() if ac is not None else None
+        args.b_silu = 1 if b_f32.get("silu") else 0
+        args.b_mode = _lib.B_F32B_GN
+    else:
+        args.b = b.data_ptr()
     args.bias = bias.data_ptr() if bias is not None else None
     args.residual = residual.data_ptr() if residual is not None else None
     args.alpha = alpha
@@ -184,18 +201,22 @@ def gemm_conv(*, cfg, a, b, out, batch, rows, rows_alloc, kdim, dims, bias=None,
         e0.record()
         check(lib.md_gemm_conv(C.byref(args), _stream()), f"md_gemm_conv(cfg={cfg})")
         e1.record()
-        PROFILE.append((cfg, flops, e0, e1, abytes))
+        PROFILE.append((cfg, flops, e0, e1, abytes,
+                        f"{kdim}->{rows}@{D}x{H}x{W}" + ("/ups" if ups else "") + (f"/ks{ksplit}" if ksplit > 1 else "") +
+                        ("/res" if residual is not None else "") + ("/stats" if stats is not None else "")))
     return out
 
 
 # ---------------------------------------------------------------------------------------------
 # GroupNorm (+SiLU) + split, with concatenated sources
 # ---------------------------------------------------------------------------------------------
+FUSE_GN_APPLY = os.environ.get("MD_FUSE_GN_APPLY", "1") == "1"   # GroupNorm affine + SiLU + split inside the conv's halo loader (inference)
 FUSE_GN_STATS = True     # take GroupNorm sums from the producing conv's epilogue when it recorded them (A/B switch)
 
 
-def gn_params(parts, gamma, beta, B, P, eps=1e-6, groups=32):
-    """parts: list of (F32B tensor, C).  Returns the float4 params tensor [B][Ctot][4].
+def gn_params(parts, gamma, beta, B, P, eps=1e-6, groups=32, want_ac=False):
+    """parts: list of (F32B tensor, C).  Returns the float4 params tensor [B][Ctot][4] (want_ac: and the folded affine
+    [B][Ctot][2] = (rstd*gamma, beta - mean*rstd*gamma) that md_gemm_conv's fused operand loader applies).
     A part whose producer attached `_md_sums` (layers.run_conv3(want_stats=True)) is not read again."""
     lib = _lib.load()
     dev = parts[0][0].device
@@ -215,9 +236,10 @@ def gn_params(parts, gamma, beta, B, P, eps=1e-6, groups=32):
                 check(lib.md_gn_stats(_ptr(t), _ptr(sums), B, c, P, ctot, off, _stream()), "md_gn_stats")
             off += c
     params = torch.empty((B, ctot, 4), dtype=torch.float32, device=dev)
+    ac = torch.empty((B, ctot, 2), dtype=torch.float32, device=dev) if want_ac else None
     check(lib.md_gn_finalize(_ptr(sums), _ptr(gamma), _ptr(beta), _ptr(params), B, ctot, groups, P,
-                             eps, _stream()), "md_gn_finalize")
-    return params
+                             eps, _ptr(ac), _stream()), "md_gn_finalize")
+    return (params, ac) if want_ac else params
 
 
 def next_dropout_seed():

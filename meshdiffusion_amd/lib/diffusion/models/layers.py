@@ -110,26 +110,34 @@ def conv3_packed(layer, name, conv, cfg):
                          lambda: ops.PackedWeight(conv.weight, "conv", cfg, conv.weight.device, prec))
 
 
+def fused_operand_ok(pw):
+    """True when a conv on packed weights `pw` can take its input as fp32 F32B parts and apply GroupNorm + SiLU + the
+    bf16 split itself (MD_B_F32B_GN: dedicated kernel, bf16x3 arithmetic)."""
+    return ops.FUSE_GN_APPLY and pw.cfg == ops.CFG_C3_128_FAST and pw.prec == ops.PREC_BF16X3
+
+
 def run_conv3(pw, act_s16, B, S_out, *, bias=None, bias_bstride=0, residual=None, res_bstride=None, ups=0,
-              out=None, out_mode=ops.OUT_F32B, rows_alloc=None, want_stats=False):
+              out=None, out_mode=ops.OUT_F32B, rows_alloc=None, want_stats=False, b_f32=None):
     """3x3x3 conv of an S16B activation tensor with packed weights `pw` on an S_out^3 output grid.
     want_stats: the output feeds a GroupNorm -- when the launch allows it (dedicated kernel, no split-K) its
-    epilogue also accumulates the per-(sample, channel) sums, attached to the result as `_md_sums`."""
+    epilogue also accumulates the per-(sample, channel) sums, attached to the result as `_md_sums`.
+    b_f32 (see hip_ops.gemm_conv): fp32 parts + folded GroupNorm affine instead of `act_s16` (fused_operand_ok)."""
     P = S_out ** 3
+    dev = act_s16.device if act_s16 is not None else b_f32["parts"][0][0].device
     rows_alloc = rows_alloc if rows_alloc is not None else ((pw.rows + 7) // 8) * 8
     if out is None:
-        out = ops.f32b_empty(B, rows_alloc, P, act_s16.device)
+        out = ops.f32b_empty(B, rows_alloc, P, dev)
     if residual is not None and res_bstride is None:
         res_bstride = rows_alloc * P
     ksplit = ops.ksplit_for(pw.cfg, B, pw.rows, pw.kdim, S_out) if out_mode == ops.OUT_F32B else 1
     stats = None
     if (want_stats and ops.FUSE_GN_STATS and pw.cfg == ops.CFG_C3_128_FAST and ksplit == 1
             and out_mode == ops.OUT_F32B and rows_alloc == pw.rows):
-        stats = torch.zeros((B, rows_alloc, 2), dtype=torch.float64, device=act_s16.device)
+        stats = torch.zeros((B, rows_alloc, 2), dtype=torch.float64, device=dev)
     ops.gemm_conv(cfg=pw.cfg, a=pw.data, b=act_s16, out=out, batch=B, rows=pw.rows,
                   rows_alloc=rows_alloc, kdim=pw.kdim, dims=(S_out, S_out, S_out), bias=bias,
                   bias_bstride=bias_bstride, residual=residual, res_bstride=res_bstride or 0, ups=ups,
-                  out_mode=out_mode, ksplit=ksplit, prec=pw.prec, stats=stats)
+                  out_mode=out_mode, ksplit=ksplit, prec=pw.prec, stats=stats, b_f32=b_f32)
     if stats is not None:
         out._md_sums = stats
     elif hasattr(out, "_md_sums"):
@@ -256,6 +264,9 @@ class Upsample(HipLayer):
     def forward_blocked(self, x, Cc, B, P, tape=None):
         s_out = 2 * _spatial_edge(P)
         pw = conv3_packed(self, "w", self.Conv_0, ops.conv_cfg_for(s_out))
+        if tape is None and fused_operand_ok(pw) and pw.kdim == Cc:   # the conv splits the raw fp32 input while loading it
+            return run_conv3(pw, None, B, s_out, bias=self.Conv_0.bias, ups=1, want_stats=True,
+                             b_f32=dict(parts=[(x, Cc)], ac=None, silu=False))
         act = ops.gn_apply([(x, Cc)], None, B, P, norm=False, silu=False, fp16=pw.prec == ops.PREC_FP16X2)
         if tape is not None:
             assert pw.prec == ops.PREC_BF16X3
@@ -337,8 +348,28 @@ class ResnetBlockDDPM(HipLayer):
         g0, g1 = self.GroupNorm_0, self.GroupNorm_1
         pw0, pw1 = conv3_packed(self, "w0", self.Conv_0, cfg), conv3_packed(self, "w1", self.Conv_1, cfg)
         f16 = pw0.prec == ops.PREC_FP16X2   # operand format follows the kernel that consumes the tensor
-        prm = ops.gn_params(parts, g0.weight, g0.bias, B, P, eps=g0.eps, groups=g0.num_groups)
         need_nin = self.in_ch != self.out_ch
+        if (tape is None and drop is None and fused_operand_ok(pw0) and fused_operand_ok(pw1) and pw0.kdim == cin
+                and pw1.kdim == self.out_ch and not ops.NIN_SIDE_STREAM):
+            # inference: no GroupNorm-apply pass at all -- both convs read the fp32 tensors and normalise / activate /
+            # split them in their halo loaders; the statistics come from the producing convs' epilogues
+            _, ac0 = ops.gn_params(parts, g0.weight, g0.bias, B, P, eps=g0.eps, groups=g0.num_groups, want_ac=True)
+            if bias0 is None:
+                if temb is not None:
+                    bias0, bias0_stride = ops.linear(temb, self.Dense_0.weight, self._bias0(), silu_in=True), self.out_ch
+                else:
+                    bias0, bias0_stride = self.Conv_0.bias, 0
+            h = run_conv3(pw0, None, B, S, bias=bias0, bias_bstride=bias0_stride, want_stats=True,
+                          b_f32=dict(parts=parts, ac=ac0, silu=True))
+            if need_nin:   # the shortcut GEMM still takes a split-bf16 operand: one raw split pass of the block input
+                xs = ops.gn_apply(parts, None, B, P, norm=False, silu=False)
+                res = self.NIN_0.forward_s16(xs, B, P)
+            else:
+                res = parts[0][0]
+            _, ac1 = ops.gn_params([(h, self.out_ch)], g1.weight, g1.bias, B, P, eps=g1.eps, groups=g1.num_groups, want_ac=True)
+            return run_conv3(pw1, None, B, S, bias=self.Conv_1.bias, residual=res, want_stats=True,
+                             b_f32=dict(parts=[(h, self.out_ch)], ac=ac1, silu=True))
+        prm = ops.gn_params(parts, g0.weight, g0.bias, B, P, eps=g0.eps, groups=g0.num_groups)
         a0 = ops.gn_apply(parts, prm, B, P, norm=True, silu=True, fp16=f16, want_raw=need_nin)
         xs = None
         res = None

@@ -116,10 +116,12 @@ def test_c_abi_exports_every_declared_symbol(hip_lib):
 
 def test_struct_layout_matches_header():
     from meshdiffusion_amd._lib import MdGemmConvArgs
-    # 5 pointers, 1 float + 12 int32 (+pad), 4 int64, 1 pointer, 2 int32, 1 pointer, 2 int32 -> natural alignment, no surprises
-    assert ctypes.sizeof(MdGemmConvArgs) == 5 * 8 + 13 * 4 + 4 + 4 * 8 + 8 + 2 * 4 + 8 + 2 * 4
-    assert MdGemmConvArgs.stats.offset == ctypes.sizeof(MdGemmConvArgs) - 16
-    assert MdGemmConvArgs.stagger.offset == ctypes.sizeof(MdGemmConvArgs) - 8
+    # 5 pointers, 1 float + 12 int32 (+pad), 4 int64, 1 pointer, 2 int32, 1 pointer, 2 int32, 2 pointers, 1 int64, 2 int32
+    # -> natural alignment, no surprises
+    size = 5 * 8 + 13 * 4 + 4 + 4 * 8 + 8 + 2 * 4 + 8 + 2 * 4 + 2 * 8 + 8 + 2 * 4
+    assert ctypes.sizeof(MdGemmConvArgs) == size
+    assert MdGemmConvArgs.stats.offset == size - 48 and MdGemmConvArgs.stagger.offset == size - 40
+    assert MdGemmConvArgs.b2.offset == size - 32 and MdGemmConvArgs.b_silu.offset == size - 4
     assert MdGemmConvArgs.a_bstride.offset % 8 == 0
 
 

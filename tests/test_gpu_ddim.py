@@ -1,5 +1,5 @@
 """DDIM sampler (reference sde_lib.py:113-140 `discretize_ddim`, sampling.py:500-570) on the HIP path:
-md_ddim_step against the unmodified reference's update (bit-exact, float64), the whole 99-evaluation sampler against the
+md_ddim_step against the unmodified reference's update (float64; bit-exact against the same op chain on the same host), the whole 99-evaluation sampler against the
 unmodified reference run (noise_removal=False: the only setting upstream can execute) and against the oracle for the
 repaired noise_removal=True path, and `--config.sampling.method=ddim` from the CLI."""
 import os
@@ -21,7 +21,7 @@ def _step_inputs(seed):
     return x, eps
 
 
-def test_ddim_step_bit_exact_vs_reference_golden(hip_lib):
+def test_ddim_step_vs_reference_golden(hip_lib):
     from meshdiffusion_amd import hip_ops as ops
     from meshdiffusion_amd.lib.diffusion import sampling, sde_lib
     gold = np.load(os.path.join(GOLD, "ddim.npz"))
@@ -34,10 +34,19 @@ def test_ddim_step_bit_exact_vs_reference_golden(hip_lib):
         i = int(gold[f"step{n}_i"])
         vt, vp = (torch.ones(2) * ts[i]).cuda(), (torch.ones(2) * ts[i - 1]).cuda()
         xin = x.double() if n == 0 else x.double() * 0.7
-        xn, x0p, x32 = ops.ddim_step(xin.cuda(), eps.cuda(), None, pred.coefficients(vt, vp))
-        assert np.array_equal(xn.cpu().numpy(), gold[f"step{n}_x_new"]), n          # float64, bit for bit
-        assert np.array_equal(x0p.cpu().numpy(), gold[f"step{n}_x0_pred"]), n
+        coef = pred.coefficients(vt, vp)
+        xn, x0p, x32 = ops.ddim_step(xin.cuda(), eps.cuda(), None, coef)
+        # (a) bit for bit (float64) against the reference's op chain evaluated with torch on this host from the same
+        #     table entries (sde_lib.py:129-139)
+        a1, a2, r1, r2 = [coef.cpu()[:, j][:, None, None, None, None] for j in range(4)]
+        x0s = xin - a2 * eps.double()
+        sst = xin - x0s
+        assert torch.equal(xn.cpu(), r1 * xin + ((-r1) + r2) * sst), n
+        assert torch.equal(x0p.cpu(), x0s / a1), n
         assert torch.equal(x32.cpu(), xn.cpu().float())
+        # (b) against the unmodified reference's recorded output.  Not bitwise: the float32 VP tables come from
+        #     torch.linspace, whose vectorised CPU kernel rounds a few entries differently from host to host (1e-7)
+        assert rel_l2(xn.cpu(), gold[f"step{n}_x_new"]) < 2e-6 and rel_l2(x0p.cpu(), gold[f"step{n}_x0_pred"]) < 2e-6, n
     # mask and inpainting blend (sampling.py:560-564) against the same ops in torch
     P = 64
     mask = (torch.rand(P, generator=torch.Generator().manual_seed(1)) < 0.5).float()

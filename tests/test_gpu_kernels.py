@@ -64,7 +64,7 @@ def test_gemm_asymmetric_identity(ops):
     assert rel_l2(y, ref) < TOL_MFMA
 
 
-@pytest.mark.parametrize("cfg_name", ["CFG_C3_128", "CFG_C3_128_FAST", "CFG_C3_128_V2"])
+@pytest.mark.parametrize("cfg_name", ["CFG_C3_128", "CFG_C3_128_FAST", "CFG_FAST_EC"])
 @pytest.mark.parametrize("cin,cout,S,B", [(32, 128, 8, 2), (64, 256, 16, 1), (160, 128, 8, 1)])
 def test_conv3_main(ops, cin, cout, S, B, cfg_name):
     cfg = getattr(ops, cfg_name)
@@ -324,3 +324,61 @@ def test_conv_epilogue_groupnorm_statistics(hip_lib):
     finally:
         ops.FUSE_GN_STATS = True
     assert rel_l2(p_cat.cpu(), p_cat_plain.cpu()) < 1e-6
+
+
+@pytest.mark.parametrize("case", ["one_part_gn_silu", "two_parts_gn_silu", "ups_split_only", "gn_no_silu"])
+def test_conv3_fused_groupnorm_silu_operand(ops, case):
+    """MD_B_F32B_GN: the dedicated conv reads fp32 F32B parts (one tensor or a channel concat of two) and applies the
+    GroupNorm affine + SiLU + bf16 split in its halo loader -- against F.conv3d(F.silu(F.group_norm(cat(parts)))) in
+    fp32 on the CPU, incl. zero padding of the ACTIVATED tensor at the grid boundary (beta != 0 makes silu(gn(0)) != 0)
+    and against the two-pass path (md_gn_apply + conv on the S16B tensor)."""
+    B, S, cout = 2, 8, 128
+    ups = case == "ups_split_only"
+    cs = {"one_part_gn_silu": [64], "two_parts_gn_silu": [96, 32], "ups_split_only": [32], "gn_no_silu": [64]}[case]
+    cin = sum(cs)
+    Sin = S // 2 if ups else S
+    Pin = Sin ** 3
+    xs = [_rand((B, c, Sin, Sin, Sin), 10 + i) * (1.0 + i) + 0.3 * i for i, c in enumerate(cs)]
+    x = torch.cat(xs, 1)
+    gamma, beta = 1.0 + 0.2 * _rand((cin,), 20), 0.5 * _rand((cin,), 21)
+    w = _rand((cout, cin, 3, 3, 3), 22, 0.05)
+    bias = _rand((B, cout), 23)
+    parts = [(ops.ncdhw_to_f32b(t.cuda()), c) for t, c in zip(xs, cs)]
+    pw = ops.PackedWeight(w.cuda(), "conv", ops.CFG_C3_128_FAST, "cuda")
+    silu = case != "gn_no_silu"
+    ac = None
+    if not ups:
+        prm, ac = ops.gn_params(parts, gamma.cuda(), beta.cuda(), B, Pin, want_ac=True)
+        ref_in = F.group_norm(x, 32, gamma, beta, eps=1e-6)
+        ref_in = F.silu(ref_in) if silu else ref_in
+    else:
+        ref_in = F.interpolate(x, scale_factor=2, mode="nearest")
+    out = ops.f32b_empty(B, cout, S ** 3, "cuda")
+    ops.gemm_conv(cfg=ops.CFG_C3_128_FAST, a=pw.data, b=None, out=out, batch=B, rows=cout, rows_alloc=cout, kdim=cin,
+                  dims=(S, S, S), bias=bias.cuda(), bias_bstride=cout, ups=1 if ups else 0,
+                  b_f32=dict(parts=parts, ac=ac, silu=silu))
+    y = ops.f32b_to_ncdhw(out, (S, S, S)).cpu()
+    ref = F.conv3d(ref_in, w, padding=1) + bias[:, :, None, None, None]
+    e = rel_l2(y, ref)
+    # two-pass path on the same inputs
+    a16 = ops.gn_apply(parts, prm if not ups else None, B, Pin, norm=not ups, silu=silu and not ups)
+    out2 = ops.f32b_empty(B, cout, S ** 3, "cuda")
+    ops.gemm_conv(cfg=ops.CFG_C3_128_FAST, a=pw.data, b=a16, out=out2, batch=B, rows=cout, rows_alloc=cout, kdim=cin,
+                  dims=(S, S, S), bias=bias.cuda(), bias_bstride=cout, ups=1 if ups else 0)
+    e2 = rel_l2(y, ops.f32b_to_ncdhw(out2, (S, S, S)).cpu())
+    print(f"fused operand ({case}): vs torch fp32 {e:.2e}, vs two-pass HIP path {e2:.2e}")
+    assert e < TOL_MFMA and e2 < TOL_MFMA
+    if ups:
+        assert e2 == 0.0          # no transcendental involved: the in-loader split is the same arithmetic
+
+
+def test_gn_finalize_folded_affine(ops):
+    B, Cc, S = 2, 64, 4
+    x = _rand((B, Cc, S, S, S), 30) * 2.0 + 1.5
+    gamma, beta = 1.0 + 0.2 * _rand((Cc,), 31), 0.5 * _rand((Cc,), 32)
+    prm, ac = ops.gn_params([(ops.ncdhw_to_f32b(x.cuda()), Cc)], gamma.cuda(), beta.cuda(), B, S ** 3, want_ac=True)
+    prm, ac = prm.cpu(), ac.cpu()
+    assert rel_l2(ac[..., 0], prm[..., 1]) == 0.0
+    assert rel_l2(ac[..., 1], prm[..., 2] - prm[..., 0] * prm[..., 1]) < 1e-6
+    y = x * ac[..., 0][:, :, None, None, None] + ac[..., 1][:, :, None, None, None]
+    assert rel_l2(y, F.group_norm(x, 32, gamma, beta, eps=1e-6)) < 2e-6

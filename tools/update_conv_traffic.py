@@ -1,0 +1,54 @@
+"""Record the PMC-measured HBM traffic of the dominant kernel for bench.py's `roofline.traffic`.
+
+    python tools/update_conv_traffic.py profiles/rNN_pmc_fetch.summary.txt profiles/rNN_pmc_write.summary.txt [--batch 8]
+
+Reads the per-launch means of FETCH_SIZE / WRITE_SIZE (KiB; tools/prof_summary.py output of two separate rocprofv3 --pmc
+passes of `python bench.py ...`) for md_conv3_main_kernel<0, 0>, applies the gfx950 correction of MI355X_MICROARCH.md
+(FETCH_SIZE reports half of a wide streaming read: doubled), and stores bytes per launch in profiles/conv_traffic.json
+under the sha of the kernel's source files -- bench.py only reports the figure while that sha still matches.
+"""
+import argparse
+import json
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+KERNEL = "md_conv3_main_kernel<0, 0"
+
+
+def counter(path, name):
+    for ln in open(path):
+        if KERNEL in ln and f"{name}=" in ln:
+            return float(re.search(name + r"=([0-9.e+]+)", ln).group(1))
+    raise SystemExit(f"{name} of {KERNEL} not found in {path}")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("fetch")
+    ap.add_argument("write")
+    ap.add_argument("--batch", type=int, default=8)
+    a = ap.parse_args()
+    fetch_kib, write_kib = counter(a.fetch, "FETCH_SIZE"), counter(a.write, "WRITE_SIZE")
+    nbytes = (2.0 * fetch_kib + write_kib) * 1024.0
+    try:
+        with open(bench.TRAFFIC_FILE) as fh:
+            tr = json.load(fh)
+    except OSError:
+        tr = {}
+    key = bench.conv_source_key()
+    tr[key] = {"kernel": "md_conv3_main_kernel<0,0>", "hbm_bytes_per_launch": round(nbytes), "batch": a.batch,
+               "fetch_size_kib": fetch_kib, "write_size_kib": write_kib,
+               "formula": "(2*FETCH_SIZE + WRITE_SIZE) KiB, mean over the launches of `python bench.py`",
+               "source": f"{os.path.relpath(a.fetch, ROOT)} + {os.path.relpath(a.write, ROOT)}"}
+    with open(bench.TRAFFIC_FILE, "w") as fh:
+        json.dump(tr, fh, indent=1, sort_keys=True)
+    print(f"{key}: {nbytes / 1e9:.3f} GB per launch")
+
+
+if __name__ == "__main__":
+    main()
