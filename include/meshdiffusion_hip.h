@@ -238,6 +238,19 @@ int md_softmax_keys(const float* s, void* p, int32_t batch, int32_t n_keys, int3
                     void* stream);
 
 /*
+ * md_attn_fwd: fused single-head self-attention (AttnBlock.forward, layers.py:595-608: the two einsums :602,:606 and the
+ * softmax :604) -- QK^T, online softmax over the keys and PV in one kernel, bf16x3 MFMA for both contractions; the
+ * [B][N][N] score matrix is never materialised.
+ *   qk  : S16B [B][2C/8][2][N][8]  q = channels 0..C-1, k = channels C..2C-1 (NIN_0 | NIN_1 outputs, one GEMM)
+ *   vT  : S16B over tokens [B][N/8][2][C][8]  (NIN_2 output WITHOUT its bias, token-major)
+ *   out : S16B [B][C/8][2][N][8]   o[c][q] = sum_key v[c][key] softmax_key(scale * k[:,key].q[:,q]) + bias_v[c]
+ * Supported: C == 256, N % 128 == 0 (the 16^3 attention levels of ddpm_res64); other shapes return MD_ERR_UNSUPPORTED
+ * and take the GEMM + md_softmax_keys path.
+ */
+int md_attn_fwd(const void* qk, const void* vT, void* out, const float* bias_v, int32_t batch, int32_t C,
+                int32_t N, float scale, void* stream);
+
+/*
  * One DDPM ancestral-sampling update (models/utils.py:191-198 score scaling,
  * sampling.py:222-230 predictor, sampling.py:476-478 mask), all NCDHW fp32:
  *   x_mean = (x - beta/sigma * eps) / sqrt(1-beta);  x = x_mean + sqrt(beta)*z

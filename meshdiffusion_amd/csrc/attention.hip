@@ -1,0 +1,209 @@
+// md_attn_fwd: fused single-head self-attention over the D*H*W tokens of a 16^3 level (N = 4096, head dim C = 256):
+//   o[c][q] = sum_key v[c][key] * softmax_key( C^-1/2 * sum_c' k[c'][key] q[c'][q] ) + b_v[c]
+// QK^T, the softmax and PV run in one kernel with an ONLINE softmax, so the [B][N][N] score matrix (67 MB fp32 per
+// sample plus its split-bf16 copy) never exists.  Both contractions use the bf16x3 operand split (hi*hi + hi*lo + lo*hi,
+// fp32 accumulate) like every other contraction of the path.
+//
+// Reference: AttnBlock.forward, lib/diffusion/models/layers.py:595-608 (the two einsums :602,:606 and F.softmax :604).
+//
+// Mapping (MFMA D[i][j] = sum_k A[i][k] B[k][j], lane (j = lane & 31, h = lane >> 5) holds rows 8r + 4h + {0..3}):
+//   S^T[key][query]: A = K (rows = keys, k = channels), B = Q (cols = queries)  -> a lane owns ONE query column and 16
+//                    keys of a 32-key tile: the softmax statistics of a query live in one lane pair (j, j + 32).
+//   O[c][query]    : A = V (rows = channels, k = keys),  B = P (cols = queries) -> P comes straight from the S^T
+//                    accumulator registers: MFMA k-slot (h, i) of key step ks is key 16 ks + 8 (i / 4) + 4 h + i % 4, and
+//                    the V fragment is read from LDS in that same key order (two 8-byte pieces), so no cross-lane traffic.
+// One workgroup = 128 queries (4 waves x 32), one wave per SIMD (512 registers: 128 O accumulators in AGPRs + the wave's
+// whole Q operand, 128 VGPRs, stay resident); K and V stream through LDS in 32-key tiles (32 KB each, double buffered,
+// next tile prefetched into registers behind the 96 MFMAs of the current one, one barrier per tile).
+#include "md_common.h"
+
+namespace {
+constexpr int AT_C = 256;            // head dim = channels
+constexpr int AT_CG = AT_C / 8;      // 32 channel groups
+constexpr int AT_TK = 32;            // keys per tile
+constexpr int AT_QW = 32;            // queries per wave
+constexpr int AT_WAVES = 4;
+constexpr int AT_THREADS = AT_WAVES * 64;
+constexpr int AT_K_ITEMS = AT_CG * 2 * AT_TK;        // 2048 uint4 (32 KB)
+constexpr int AT_V_ITEMS = (AT_TK / 8) * 2 * AT_C;   // 2048 uint4 (32 KB)
+constexpr int AT_PF = AT_K_ITEMS / AT_THREADS;       // 8 K items + 8 V items per thread and tile
+constexpr int AT_BUF_BYTES = (AT_K_ITEMS + AT_V_ITEMS) * 16;   // 64 KB per buffer
+typedef __attribute__((ext_vector_type(4))) short bf16x4;
+}  // namespace
+
+__global__ __launch_bounds__(AT_THREADS) void md_attn_fwd_kernel(const uint4* __restrict__ qk, const uint4* __restrict__ vT,
+                                                                 uint16_t* __restrict__ out, const float* __restrict__ bias_v,
+                                                                 int N, int batch, float scale_log2e) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * AT_BUF_BYTES];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 31, h = lane >> 5;
+  // workgroup w runs on XCD w % 8: give every XCD one sample (all of its query tiles stream the same K / V through that L2)
+  const int b = blockIdx.x % batch;
+  const int qt = blockIdx.x / batch;
+  const int q0 = qt * (AT_WAVES * AT_QW) + wid * AT_QW;
+  const uint4* qkb = qk + (int64_t)b * (2 * AT_CG) * 2 * N;          // [2C/8][2][N] uint4
+  const uint4* vb = vT + (int64_t)b * (N / 8) * 2 * AT_C;            // [N/8][2][C] uint4
+
+  // ---- the wave's Q operand: B fragments for all 16 channel steps, hi and lo (128 VGPRs) ----
+  bf16x8 qhi[AT_C / 16], qlo[AT_C / 16];
+#pragma unroll
+  for (int ks = 0; ks < AT_C / 16; ++ks) {
+    const int g = 2 * ks + h;
+    qhi[ks] = __builtin_bit_cast(bf16x8, qkb[((int64_t)(g * 2 + 0)) * N + q0 + j]);
+    qlo[ks] = __builtin_bit_cast(bf16x8, qkb[((int64_t)(g * 2 + 1)) * N + q0 + j]);
+  }
+  f32x16 oacc[AT_C / 32];
+#pragma unroll
+  for (int rt = 0; rt < AT_C / 32; ++rt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[rt][r] = 0.f;
+  float m_run = -1e30f, l_run = 0.f;       // running max (log2 domain) and this lane's partial denominator
+
+  // ---- tile prefetch: global -> registers -> LDS ----
+  uint4 pfk[AT_PF], pfv[AT_PF];
+  const uint4* kpart = qkb + (int64_t)AT_CG * 2 * N;                 // k = channels C .. 2C-1 of the fused q|k tensor
+  auto issue = [&](int t) {
+    const int k0 = t * AT_TK;
+#pragma unroll
+    for (int i = 0; i < AT_PF; ++i) {
+      const int idx = tid + i * AT_THREADS;
+      pfk[i] = kpart[(int64_t)(idx / AT_TK) * N + k0 + (idx % AT_TK)];            // (g*2+plane) = idx / 32, key = idx % 32
+      pfv[i] = vb[((int64_t)(k0 / 8) * 2) * AT_C + idx];                          // ((kg*2+plane) * C + c) = idx
+    }
+  };
+  auto commit = [&](int buf) {
+    unsigned char* base = lds + buf * AT_BUF_BYTES;
+#pragma unroll
+    for (int i = 0; i < AT_PF; ++i) {
+      const int idx = tid + i * AT_THREADS;
+      *(uint4*)(base + idx * 16) = pfk[i];
+      // V: the two 8-byte halves (keys 0-3 / 4-7 of the group) go to separate planes so that a half-wave's 32 lanes read
+      // 32 consecutive 8-byte words: [kg*2+plane][half][c]
+      const int gp = idx / AT_C, c = idx % AT_C;
+      unsigned char* vbase = base + AT_K_ITEMS * 16 + ((gp * 2) * AT_C + c) * 8;
+      *(uint2*)(vbase) = make_uint2(pfv[i].x, pfv[i].y);
+      *(uint2*)(vbase + AT_C * 8) = make_uint2(pfv[i].z, pfv[i].w);
+    }
+  };
+
+  const int ntiles = N / AT_TK;
+  issue(0);
+  commit(0);
+  __syncthreads();
+  for (int t = 0; t < ntiles; ++t) {
+    const unsigned char* kb = lds + (t & 1) * AT_BUF_BYTES;
+    const unsigned char* vbuf = kb + AT_K_ITEMS * 16;
+    if (t + 1 < ntiles) issue(t + 1);
+    // ---- S^T tile: 32 keys x 32 queries, K = 256 channels; two accumulators (even / odd channel steps) ----
+    f32x16 s0, s1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
+#pragma unroll
+    for (int ks = 0; ks < AT_C / 16; ++ks) {
+      const int g = 2 * ks + h;
+      const bf16x8 khi = *(const bf16x8*)(kb + ((g * 2 + 0) * AT_TK + j) * 16);
+      const bf16x8 klo = *(const bf16x8*)(kb + ((g * 2 + 1) * AT_TK + j) * 16);
+      if (ks & 1) {
+        s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(klo, qhi[ks], s1, 0, 0, 0);
+        s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(khi, qlo[ks], s1, 0, 0, 0);
+        s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(khi, qhi[ks], s1, 0, 0, 0);
+      } else {
+        s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(klo, qhi[ks], s0, 0, 0, 0);
+        s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(khi, qlo[ks], s0, 0, 0, 0);
+        s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(khi, qhi[ks], s0, 0, 0, 0);
+      }
+    }
+    // ---- online softmax of this query column (log2 domain: exp(x) = 2^(x log2 e), the 1/sqrt(C) scale folded in) ----
+    float tv[16];
+    float mloc = -1e30f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { tv[r] = (s0[r] + s1[r]) * scale_log2e; mloc = fmaxf(mloc, tv[r]); }
+    mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+    // Lazy rescale: the reference point m_run only moves when some query's tile maximum exceeds it by more than 2^8
+    // (p <= 256 is harmless in fp32 / split bf16), so the 128 accumulator registers are rescaled a few times per
+    // kernel instead of once per tile.  Wave-uniform decision: every lane then applies its own factor (1 if unmoved).
+    if (__builtin_amdgcn_ballot_w64(mloc > m_run + 8.0f) != 0) {
+      const float m_new = fmaxf(m_run, mloc);
+      const float corr = __builtin_amdgcn_exp2f(m_run - m_new);
+      m_run = m_new;
+      l_run *= corr;
+#pragma unroll
+      for (int rt = 0; rt < AT_C / 32; ++rt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[rt][r] *= corr;
+    }
+    float psum = 0.f;
+    uint32_t phi[16], plo[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float p = __builtin_amdgcn_exp2f(tv[r] - m_run);
+      psum += p;
+      md_split(p, phi[r], plo[r]);
+    }
+    l_run += psum;
+    // P as MFMA B fragments: key step ks takes accumulator rows {2ks, 2ks+1} x 4
+    bf16x8 pbh[2], pbl[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      uint4 uh, ul;
+      uh.x = phi[(2 * ks) * 4 + 0] | (phi[(2 * ks) * 4 + 1] << 16); uh.y = phi[(2 * ks) * 4 + 2] | (phi[(2 * ks) * 4 + 3] << 16);
+      uh.z = phi[(2 * ks + 1) * 4 + 0] | (phi[(2 * ks + 1) * 4 + 1] << 16); uh.w = phi[(2 * ks + 1) * 4 + 2] | (phi[(2 * ks + 1) * 4 + 3] << 16);
+      ul.x = plo[(2 * ks) * 4 + 0] | (plo[(2 * ks) * 4 + 1] << 16); ul.y = plo[(2 * ks) * 4 + 2] | (plo[(2 * ks) * 4 + 3] << 16);
+      ul.z = plo[(2 * ks + 1) * 4 + 0] | (plo[(2 * ks + 1) * 4 + 1] << 16); ul.w = plo[(2 * ks + 1) * 4 + 2] | (plo[(2 * ks + 1) * 4 + 3] << 16);
+      pbh[ks] = __builtin_bit_cast(bf16x8, uh);
+      pbl[ks] = __builtin_bit_cast(bf16x8, ul);
+    }
+    // ---- O += V P : 8 channel row tiles x 2 key steps x 3 MFMAs ----
+#pragma unroll
+    for (int rt = 0; rt < AT_C / 32; ++rt) {
+      const int c = rt * 32 + j;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        // V fragment in the P key order: keys 16ks + 4h + {0..3} (group 2ks, half h) then 16ks + 8 + 4h + {0..3} (group 2ks+1)
+        const uint2 a0 = *(const uint2*)(vbuf + ((((2 * ks) * 2 + 0) * 2 + h) * AT_C + c) * 8);
+        const uint2 a1 = *(const uint2*)(vbuf + ((((2 * ks + 1) * 2 + 0) * 2 + h) * AT_C + c) * 8);
+        const uint2 l0 = *(const uint2*)(vbuf + ((((2 * ks) * 2 + 1) * 2 + h) * AT_C + c) * 8);
+        const uint2 l1 = *(const uint2*)(vbuf + ((((2 * ks + 1) * 2 + 1) * 2 + h) * AT_C + c) * 8);
+        const bf16x8 vhi = __builtin_bit_cast(bf16x8, make_uint4(a0.x, a0.y, a1.x, a1.y));
+        const bf16x8 vlo = __builtin_bit_cast(bf16x8, make_uint4(l0.x, l0.y, l1.x, l1.y));
+        oacc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vlo, pbh[ks], oacc[rt], 0, 0, 0);
+        oacc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vhi, pbl[ks], oacc[rt], 0, 0, 0);
+        oacc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vhi, pbh[ks], oacc[rt], 0, 0, 0);
+      }
+    }
+    if (t + 1 < ntiles) commit((t + 1) & 1);     // its last readers (tile t-1) are behind the previous barrier
+    __syncthreads();
+  }
+
+  // ---- epilogue: o = O / l + b_v, written as split bf16 (S16B [B][C/8][2][N][8]) ----
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.0f / l_tot;
+  uint16_t* ob = out + (int64_t)b * AT_CG * 2 * N * 8;
+  const int64_t qpos = q0 + j;
+#pragma unroll
+  for (int rt = 0; rt < AT_C / 32; ++rt)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int row = rt * 32 + 8 * q + 4 * h;          // 4 consecutive channels
+      uint32_t hi[4], lo[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) md_split(oacc[rt][q * 4 + e] * inv + bias_v[row + e], hi[e], lo[e]);
+      const int64_t o = (((int64_t)(row >> 3) * 2) * N + qpos) * 8 + (row & 7);
+      *(uint2*)(ob + o) = make_uint2(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16));
+      *(uint2*)(ob + o + (int64_t)N * 8) = make_uint2(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16));
+    }
+}
+
+extern "C" int md_attn_fwd(const void* qk, const void* vT, void* out, const float* bias_v, int32_t batch, int32_t C,
+                           int32_t N, float scale, void* stream) {
+  if (!qk || !vT || !out || !bias_v || batch <= 0) return MD_ERR_BAD_ARG;
+  if (C != AT_C || N <= 0 || (N % (AT_WAVES * AT_QW))) return MD_ERR_UNSUPPORTED;
+  MD_HIP_CLEAR_ERROR();
+  hipLaunchKernelGGL(md_attn_fwd_kernel, dim3((unsigned)(batch * (N / (AT_WAVES * AT_QW)))), dim3(AT_THREADS), 0,
+                     (hipStream_t)stream, (const uint4*)qk, (const uint4*)vT, (uint16_t*)out, bias_v, N, batch,
+                     scale * 1.4426950408889634f);
+  MD_HIP_CHECK_LAUNCH();
+  return MD_OK;
+}

@@ -34,6 +34,7 @@ constexpr int A_PER_THREAD = (A_ITEMS + NTHREADS - 1) / NTHREADS;  // 10
 constexpr int W_LDS_BYTES = 2 * W_ITEMS * 16;                     // 32 KiB (double buffer)
 constexpr int LDS_ITEMS = 2 * W_ITEMS + KG * 2 * HS;              // 124928 B
 constexpr int PF_TAP = 20;               // tap at which the next chunk's halo loads are issued
+constexpr int PF_TAP_BF = 15;            // ... in the fused-operand mode: 10 taps of transform work follow (taps 16-25)
 
 __device__ __forceinline__ int slot_of(int hz, int hy, int hx) {
   return (hz >> 1) * (YH * 24) + hy * 24 + (hz & 1) * 12 + hx;
@@ -51,7 +52,7 @@ __device__ __forceinline__ int slot_of(int hz, int hy, int hx) {
 // MFMAs cover the ds_write latency) instead of right before the barrier.
 // BF = 1 (MD_B_F32B_GN): the B operand is read as fp32 (F32B, up to two channel-concatenated parts) and GroupNorm affine
 // + SiLU + the bf16 hi/lo split are applied while the halo tile is staged: one thread = one 8-channel group (kg = tid / 128,
-// wave-uniform) x 5 halo positions; the transform of item i runs at tap PF_TAP+1+i of the chunk before, between MFMAs.
+// wave-uniform) x 5 halo positions; the transform runs half an item per tap at taps 16-25 of the chunk before, between MFMAs.
 template <int ABL, int PREC, int VAR = 0, int BF = 0>
 __global__ __launch_bounds__(NTHREADS) void md_conv3_main_kernel(const MdGemmConvArgs A) {
   constexpr int PL = (PREC == MD_PREC_FP16X2) ? 1 : 2;        // activation planes staged in LDS
@@ -161,19 +162,21 @@ __global__ __launch_bounds__(NTHREADS) void md_conv3_main_kernel(const MdGemmCon
   };
   // BF: fp32 x 8 channels of item i -> (hi plane uint4, lo plane uint4) in place.  y = x*a + c, SiLU = y / (1 + 2^(-y log2 e))
   // with the hardware exp2 / rcp (1 ulp each), hi = bf16(y) (v_cvt_pk_bf16_f32, RNE), lo = bf16(y - hi).
-  auto act_transform = [&](int i) {
+  // One call handles HALF an item (4 channels = one fp32 uint4 -> (hi pair, lo pair) in place: .xy = hi, .zw = lo), so the
+  // VALU work of a chunk is spread thinly over 10 taps (about 1.5 VALU instructions per MFMA and wave).
+  auto act_transform = [&](int hidx) {
     if constexpr (BF) {
-      float v[8];
-      const uint4 r0 = hreg[2 * i], r1 = hreg[2 * i + 1];
-      v[0] = __uint_as_float(r0.x); v[1] = __uint_as_float(r0.y); v[2] = __uint_as_float(r0.z); v[3] = __uint_as_float(r0.w);
-      v[4] = __uint_as_float(r1.x); v[5] = __uint_as_float(r1.y); v[6] = __uint_as_float(r1.z); v[7] = __uint_as_float(r1.w);
-      uint32_t hi[8], lo[8];
+      const int i = hidx >> 1;
+      const uint4 r = hreg[hidx];
+      const float v[4] = {__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z), __uint_as_float(r.w)};
+      uint32_t hi[4], lo[4];
       const bool live = hsrc[i] >= 0;                     // outside the grid the ACTIVATED tensor is zero padded
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
+      for (int e = 0; e < 4; ++e) {
+        const int ce = (hidx & 1) * 4 + e;                // channel within the group of 8
         float y = v[e];
         if (A.b_ac != nullptr) {
-          y = y * bf_ac[e >> 1][(e & 1) * 2] + bf_ac[e >> 1][(e & 1) * 2 + 1];
+          y = y * bf_ac[ce >> 1][(ce & 1) * 2] + bf_ac[ce >> 1][(ce & 1) * 2 + 1];
           if (A.b_silu) y = y * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(y * -1.4426950408889634f));
         }
         if (!live) y = 0.f;
@@ -182,8 +185,7 @@ __global__ __launch_bounds__(NTHREADS) void md_conv3_main_kernel(const MdGemmCon
         hi[e] = __builtin_bit_cast(unsigned short, h);
         lo[e] = __builtin_bit_cast(unsigned short, l);
       }
-      hreg[2 * i] = make_uint4(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16), hi[4] | (hi[5] << 16), hi[6] | (hi[7] << 16));
-      hreg[2 * i + 1] = make_uint4(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16), lo[4] | (lo[5] << 16), lo[6] | (lo[7] << 16));
+      hreg[hidx] = make_uint4(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16), lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16));
     }
   };
   auto act_commit = [&]() {
@@ -191,8 +193,9 @@ __global__ __launch_bounds__(NTHREADS) void md_conv3_main_kernel(const MdGemmCon
 #pragma unroll
       for (int i = 0; i < BF_IT; ++i)
         if (hdst[i] >= 0) {
-          *(uint4*)(lds + hdst[i]) = hreg[2 * i];
-          *(uint4*)(lds + hdst[i] + HS * 16) = hreg[2 * i + 1];
+          const uint4 r0 = hreg[2 * i], r1 = hreg[2 * i + 1];
+          *(uint4*)(lds + hdst[i]) = make_uint4(r0.x, r0.y, r1.x, r1.y);
+          *(uint4*)(lds + hdst[i] + HS * 16) = make_uint4(r0.z, r0.w, r1.z, r1.w);
         }
     } else {
 #pragma unroll
@@ -237,7 +240,7 @@ __global__ __launch_bounds__(NTHREADS) void md_conv3_main_kernel(const MdGemmCon
     act_issue(0);
     if constexpr (BF) {
 #pragma unroll
-      for (int i = 0; i < BF_IT; ++i) act_transform(i);
+      for (int i = 0; i < 2 * BF_IT; ++i) act_transform(i);
     }
     act_commit();
     *(uint4*)(lds + tid * 16) = wreg0;
@@ -354,9 +357,9 @@ __global__ __launch_bounds__(NTHREADS) void md_conv3_main_kernel(const MdGemmCon
         const uint4* wt = wbase + (int64_t)ts * W_ITEMS;
         wreg0 = wt[tid]; wreg1 = wt[tid + NTHREADS];
       }
-      if (tap == PF_TAP) act_issue(cpre);
+      if (tap == (BF ? PF_TAP_BF : PF_TAP)) act_issue(cpre);
       if constexpr (BF) {
-        if (tap > PF_TAP && tap <= PF_TAP + BF_IT) act_transform(tap - PF_TAP - 1);   // one item per tap, beside the MFMAs
+        if (tap > PF_TAP_BF && tap <= PF_TAP_BF + 2 * BF_IT) act_transform(tap - PF_TAP_BF - 1);   // half an item per tap, beside the MFMAs
       }
       if (tap == TAPS - 1) {
         __syncthreads();  // every wave has issued and completed its reads of this chunk's halo tile

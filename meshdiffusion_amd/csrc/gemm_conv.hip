@@ -168,7 +168,45 @@ __global__ __launch_bounds__(C::NTHREADS) void md_gemm_conv_kernel(const MdGemmC
 
   // ---- activation halo tile: global -> registers -> LDS (zero fill outside the grid) ----
   uint4 hreg[C::A_PER_THREAD];
+  // MD_B_F32B_GN on a 1x1x1 configuration (the ResnetBlock shortcut NIN_0 reading the raw block input, layers.py:688):
+  // one thread = (8-channel group, position) pairs; two fp32 uint4 in, the hi and the lo plane item out.  No affine /
+  // SiLU here (b_ac must be NULL): the shortcut takes the un-normalised input.
+  const bool bf32 = (C::TAPS == 1) && A.b_mode == MD_B_F32B_GN;
+  const uint4* bf_p1 = (const uint4*)A.b + (int64_t)b * (A.b_bstride / 4);
+  const uint4* bf_p2 = (const uint4*)A.b2 + (int64_t)b * (A.b2_bstride / 4);
+  auto act_issue_f32 = [&](int cc) {
+    if constexpr (C::TAPS == 1 && (C::A_PER_THREAD % 2) == 0) {
+#pragma unroll
+      for (int i = 0; i < C::A_PER_THREAD / 2; ++i) {
+        const int q = tid + i * C::NTHREADS;                 // pair index: (kg, position)
+        const int kg = q / C::HPOS, r = q % C::HPOS;
+        const int g8 = (cc_lo + cc) * C::KG + kg;
+        const uint4* cb = (g8 < (A.b_split >> 3)) ? bf_p1 + (int64_t)g8 * Pin * 2 : bf_p2 + (int64_t)(g8 - (A.b_split >> 3)) * Pin * 2;
+        const int64_t src = ((int64_t)t * C::MT + r) * 2;
+        const uint4 r0 = cb[src], r1 = cb[src + 1];
+        const float v[8] = {__uint_as_float(r0.x), __uint_as_float(r0.y), __uint_as_float(r0.z), __uint_as_float(r0.w),
+                            __uint_as_float(r1.x), __uint_as_float(r1.y), __uint_as_float(r1.z), __uint_as_float(r1.w)};
+        uint32_t hi[8], lo[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) md_split(v[e], hi[e], lo[e]);
+        hreg[2 * i] = make_uint4(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16), hi[4] | (hi[5] << 16), hi[6] | (hi[7] << 16));
+        hreg[2 * i + 1] = make_uint4(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16), lo[4] | (lo[5] << 16), lo[6] | (lo[7] << 16));
+      }
+    }
+  };
+  auto act_commit_f32 = [&]() {
+    if constexpr (C::TAPS == 1 && (C::A_PER_THREAD % 2) == 0) {
+#pragma unroll
+      for (int i = 0; i < C::A_PER_THREAD / 2; ++i) {
+        const int q = tid + i * C::NTHREADS;
+        const int kg = q / C::HPOS, r = q % C::HPOS;
+        al[(kg * 2) * C::HS + r] = hreg[2 * i];
+        al[(kg * 2 + 1) * C::HS + r] = hreg[2 * i + 1];
+      }
+    }
+  };
   auto act_issue = [&](int cc) {
+    if (bf32) { act_issue_f32(cc); return; }
 #pragma unroll
     for (int i = 0; i < C::A_PER_THREAD; ++i) {
       const int item = tid + i * C::NTHREADS;
@@ -198,6 +236,7 @@ __global__ __launch_bounds__(C::NTHREADS) void md_gemm_conv_kernel(const MdGemmC
     }
   };
   auto act_commit = [&]() {
+    if (bf32) { act_commit_f32(); return; }
 #pragma unroll
     for (int i = 0; i < C::A_PER_THREAD; ++i) {
       const int item = tid + i * C::NTHREADS;
@@ -566,9 +605,11 @@ using Cfg_C3_LOW = GCfg<128, 32, 4, 4, 4, 27, 1, 4, 2>;
 // for the larger halo re-read factor (2.8 vs 2.3)
 using Cfg_C3_128_W4 = GCfg<128, 32, 4, 4, 8, 27, 1, 2, 2>;
 using Cfg_C3_S2 = GCfg<128, 32, 4, 4, 4, 27, 2, 4, 2>;
-using Cfg_G1_128 = GCfg<128, 32, 1, 1, 256, 1, 1, 2, 4>;
-using Cfg_G1_128_LOW = GCfg<128, 32, 1, 1, 64, 1, 1, 4, 2>;
-using Cfg_G1_64_LOW = GCfg<64, 32, 1, 1, 64, 1, 1, 2, 2>;
+// PIPE=1: next chunk's weight and activation tiles are requested before the MFMAs of the current one (the 1x1x1 / GEMM
+// launches are HBM-bound: the unpipelined loop left the memory system idle during every compute phase)
+using Cfg_G1_128 = GCfg<128, 32, 1, 1, 256, 1, 1, 2, 4, 0, 1>;
+using Cfg_G1_128_LOW = GCfg<128, 32, 1, 1, 64, 1, 1, 4, 2, 0, 1>;
+using Cfg_G1_64_LOW = GCfg<64, 32, 1, 1, 64, 1, 1, 2, 2, 0, 1>;
 
 // ---- split-K finish: out = alpha * sum_z partial[z] + bias + residual (slices added in order) ----
 __global__ void md_splitk_reduce_kernel(const MdGemmConvArgs A, int64_t P) {
@@ -634,6 +675,11 @@ static int launch_cfg(const MdGemmConvArgs& a, hipStream_t stream) {
   }
   if (a.a_src == MD_A_S16B && a.a_rows <= 0) return MD_ERR_BAD_ARG;
   if (a.prec != MD_PREC_BF16X3) return MD_ERR_UNSUPPORTED;  // fp16x2 lives in the dedicated conv kernel only
+  if (a.b_mode != MD_B_S16B) {   // fp32 operand: split-only, 1x1x1 configurations whose tile is a whole number of pairs per thread
+    if (a.b_mode != MD_B_F32B_GN || C::TAPS != 1 || (C::A_PER_THREAD % 2) || (C::A_ITEMS % (2 * C::NTHREADS)) || a.b_ac != nullptr ||
+        (a.b_split & 7) || a.b_split <= 0 || (a.b_split < a.kdim && a.b2 == nullptr))
+      return MD_ERR_UNSUPPORTED;
+  }
   if (C::PIPE == 2 && a.a_src != MD_A_PACKED) return MD_ERR_UNSUPPORTED;
   const int row_tiles = (a.rows + C::NT - 1) / C::NT;
   const int ks = a.ksplit > 1 ? a.ksplit : 1;

@@ -356,6 +356,21 @@ def s16b_to_ncdhw(x, spatial):
     return out
 
 
+FUSE_ATTN = os.environ.get("MD_FUSE_ATTN", "1") == "1"   # fused QK^T / online softmax / PV kernel where it applies (inference)
+
+
+def attn_fused_ok(Cc, n_tokens):
+    return FUSE_ATTN and Cc == 256 and n_tokens % 128 == 0
+
+
+def attn_fwd(qk, vT, bias_v, B, Cc, n_tokens, scale):
+    """qk: S16B [B][2C][N] (q | k), vT: S16B over tokens [B][N][C] -> o: S16B [B][C][N] (md_attn_fwd)."""
+    lib = _lib.load()
+    o = s16b_empty(B, Cc, n_tokens, qk.device)
+    check(lib.md_attn_fwd(_ptr(qk), _ptr(vT), _ptr(o), _ptr(bias_v), B, Cc, n_tokens, float(scale), _stream()), "md_attn_fwd")
+    return o
+
+
 def softmax_keys(s, B, nk, nq):
     lib = _lib.load()
     p = torch.empty((B, nk // 8, 2, nq, 8), dtype=torch.bfloat16, device=s.device)

@@ -340,7 +340,8 @@ class DDPMUNet3D(layers.HipLayer):
             if isinstance(m, ResnetBlockDDPM):
                 put(late, [m.Dense_0.weight, m.Dense_0.bias, m.Conv_0.bias])
             put(order, m.parameters())
-        put(late, self.parameters())
+        unused = set() if self.USE_COORDS else {id(p) for p in self.pos_layer.parameters()}   # ddpm_res128 never runs pos_layer
+        put(late, [p for p in self.parameters() if id(p) not in unused])
         return order + late
 
     def _stem_cfg(self):

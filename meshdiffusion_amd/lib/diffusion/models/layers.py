@@ -146,16 +146,18 @@ def run_conv3(pw, act_s16, B, S_out, *, bias=None, bias_bstride=0, residual=None
 
 
 def run_gemm(pw, act_s16, B, P, *, bias=None, bias_bstride=0, residual=None, out=None, out_mode=ops.OUT_F32B,
-             alpha=1.0, b_bstride=None):
-    """1x1x1 conv / GEMM with packed weights: out[rows][P]."""
+             alpha=1.0, b_bstride=None, b_f32=None):
+    """1x1x1 conv / GEMM with packed weights: out[rows][P].  b_f32: fp32 F32B parts split by the kernel's loader
+    (CFG_G1_128 only; hip_ops.gemm_conv) instead of the S16B operand `act_s16`."""
     rows_alloc = ((pw.rows + 7) // 8) * 8
+    dev = act_s16.device if act_s16 is not None else b_f32["parts"][0][0].device
     if out is None:
-        out = (ops.f32b_empty if out_mode == ops.OUT_F32B else ops.s16b_empty)(B, rows_alloc, P, act_s16.device)
+        out = (ops.f32b_empty if out_mode == ops.OUT_F32B else ops.s16b_empty)(B, rows_alloc, P, dev)
     return ops.gemm_conv(cfg=pw.cfg, a=pw.data, b=act_s16, out=out, batch=B, rows=pw.rows,
                          rows_alloc=rows_alloc, kdim=pw.kdim, dims=(1, 1, P), bias=bias,
                          bias_bstride=bias_bstride, residual=residual,
                          res_bstride=rows_alloc * P if residual is not None else 0, alpha=alpha,
-                         out_mode=out_mode, b_bstride=b_bstride)
+                         out_mode=out_mode, b_bstride=b_bstride, b_f32=b_f32)
 
 
 # --------------------------------------------------------------------------------------------
@@ -227,6 +229,10 @@ class AttnBlock(HipLayer):
         ops.gemm_conv(cfg=cfg_v, a=h, b=self._wv_s16(), out=vT, batch=B, rows=P, rows_alloc=P, kdim=Cc,
                       dims=(1, 1, Cc), a_src=ops.A_S16B, a_rows=P, a_bstride=(Cc // 8) * 2 * P * 8,
                       b_bstride=0, out_mode=ops.OUT_S16B)
+        if tape is None and ops.attn_fused_ok(Cc, P):
+            # inference at the 16^3 levels: QK^T, online softmax and PV in one kernel (no [B][P][P] score matrix)
+            o = ops.attn_fwd(qk, vT, self.NIN_2.b, B, Cc, P, ops.attn_scale(Cc))
+            return self.NIN_3.forward_s16(o, B, P, residual=x)
         # S^T[key][query] = C^-1/2 * sum_c k[c][key] q[c][query]   (fp32, keys blocked by 8)
         cfg_s = ops.gemm_cfg_for(P, P)
         sT = ops.f32b_empty(B, P, P, dev)
@@ -361,9 +367,13 @@ class ResnetBlockDDPM(HipLayer):
                     bias0, bias0_stride = self.Conv_0.bias, 0
             h = run_conv3(pw0, None, B, S, bias=bias0, bias_bstride=bias0_stride, want_stats=True,
                           b_f32=dict(parts=parts, ac=ac0, silu=True))
-            if need_nin:   # the shortcut GEMM still takes a split-bf16 operand: one raw split pass of the block input
-                xs = ops.gn_apply(parts, None, B, P, norm=False, silu=False)
-                res = self.NIN_0.forward_s16(xs, B, P)
+            if need_nin:
+                pwn = self.NIN_0.packed(P)
+                if pwn.cfg == ops.CFG_G1_128 and pwn.kdim == cin:   # the shortcut GEMM splits the raw fp32 parts itself
+                    res = run_gemm(pwn, None, B, P, bias=self.NIN_0.b, b_f32=dict(parts=parts, ac=None, silu=False))
+                else:                                               # small grids: one raw split pass of the block input
+                    xs = ops.gn_apply(parts, None, B, P, norm=False, silu=False)
+                    res = self.NIN_0.forward_s16(xs, B, P)
             else:
                 res = parts[0][0]
             _, ac1 = ops.gn_params([(h, self.out_ch)], g1.weight, g1.bias, B, P, eps=g1.eps, groups=g1.num_groups, want_ac=True)

@@ -173,11 +173,10 @@ class FlatGrads:
 def flat_grads_for(net):
     """The FlatGrads of a network that knows its gradient completion order (cached on the module; rebuilt when the
     parameters were re-created or moved)."""
-    params = list(net.parameters())
+    order = net.grad_completion_order()      # every parameter the backward writes (unused ones keep .grad = None)
     fg = net.__dict__.get("_md_flat_grads")
-    if fg is None or not fg.matches(params):
-        fg = FlatGrads(net.grad_completion_order())
-        assert fg.matches(params), "grad_completion_order() must list every trainable parameter exactly once"
+    if fg is None or not fg.matches(order):
+        fg = FlatGrads(order)
         net.__dict__["_md_flat_grads"] = fg
     return fg
 

@@ -59,8 +59,10 @@ def test_resnet_block(env, cin, cout, S):
     assert rel_l2(y, ref) < TOL_EVAL
 
 
-@pytest.mark.parametrize("Cc,S", [(64, 8), (64, 4), (256, 8)])
+@pytest.mark.parametrize("Cc,S", [(64, 8), (64, 4), (256, 8), (256, 16)])
 def test_attn_block(env, Cc, S):
+    """(256, 8) and (256, 16) run the fused attention kernel (md_attn_fwd: C = 256, N % 128 == 0; 16^3 is the res64 shape),
+    the others the GEMM + softmax path."""
     layers, uo = env["layers"], env["uo"]
     blk = layers.AttnBlock(channels=Cc)
     sd = _layer_sd(blk, 4)
@@ -71,6 +73,17 @@ def test_attn_block(env, Cc, S):
         ref = uo.attn_block(sd, x)
     assert rel_l2(y, ref) < TOL_EVAL
     assert rel_l2(y - x, ref - x) < 5e-4      # the attention branch itself, not just the residual
+    from meshdiffusion_amd import hip_ops
+    if hip_ops.attn_fused_ok(Cc, S ** 3):     # the fused kernel against the GEMM + md_softmax_keys path on the same input
+        hip_ops.FUSE_ATTN = False
+        try:
+            with torch.no_grad():
+                y2 = blk(x.cuda()).cpu()
+        finally:
+            hip_ops.FUSE_ATTN = True
+        e = rel_l2(y - x, y2 - x)
+        print(f"fused attention vs GEMM+softmax path (C={Cc}, N={S ** 3}): branch rel-L2 {e:.2e}; vs oracle {rel_l2(y - x, ref - x):.2e} / {rel_l2(y2 - x, ref - x):.2e}")
+        assert e < 1e-4
 
 
 def test_up_down_nin(env):
