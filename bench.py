@@ -331,7 +331,8 @@ def train_step_bench(a, cfg, model, rank, world, dev, dist, barrier):
                          "buckets": ex.get("buckets", 0), "bytes": ex.get("bytes", 0), "bucket_cap_bytes": 128 << 20,
                          "exposed_ms": round(split.get("exchange_exposed", 0.0), 2)},
             "loss": [round(float(v.detach()), 5) for v in losses_seen],
-            "peak_hbm_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1), "optimizer": "torch.optim.Adam + clip_grad_norm_ (reference optimize_fn)"}
+            "peak_hbm_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1), "optimizer": "reference objects (torch.optim.Adam state, EMA shadow params, optimization_manager hyper-parameters) executed by "
+                         "md_grad_sqnorm + md_adam_ema_step over flat buffers (MD_FUSED_OPT=0: torch kernels)"}
 
 
 def res128_step(dev, steps=3, warmup=2):

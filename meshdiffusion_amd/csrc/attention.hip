@@ -135,25 +135,20 @@ __global__ __launch_bounds__(AT_THREADS) void md_attn_fwd_kernel(const uint4* __
         for (int r = 0; r < 16; ++r) oacc[rt][r] *= corr;
     }
     float psum = 0.f;
-    uint32_t phi[16], plo[16];
+    uint32_t phi[8], plo[8];            // packed pairs of accumulator rows (2r, 2r+1)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float p = __builtin_amdgcn_exp2f(tv[r] - m_run);
-      psum += p;
-      md_split(p, phi[r], plo[r]);
+    for (int r = 0; r < 8; ++r) {
+      const float p0 = __builtin_amdgcn_exp2f(tv[2 * r] - m_run), p1 = __builtin_amdgcn_exp2f(tv[2 * r + 1] - m_run);
+      psum += p0 + p1;
+      md_split2(p0, p1, phi[r], plo[r]);
     }
     l_run += psum;
     // P as MFMA B fragments: key step ks takes accumulator rows {2ks, 2ks+1} x 4
     bf16x8 pbh[2], pbl[2];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      uint4 uh, ul;
-      uh.x = phi[(2 * ks) * 4 + 0] | (phi[(2 * ks) * 4 + 1] << 16); uh.y = phi[(2 * ks) * 4 + 2] | (phi[(2 * ks) * 4 + 3] << 16);
-      uh.z = phi[(2 * ks + 1) * 4 + 0] | (phi[(2 * ks + 1) * 4 + 1] << 16); uh.w = phi[(2 * ks + 1) * 4 + 2] | (phi[(2 * ks + 1) * 4 + 3] << 16);
-      ul.x = plo[(2 * ks) * 4 + 0] | (plo[(2 * ks) * 4 + 1] << 16); ul.y = plo[(2 * ks) * 4 + 2] | (plo[(2 * ks) * 4 + 3] << 16);
-      ul.z = plo[(2 * ks + 1) * 4 + 0] | (plo[(2 * ks + 1) * 4 + 1] << 16); ul.w = plo[(2 * ks + 1) * 4 + 2] | (plo[(2 * ks + 1) * 4 + 3] << 16);
-      pbh[ks] = __builtin_bit_cast(bf16x8, uh);
-      pbl[ks] = __builtin_bit_cast(bf16x8, ul);
+      pbh[ks] = __builtin_bit_cast(bf16x8, make_uint4(phi[4 * ks], phi[4 * ks + 1], phi[4 * ks + 2], phi[4 * ks + 3]));
+      pbl[ks] = __builtin_bit_cast(bf16x8, make_uint4(plo[4 * ks], plo[4 * ks + 1], plo[4 * ks + 2], plo[4 * ks + 3]));
     }
     // ---- O += V P : 8 channel row tiles x 2 key steps x 3 MFMAs ----
 #pragma unroll

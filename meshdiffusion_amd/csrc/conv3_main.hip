@@ -169,7 +169,7 @@ __global__ __launch_bounds__(NTHREADS) void md_conv3_main_kernel(const MdGemmCon
       const int i = hidx >> 1;
       const uint4 r = hreg[hidx];
       const float v[4] = {__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z), __uint_as_float(r.w)};
-      uint32_t hi[4], lo[4];
+      float yv[4];
       const bool live = hsrc[i] >= 0;                     // outside the grid the ACTIVATED tensor is zero padded
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -179,13 +179,12 @@ __global__ __launch_bounds__(NTHREADS) void md_conv3_main_kernel(const MdGemmCon
           y = y * bf_ac[ce >> 1][(ce & 1) * 2] + bf_ac[ce >> 1][(ce & 1) * 2 + 1];
           if (A.b_silu) y = y * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(y * -1.4426950408889634f));
         }
-        if (!live) y = 0.f;
-        const __bf16 h = (__bf16)y;
-        const __bf16 l = (__bf16)(y - (float)h);
-        hi[e] = __builtin_bit_cast(unsigned short, h);
-        lo[e] = __builtin_bit_cast(unsigned short, l);
+        yv[e] = live ? y : 0.f;
       }
-      hreg[hidx] = make_uint4(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16), lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16));
+      uint32_t h01, l01, h23, l23;                       // packed pairs: one v_cvt_pk_bf16_f32 per plane and pair
+      md_split2(yv[0], yv[1], h01, l01);
+      md_split2(yv[2], yv[3], h23, l23);
+      hreg[hidx] = make_uint4(h01, h23, l01, l23);
     }
   };
   auto act_commit = [&]() {

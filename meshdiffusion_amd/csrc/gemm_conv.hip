@@ -186,11 +186,11 @@ __global__ __launch_bounds__(C::NTHREADS) void md_gemm_conv_kernel(const MdGemmC
         const uint4 r0 = cb[src], r1 = cb[src + 1];
         const float v[8] = {__uint_as_float(r0.x), __uint_as_float(r0.y), __uint_as_float(r0.z), __uint_as_float(r0.w),
                             __uint_as_float(r1.x), __uint_as_float(r1.y), __uint_as_float(r1.z), __uint_as_float(r1.w)};
-        uint32_t hi[8], lo[8];
+        uint32_t hi[4], lo[4];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) md_split(v[e], hi[e], lo[e]);
-        hreg[2 * i] = make_uint4(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16), hi[4] | (hi[5] << 16), hi[6] | (hi[7] << 16));
-        hreg[2 * i + 1] = make_uint4(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16), lo[4] | (lo[5] << 16), lo[6] | (lo[7] << 16));
+        for (int e = 0; e < 4; ++e) md_split2(v[2 * e], v[2 * e + 1], hi[e], lo[e]);
+        hreg[2 * i] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+        hreg[2 * i + 1] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
       }
     }
   };
@@ -595,16 +595,16 @@ using Cfg_ABL4 = GCfg<128, 32, 4, 8, 8, 27, 1, 2, 4, 1, 1, 4>;
 using Cfg_ABL5 = GCfg<128, 32, 4, 8, 8, 27, 1, 2, 4, 1, 1, 5>;
 using Cfg_C3_128_K16 = GCfg<128, 16, 4, 8, 8, 27, 1, 2, 4>;
 using Cfg_C3_32 = GCfg<32, 32, 4, 8, 8, 27, 1, 1, 8>;
-using Cfg_C3X_32 = GCfg<32, 32, 4, 8, 8, 9, 1, 1, 8>;        // 3x3x1 taps: dx-folded 3x3x3 head (rows = (co, dx))
-using Cfg_C5X_32_K16 = GCfg<32, 16, 4, 8, 8, 25, 1, 1, 8>;   // 5x5x1 taps: dx-folded 5x5x5 head of ddpm_res128
-using Cfg_C3X_128_K16 = GCfg<128, 16, 4, 8, 8, 9, 1, 2, 4>;  // dx-folded 3x3x3 stem: K = 4 ch x 3 dx (12 -> 16)
-using Cfg_C5X_128 = GCfg<128, 32, 4, 8, 8, 25, 1, 2, 4>;     // dx-folded 5x5x5 stem: K = 4 ch x 5 dx (20 -> 32)
-using Cfg_C3_LOW = GCfg<128, 32, 4, 4, 4, 27, 1, 4, 2>;
+using Cfg_C3X_32 = GCfg<32, 32, 4, 8, 8, 9, 1, 1, 8, 0, 1>;        // 3x3x1 taps: dx-folded 3x3x3 head (rows = (co, dx))
+using Cfg_C5X_32_K16 = GCfg<32, 16, 4, 8, 8, 25, 1, 1, 8, 0, 1>;   // 5x5x1 taps: dx-folded 5x5x5 head of ddpm_res128
+using Cfg_C3X_128_K16 = GCfg<128, 16, 4, 8, 8, 9, 1, 2, 4, 0, 1>;  // dx-folded 3x3x3 stem: K = 4 ch x 3 dx (12 -> 16)
+using Cfg_C5X_128 = GCfg<128, 32, 4, 8, 8, 25, 1, 2, 4, 0, 1>;     // dx-folded 5x5x5 stem: K = 4 ch x 5 dx (20 -> 32)
+using Cfg_C3_LOW = GCfg<128, 32, 4, 4, 4, 27, 1, 4, 2, 0, 1>;   // PIPE=1: weight / halo loads requested ahead of the MFMAs
 // experiment: 4-wave workgroups on a 4x4x8 tile (78.8 KB of LDS => two independent workgroups per CU instead of one
 // 8-wave workgroup): +4.5 % on 128->128 @64^3, -3 % on 256->128 against Cfg_C3_128 -- decoupling the barriers does not pay
 // for the larger halo re-read factor (2.8 vs 2.3)
 using Cfg_C3_128_W4 = GCfg<128, 32, 4, 4, 8, 27, 1, 2, 2>;
-using Cfg_C3_S2 = GCfg<128, 32, 4, 4, 4, 27, 2, 4, 2>;
+using Cfg_C3_S2 = GCfg<128, 32, 4, 4, 4, 27, 2, 4, 2, 0, 1>;
 // PIPE=1: next chunk's weight and activation tiles are requested before the MFMAs of the current one (the 1x1x1 / GEMM
 // launches are HBM-bound: the unpipelined loop left the memory system idle during every compute phase)
 using Cfg_G1_128 = GCfg<128, 32, 1, 1, 256, 1, 1, 2, 4, 0, 1>;

@@ -32,6 +32,16 @@ __device__ __forceinline__ void md_split(float x, uint32_t& hi, uint32_t& lo) {
   lo = md_f2bf(x - md_bf2f(hi));
 }
 
+// Two values at once: one v_cvt_pk_bf16_f32 (RNE) per plane, results already packed as [lo half = x0 | hi half = x1].
+typedef __bf16 md_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float md_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void md_split2(float x0, float x1, uint32_t& hi, uint32_t& lo) {
+  const md_f32x2 y = {x0, x1};
+  hi = __builtin_bit_cast(uint32_t, __builtin_convertvector(y, md_bf16x2));
+  const md_f32x2 hf = {__uint_as_float(hi << 16), __uint_as_float(hi & 0xffff0000u)};
+  lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(y - hf, md_bf16x2));
+}
+
 // fp16x2 mode ("weights split, activations single"): w ~= hi + lo with hi = fp16(w), lo = fp16(w - hi);
 // activations are one fp16 (saturated to the finite range).
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));

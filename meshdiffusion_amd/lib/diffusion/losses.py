@@ -39,7 +39,115 @@ def optimization_manager(config):
             torch.nn.utils.clip_grad_norm_(params, max_norm=grad_clip)
         optimizer.step()
 
+    optimize_fn._md_hparams = True     # (lr, warmup, grad_clip) = optimize_fn.__defaults__: lets the step function fuse it
     return optimize_fn
+
+
+FUSED_OPT = __import__("os").environ.get("MD_FUSED_OPT", "1") == "1"
+
+
+class _FlatOptState:
+    """torch.optim.Adam + clip_grad_norm_ + ExponentialMovingAverage.update as the two launches of md_grad_sqnorm /
+    md_adam_ema_step over flat buffers -- WITHOUT changing what the caller holds: parameters, Adam's `exp_avg` /
+    `exp_avg_sq` and the EMA's `shadow_params` become views of flat buffers laid out like parallel.FlatGrads, so
+    `optimizer.state_dict()`, `ema.state_dict()` and therefore the reference checkpoint format keep working, and a
+    `load_state_dict` (new tensors) is detected and re-imported on the next step."""
+
+    def __init__(self, fg, optimizer, ema):
+        self.fg = fg
+        dev = fg.flat.device
+        self.p = torch.empty_like(fg.flat)
+        self.m = torch.zeros_like(fg.flat)
+        self.v = torch.zeros_like(fg.flat)
+        self.e = torch.empty_like(fg.flat)
+        self.sq = torch.zeros(1, dtype=torch.float64, device=dev)
+        self.step_t = torch.zeros((), dtype=torch.float32)          # shared by every parameter's Adam state entry
+        self.ema_index = None
+        for p in fg.params:                                          # parameters -> views of the flat buffer
+            _, o, n = fg.slices[id(p)]
+            self.p[o:o + n].copy_(p.data.reshape(-1))
+            p.data = self.p[o:o + n].view_as(p)
+        ops.bump_param_epoch()
+        self.opt_steps = 0
+        self._import(optimizer, ema)
+
+    def _views(self, flat):
+        return [flat[o:o + n].view_as(p) for p, (_, o, n) in ((p, self.fg.slices[id(p)]) for p in self.fg.params)]
+
+    def _import(self, optimizer, ema):
+        """Adopt whatever state the torch objects currently hold (fresh, or just loaded from a checkpoint)."""
+        mv, vv = self._views(self.m), self._views(self.v)
+        self.opt_steps = 0
+        for p, m_, v_ in zip(self.fg.params, mv, vv):
+            st = optimizer.state.get(p)
+            if st and "exp_avg" in st:
+                m_.copy_(st["exp_avg"]); v_.copy_(st["exp_avg_sq"])
+                self.opt_steps = int(float(st["step"]))
+            else:
+                m_.zero_(); v_.zero_()
+            optimizer.state[p] = dict(step=self.step_t, exp_avg=m_, exp_avg_sq=v_)
+        self.step_t.fill_(float(self.opt_steps))
+        live = [p for g in optimizer.param_groups for p in g["params"] if p.requires_grad]
+        idx = {id(p): i for i, p in enumerate(live)}
+        ev = self._views(self.e)
+        for p, e_ in zip(self.fg.params, ev):
+            i = idx[id(p)]
+            e_.copy_(ema.shadow_params[i])
+            ema.shadow_params[i] = e_
+        self.m0, self.e0, self.ema_i0 = mv[0], ev[0], idx[id(self.fg.params[0])]
+
+    def usable(self, optimizer, ema):
+        p0 = self.fg.params[0]
+        st = optimizer.state.get(p0)
+        if not st or st.get("exp_avg") is None or st["exp_avg"].data_ptr() != self.m0.data_ptr() \
+                or ema.shadow_params[self.ema_i0].data_ptr() != self.e0.data_ptr():
+            self._import(optimizer, ema)          # state was replaced (load_state_dict / restore_checkpoint)
+        return True
+
+    def step(self, optimizer, ema, sched_step, lr0, warmup, grad_clip):
+        lib = _lib.load()
+        g = optimizer.param_groups[0]
+        lr = float(lr0 * np.minimum(sched_step / warmup, 1.0)) if warmup > 0 else float(g["lr"])
+        g["lr"] = lr
+        self.opt_steps += 1
+        self.step_t.fill_(float(self.opt_steps))
+        d = ema._effective_decay()
+        sq = None
+        if grad_clip >= 0:
+            self.sq.zero_()
+            _lib.check(lib.md_grad_sqnorm(ops._ptr(self.fg.flat), self.fg.n, ops._ptr(self.sq), ops._stream()), "md_grad_sqnorm")
+            sq = self.sq
+        b1, b2 = g["betas"]
+        _lib.check(lib.md_adam_ema_step(ops._ptr(self.p), ops._ptr(self.fg.flat), ops._ptr(self.m), ops._ptr(self.v),
+                                        ops._ptr(self.e), self.fg.n, lr, float(b1), float(b2), float(g["eps"]),
+                                        float(g["weight_decay"]), self.opt_steps, float(d), ops._ptr(sq), float(grad_clip),
+                                        ops._stream()), "md_adam_ema_step")
+        ops.bump_param_epoch()   # raw-pointer update: packed-weight caches are keyed on data_ptr/_version
+
+
+def _fused_opt_for(net, fg, optimizer, ema, optimize_fn):
+    """The _FlatOptState of `net` when the step's optimizer / EMA are the reference configuration it can replace:
+    plain torch.optim.Adam (one group, no amsgrad / maximize) over exactly the parameters of `fg`, our EMA class and an
+    optimize_fn made by optimization_manager.  Otherwise None (the torch objects run as they are)."""
+    from .models.ema import ExponentialMovingAverage
+    if not (FUSED_OPT and fg is not None and getattr(optimize_fn, "_md_hparams", False)):
+        return None
+    if type(optimizer) is not optim.Adam or len(optimizer.param_groups) != 1 or not isinstance(ema, ExponentialMovingAverage):
+        return None
+    g = optimizer.param_groups[0]
+    if g.get("amsgrad") or g.get("maximize") or g.get("capturable") or g.get("differentiable"):
+        return None
+    live = [p for p in g["params"] if p.requires_grad]
+    if len(ema.shadow_params) != len(live) or any(id(p) not in {id(q) for q in live} for p in fg.params):
+        return None
+    if any(p.grad is not None for p in live if id(p) not in fg.slices):
+        return None                                  # a parameter outside the flat buffer received a gradient
+    fs = net.__dict__.get("_md_flat_opt")
+    if fs is None or fs.fg is not fg:
+        fs = _FlatOptState(fg, optimizer, ema)
+        net.__dict__["_md_flat_opt"] = fs
+    fs.usable(optimizer, ema)
+    return fs
 
 
 def ddpm_perturb(vpsde, batch, labels, noise, mask_flat):
@@ -155,6 +263,12 @@ def get_step_fn(sde, train, optimize_fn=None, mask=None, loss_type="l2"):
                 reducer.finish(model.parameters())
                 mark("exchange_exposed")               # what the backward did not hide
                 state["exchange"] = reducer.stats      # buckets / bytes of this step's all-reduces (bench.py reports them)
+                fs = _fused_opt_for(net, fg, optimizer, state["ema"], optimize_fn)
+                if fs is not None:      # clip + Adam + EMA: two launches over the flat buffers (same arithmetic)
+                    fs.step(optimizer, state["ema"], state["step"], *optimize_fn.__defaults__)
+                    state["step"] += 1
+                    mark("clip_adam_ema")
+                    return {"loss": loss}
                 optimize_fn(optimizer, model.parameters(), step=state["step"])
             state["step"] += 1
             state["ema"].update(model.parameters())

@@ -205,7 +205,7 @@ def sample_stats(x, mask, stride):
     li = live_cells(mask, stride)
     flat = x.reshape(B, C, -1)
     return dict(live=flat[:, :, li].numpy().copy(), norms=flat.double().reshape(B, -1).norm(dim=1).numpy(),
-                sums=flat.double().sum(dim=2).numpy(), stride=np.int64(stride))
+                sums=flat.double().sum(dim=2).numpy(), l1=flat.double().abs().sum(dim=2).numpy(), stride=np.int64(stride))
 
 
 def cond_inputs(R, mask, seed=5):
