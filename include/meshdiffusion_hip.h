@@ -68,7 +68,8 @@ enum {
   MD_CFG_C5X_32_K16 = 19, /* 5x5x1 taps, NT=32, KC=16: dx-folded 5x5x5 head of ddpm_res128                        */
   MD_CFG_C3X_128_K16 = 20, /* 3x3x1 taps, NT=128, KC=16: dx-folded 3x3x3 stem (K = 4 channels x 3 dx)                    */
   MD_CFG_C5X_128 = 21,     /* 5x5x1 taps, NT=128, KC=32: dx-folded 5x5x5 stem of ddpm_res128 (K = 4 channels x 5 dx)     */
-  MD_CFG_COUNT = 22
+  MD_CFG_G1_128_N128 = 22, /* 1x1x1 / GEMM, 128 cols, NT=128, KC=32: three workgroups per CU (HBM-bound shortcut NINs)         */
+  MD_CFG_COUNT = 23
 };
 
 enum { MD_OUT_F32B = 0, MD_OUT_S16B = 1, MD_OUT_NCDHW = 2 };

@@ -595,10 +595,10 @@ using Cfg_ABL4 = GCfg<128, 32, 4, 8, 8, 27, 1, 2, 4, 1, 1, 4>;
 using Cfg_ABL5 = GCfg<128, 32, 4, 8, 8, 27, 1, 2, 4, 1, 1, 5>;
 using Cfg_C3_128_K16 = GCfg<128, 16, 4, 8, 8, 27, 1, 2, 4>;
 using Cfg_C3_32 = GCfg<32, 32, 4, 8, 8, 27, 1, 1, 8>;
-using Cfg_C3X_32 = GCfg<32, 32, 4, 8, 8, 9, 1, 1, 8, 0, 1>;        // 3x3x1 taps: dx-folded 3x3x3 head (rows = (co, dx))
-using Cfg_C5X_32_K16 = GCfg<32, 16, 4, 8, 8, 25, 1, 1, 8, 0, 1>;   // 5x5x1 taps: dx-folded 5x5x5 head of ddpm_res128
-using Cfg_C3X_128_K16 = GCfg<128, 16, 4, 8, 8, 9, 1, 2, 4, 0, 1>;  // dx-folded 3x3x3 stem: K = 4 ch x 3 dx (12 -> 16)
-using Cfg_C5X_128 = GCfg<128, 32, 4, 8, 8, 25, 1, 2, 4, 0, 1>;     // dx-folded 5x5x5 stem: K = 4 ch x 5 dx (20 -> 32)
+using Cfg_C3X_32 = GCfg<32, 32, 4, 8, 8, 9, 1, 1, 8>;        // 3x3x1 taps: dx-folded 3x3x3 head (rows = (co, dx))
+using Cfg_C5X_32_K16 = GCfg<32, 16, 4, 8, 8, 25, 1, 1, 8>;   // 5x5x1 taps: dx-folded 5x5x5 head of ddpm_res128
+using Cfg_C3X_128_K16 = GCfg<128, 16, 4, 8, 8, 9, 1, 2, 4>;   // (PIPE=1 measured slower here: 1.02 vs 0.67 ms)  // dx-folded 3x3x3 stem: K = 4 ch x 3 dx (12 -> 16)
+using Cfg_C5X_128 = GCfg<128, 32, 4, 8, 8, 25, 1, 2, 4>;     // dx-folded 5x5x5 stem: K = 4 ch x 5 dx (20 -> 32)
 using Cfg_C3_LOW = GCfg<128, 32, 4, 4, 4, 27, 1, 4, 2, 0, 1>;   // PIPE=1: weight / halo loads requested ahead of the MFMAs
 // experiment: 4-wave workgroups on a 4x4x8 tile (78.8 KB of LDS => two independent workgroups per CU instead of one
 // 8-wave workgroup): +4.5 % on 128->128 @64^3, -3 % on 256->128 against Cfg_C3_128 -- decoupling the barriers does not pay
@@ -609,6 +609,9 @@ using Cfg_C3_S2 = GCfg<128, 32, 4, 4, 4, 27, 2, 4, 2, 0, 1>;
 // launches are HBM-bound: the unpipelined loop left the memory system idle during every compute phase)
 using Cfg_G1_128 = GCfg<128, 32, 1, 1, 256, 1, 1, 2, 4, 0, 1>;
 using Cfg_G1_128_LOW = GCfg<128, 32, 1, 1, 64, 1, 1, 4, 2, 0, 1>;
+// 128 columns per workgroup (48 KB of LDS: three workgroups per CU): the HBM-bound ResnetBlock shortcut at 64^3 / 32^3 --
+// one workgroup's output burst (64 KB) overlaps the other workgroups' loads
+using Cfg_G1_128_N128 = GCfg<128, 32, 1, 1, 128, 1, 1, 2, 4, 0, 1>;
 using Cfg_G1_64_LOW = GCfg<64, 32, 1, 1, 64, 1, 1, 2, 2, 0, 1>;
 
 // ---- split-K finish: out = alpha * sum_z partial[z] + bias + residual (slices added in order) ----
@@ -716,6 +719,7 @@ static void cfg_info(int32_t* nt, int32_t* kc, int32_t* cols, int32_t* taps, int
     case MD_CFG_C3_S2: F<Cfg_C3_S2>(__VA_ARGS__); break;            \
     case MD_CFG_G1_128: F<Cfg_G1_128>(__VA_ARGS__); break;          \
     case MD_CFG_G1_128_LOW: F<Cfg_G1_128_LOW>(__VA_ARGS__); break;  \
+    case MD_CFG_G1_128_N128: F<Cfg_G1_128_N128>(__VA_ARGS__); break; \
     case MD_CFG_G1_64_LOW: F<Cfg_G1_64_LOW>(__VA_ARGS__); break;    \
     case MD_CFG_C5_128_K16: F<Cfg_C5_128_K16>(__VA_ARGS__); break;  \
     case MD_CFG_C5_32_K16: F<Cfg_C5_32_K16>(__VA_ARGS__); break;

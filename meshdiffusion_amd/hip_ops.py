@@ -10,7 +10,7 @@ import os
 import torch
 
 from . import _lib
-from ._lib import (A_PACKED, A_S16B, PREC_BF16X3, PREC_FP16X2, CFG_C3_128, CFG_C3_128_V2, CFG_C3_128_SW, CFG_C3_128_PIPE, CFG_C3_128_V3, CFG_C3_128_V3B, CFG_C3_128_V4, CFG_C3_128_FAST, CFG_C5_128_K16, CFG_C5_32_K16, CFG_C3_128_W4, CFG_C3X_32, CFG_C5X_32_K16, CFG_C3X_128_K16, CFG_C5X_128, CFG_C3_128_K16, CFG_C3_32, CFG_C3_LOW, CFG_C3_S2,
+from ._lib import (A_PACKED, A_S16B, PREC_BF16X3, PREC_FP16X2, CFG_C3_128, CFG_C3_128_V2, CFG_C3_128_SW, CFG_C3_128_PIPE, CFG_C3_128_V3, CFG_C3_128_V3B, CFG_C3_128_V4, CFG_C3_128_FAST, CFG_C5_128_K16, CFG_C5_32_K16, CFG_C3_128_W4, CFG_C3X_32, CFG_C5X_32_K16, CFG_C3X_128_K16, CFG_C5X_128, CFG_G1_128_N128, CFG_C3_128_K16, CFG_C3_32, CFG_C3_LOW, CFG_C3_S2,
                    CFG_G1_128, CFG_G1_128_LOW, CFG_G1_64_LOW, CFG_NT_KC, OUT_F32B, OUT_NCDHW, OUT_S16B,
                    MdGemmConvArgs, check)
 
@@ -448,7 +448,13 @@ def conv_cfg_for(spatial, stride=1):
     return CFG_C3_128_FAST if spatial % 8 == 0 else CFG_C3_LOW
 
 
-def gemm_cfg_for(ncols, nrows):
+NIN_N128 = os.environ.get("MD_NIN_N128", "1") == "1"   # A/B: 128-column GEMM tile (3 workgroups / CU) for the HBM-bound shortcut NINs
+
+
+def gemm_cfg_for(ncols, nrows, hbm_bound=False):
+    """hbm_bound: a 1x1x1 layer over a big grid with few channels (ResnetBlock shortcut): prefer the 128-column tile."""
+    if hbm_bound and NIN_N128 and ncols % 128 == 0 and ncols >= 32768:
+        return CFG_G1_128_N128
     if ncols % 256 == 0:
         return CFG_G1_128
     return CFG_G1_128_LOW if nrows % 128 == 0 else CFG_G1_64_LOW

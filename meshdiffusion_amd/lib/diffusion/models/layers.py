@@ -171,9 +171,9 @@ class NIN(HipLayer):
         self.W = nn.Parameter(default_init(scale=init_scale)((in_dim, num_units)), requires_grad=True)
         self.b = nn.Parameter(torch.zeros(num_units), requires_grad=True)
 
-    def packed(self, P):
+    def packed(self, P, hbm_bound=False):
         rows = self.W.shape[1]
-        cfg = ops.gemm_cfg_for(P, rows)
+        cfg = ops.gemm_cfg_for(P, rows, hbm_bound)
         return self._cached(f"w{cfg}", [self.W], lambda: ops.PackedWeight(self.W, "nin", cfg, self.W.device))
 
     def forward_s16(self, act_s16, B, P, residual=None, out_mode=ops.OUT_F32B):
@@ -368,8 +368,8 @@ class ResnetBlockDDPM(HipLayer):
             h = run_conv3(pw0, None, B, S, bias=bias0, bias_bstride=bias0_stride, want_stats=True,
                           b_f32=dict(parts=parts, ac=ac0, silu=True))
             if need_nin:
-                pwn = self.NIN_0.packed(P)
-                if pwn.cfg == ops.CFG_G1_128 and pwn.kdim == cin:   # the shortcut GEMM splits the raw fp32 parts itself
+                pwn = self.NIN_0.packed(P, hbm_bound=True)
+                if pwn.cfg in (ops.CFG_G1_128, ops.CFG_G1_128_N128) and pwn.kdim == cin:   # the shortcut GEMM splits the raw fp32 parts itself
                     res = run_gemm(pwn, None, B, P, bias=self.NIN_0.b, b_f32=dict(parts=parts, ac=None, silu=False))
                 else:                                               # small grids: one raw split pass of the block input
                     xs = ops.gn_apply(parts, None, B, P, norm=False, silu=False)

@@ -149,11 +149,13 @@ def test_ema_swap_invalidates_packed_weights_around_train_steps(hip_lib):
     g = torch.Generator().manual_seed(9)
     for s in ema.shadow_params:                      # EMA = live * (1 + 5 % noise): a clearly different network
         s.mul_(1.0 + 0.05 * torch.randn(s.shape, generator=g).to(s.device))
-    ema.update = lambda params: None                 # keep the perturbed EMA fixed across the train steps
-    sd_ema = dict(sd)
     names = [n for n, p in model.module.named_parameters() if p.requires_grad]
-    for n, s in zip(names, ema.shadow_params):
-        sd_ema[n] = s.detach().cpu().clone()
+
+    def ema_weights():                               # the EMA as it is NOW (every train step moves it 0.1 % towards live)
+        w = dict(sd)
+        for n, s in zip(names, ema.shadow_params):
+            w[n] = s.detach().cpu().clone()
+        return w
     opt = losses.get_optimizer(cfg, model.parameters())
     sde = sde_lib.VPSDE(0.1, 20.0, 1000, device="cuda")
     mask = synth.synthetic_grid_mask(R).view(1, 1, R, R, R).cuda()
@@ -175,15 +177,15 @@ def test_ema_swap_invalidates_packed_weights_around_train_steps(hip_lib):
         ls = (torch.square(e - noise) * m).reshape(2, -1).mean(-1)
         return float(ls.mean() / m.sum() * m.numel())
 
-    got = []
+    got, want = [], []
     # step 3 catches "restore left EMA-packed weights behind" (no optimizer step between the eval and the forward that
     # follows it touches the key); steps 5-6 catch the other order: a forward on live weights WITHOUT an optimizer step
     # (gradient accumulation, update_param=False) followed by the EMA swap-in
     for fn, seed, kw in ((train_fn, 1, {}), (eval_fn, 2, {}), (train_fn, 3, {}), (eval_fn, 4, {}),
                          (train_fn, 5, dict(update_param=False)), (eval_fn, 6, {})):
+        want.append(oracle_loss(ema_weights() if fn is eval_fn else sd, seed))
         torch.manual_seed(seed)
         got.append(float(fn(state, batch, **kw)["loss"].detach()))
-    want = [oracle_loss(w, i + 1) for i, w in enumerate((sd, sd_ema, sd, sd_ema, sd, sd_ema))]
     print("losses (train, eval/EMA, train, eval/EMA, train w/o update, eval/EMA):", got, want)
     assert abs(want[0] - want[1]) / want[0] > 1e-3, "EMA perturbation too small to tell the two networks apart"
     for a, b in zip(got, want):

@@ -384,7 +384,8 @@ def test_gn_finalize_folded_affine(ops):
     assert rel_l2(y, F.group_norm(x, 32, gamma, beta, eps=1e-6)) < 2e-6
 
 
-def test_nin_gemm_fp32_parts_operand(ops):
+@pytest.mark.parametrize("cfg_name", ["CFG_G1_128", "CFG_G1_128_N128"])
+def test_nin_gemm_fp32_parts_operand(ops, cfg_name):
     """MD_B_F32B_GN on the 1x1x1 configuration: the shortcut GEMM reads the fp32 block input (a channel concat of two
     tensors) and splits it in its loader -- bit-identical to the GEMM on the pre-split S16B tensor."""
     B, S, cs, cout = 2, 8, [96, 32], 128
@@ -392,13 +393,14 @@ def test_nin_gemm_fp32_parts_operand(ops):
     xs = [_rand((B, c, S, S, S), 40 + i) for i, c in enumerate(cs)]
     W, bias = _rand((cin, cout), 42, 0.1), _rand((cout,), 43)
     parts = [(ops.ncdhw_to_f32b(t.cuda()), c) for t, c in zip(xs, cs)]
-    pw = ops.PackedWeight(W.cuda(), "nin", ops.CFG_G1_128, "cuda")
+    cfg = getattr(ops, cfg_name)
+    pw = ops.PackedWeight(W.cuda(), "nin", cfg, "cuda")
     out = ops.f32b_empty(B, cout, P, "cuda")
-    ops.gemm_conv(cfg=ops.CFG_G1_128, a=pw.data, b=None, out=out, batch=B, rows=cout, rows_alloc=cout, kdim=cin,
+    ops.gemm_conv(cfg=cfg, a=pw.data, b=None, out=out, batch=B, rows=cout, rows_alloc=cout, kdim=cin,
                   dims=(1, 1, P), bias=bias.cuda(), b_f32=dict(parts=parts, ac=None, silu=False))
     a16 = ops.gn_apply(parts, None, B, P, norm=False, silu=False)
     out2 = ops.f32b_empty(B, cout, P, "cuda")
-    ops.gemm_conv(cfg=ops.CFG_G1_128, a=pw.data, b=a16, out=out2, batch=B, rows=cout, rows_alloc=cout, kdim=cin,
+    ops.gemm_conv(cfg=cfg, a=pw.data, b=a16, out=out2, batch=B, rows=cout, rows_alloc=cout, kdim=cin,
                   dims=(1, 1, P), bias=bias.cuda())
     assert torch.equal(out, out2)
     ref = torch.einsum("bcdhw,co->bodhw", torch.cat(xs, 1), W) + bias[None, :, None, None, None]

@@ -6,10 +6,11 @@ OUT=$R/gpurun_out/prof
 mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
 STEPS=${STEPS:-3}
+BASE_ARGS="--no-res128 --no-train-step --no-fast-mode"   # the sampling step only (configs[1])
 run() {  # name, rocprof args...
   local name=$1; shift
   rm -rf /tmp/rp_$name
-  timeout 300 rocprofv3 "$@" --output-format csv -d /tmp/rp_$name -o $name -- python $R/bench.py --steps $STEPS --warmup 1 --no-cpu-baseline $BENCH_ARGS > $OUT/$name.log 2>&1
+  timeout 300 rocprofv3 "$@" --output-format csv -d /tmp/rp_$name -o $name -- python $R/bench.py --steps $STEPS --warmup 1 --no-cpu-baseline $BASE_ARGS $BENCH_ARGS > $OUT/$name.log 2>&1
   python $R/tools/prof_summary.py /tmp/rp_$name $OUT/$name.summary.txt
   find /tmp/rp_$name -name "*kernel_stats.csv" -exec cp {} $OUT/$name.kernel_stats.csv \;
   tail -2 $OUT/$name.log
