@@ -394,6 +394,15 @@ int md_marching_tets(const float* pos, const float* sdf, const int32_t* tets,
                      int64_t* faces, int64_t* face_tet, int32_t* counts, void* workspace,
                      int64_t workspace_bytes, void* stream);
 
+/*
+ * Smooth vertex normals of an extracted mesh (nvdiffrec/lib/render/mesh.py:200-229 `auto_normals`, called from
+ * nvdiffrec/eval.py:422 on the marching-tets output): face normals cross(v1-v0, v2-v0) accumulated on their three
+ * vertices, degenerate sums replaced by (0,0,1), normalised.  verts float32 [V][3], faces int64 [F][3] (as returned by
+ * md_marching_tets); v_nrm float32 [V][3] (zeroed by the call), f_nrm float32 [F][3] or NULL (unnormalised face normals).
+ */
+int md_vertex_normals(const float* verts, const int64_t* faces, int64_t n_verts, int64_t n_faces, float* v_nrm,
+                      float* f_nrm, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

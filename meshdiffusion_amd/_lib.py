@@ -91,6 +91,7 @@ SIGNATURES = {
     "md_softmax_keys_bwd": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _F, _P]),
     "md_grad_resample": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P]),
     "md_marching_tets_workspace_bytes": (_I64, [_I32, _I32]),
+    "md_vertex_normals": (C.c_int, [_P, _P, _I64, _I64, _P, _P, _P]),
     "md_marching_tets": (C.c_int, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _I64, _P]),
 }
 

@@ -177,3 +177,48 @@ extern "C" int md_marching_tets(const float* pos, const float* sdf, const int32_
   MD_HIP_CHECK_LAUNCH();
   return MD_OK;
 }
+
+// ---- smooth vertex normals of an extracted mesh (nvdiffrec/lib/render/mesh.py:200-229 `auto_normals`) ----------------
+// f_nrm = cross(v1 - v0, v2 - v0) per face, splatted onto its three vertices (scatter_add in the reference: float
+// atomics here, so the summation order -- not the set of terms -- differs), then v / sqrt(max(v.v, 1e-20)) with
+// degenerate sums (v.v <= 1e-20) replaced by (0, 0, 1) first (util.safe_normalize, util.py:33-35).
+__global__ void md_face_normals_kernel(const float* __restrict__ verts, const int64_t* __restrict__ faces, int64_t F,
+                                       float* __restrict__ v_nrm, float* __restrict__ f_nrm) {
+  const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= F) return;
+  const int64_t i0 = faces[f * 3], i1 = faces[f * 3 + 1], i2 = faces[f * 3 + 2];
+  const float ax = verts[i1 * 3] - verts[i0 * 3], ay = verts[i1 * 3 + 1] - verts[i0 * 3 + 1], az = verts[i1 * 3 + 2] - verts[i0 * 3 + 2];
+  const float bx = verts[i2 * 3] - verts[i0 * 3], by = verts[i2 * 3 + 1] - verts[i0 * 3 + 1], bz = verts[i2 * 3 + 2] - verts[i0 * 3 + 2];
+  const float nx = ay * bz - az * by, ny = az * bx - ax * bz, nz = ax * by - ay * bx;
+  if (f_nrm) { f_nrm[f * 3] = nx; f_nrm[f * 3 + 1] = ny; f_nrm[f * 3 + 2] = nz; }
+  const int64_t idx[3] = {i0, i1, i2};
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    atomicAdd(v_nrm + idx[k] * 3, nx); atomicAdd(v_nrm + idx[k] * 3 + 1, ny); atomicAdd(v_nrm + idx[k] * 3 + 2, nz);
+  }
+}
+
+__global__ void md_normalize_normals_kernel(float* __restrict__ v_nrm, int64_t V) {
+  const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= V) return;
+  float x = v_nrm[v * 3], y = v_nrm[v * 3 + 1], z = v_nrm[v * 3 + 2];
+  float d = x * x + y * y + z * z;
+  if (!(d > 1e-20f)) { x = 0.f; y = 0.f; z = 1.f; d = 1.f; }
+  const float len = sqrtf(fmaxf(d, 1e-20f));
+  v_nrm[v * 3] = x / len; v_nrm[v * 3 + 1] = y / len; v_nrm[v * 3 + 2] = z / len;
+}
+
+extern "C" int md_vertex_normals(const float* verts, const int64_t* faces, int64_t n_verts, int64_t n_faces, float* v_nrm,
+                                 float* f_nrm, void* stream) {
+  if (!verts || !faces || !v_nrm || n_verts <= 0 || n_faces < 0) return MD_ERR_BAD_ARG;
+  hipError_t e = hipMemsetAsync(v_nrm, 0, (size_t)n_verts * 3 * sizeof(float), (hipStream_t)stream);
+  if (e != hipSuccess) return (int)e;
+  MD_HIP_CLEAR_ERROR();
+  if (n_faces > 0)
+    hipLaunchKernelGGL(md_face_normals_kernel, dim3((unsigned)((n_faces + 255) / 256)), dim3(256), 0, (hipStream_t)stream, verts,
+                       faces, n_faces, v_nrm, f_nrm);
+  hipLaunchKernelGGL(md_normalize_normals_kernel, dim3((unsigned)((n_verts + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     v_nrm, n_verts);
+  MD_HIP_CHECK_LAUNCH();
+  return MD_OK;
+}

@@ -143,3 +143,21 @@ class GridMesher:
 
 
 _ = C
+
+
+def auto_normals(verts, faces):
+    """Smooth vertex normals of a mesh (nvdiffrec/lib/render/mesh.py:200-229, the call at nvdiffrec/eval.py:422 on the
+    marching-tets output): returns (v_nrm float32 [V,3], f_nrm float32 [F,3] unnormalised) -- md_vertex_normals."""
+    import ctypes as C
+    from . import _lib
+    lib = _lib.load()
+    if not verts.is_cuda:
+        raise _lib.MeshDiffusionHipError("auto_normals runs on the GPU only")
+    v = verts.to(torch.float32).contiguous()
+    f = faces.to(torch.int64).contiguous()
+    v_nrm = torch.empty_like(v)
+    f_nrm = torch.empty((f.shape[0], 3), dtype=torch.float32, device=v.device)
+    _lib.check(lib.md_vertex_normals(C.c_void_p(v.data_ptr()), C.c_void_p(f.data_ptr()), v.shape[0], f.shape[0],
+                                     C.c_void_p(v_nrm.data_ptr()), C.c_void_p(f_nrm.data_ptr()),
+                                     C.c_void_p(torch.cuda.current_stream().cuda_stream)), "md_vertex_normals")
+    return v_nrm, f_nrm

@@ -21,16 +21,23 @@ import torch
 from .dmtet import GridMesher, tet_vertices_to_grid_index
 
 
-def save_obj(path, verts, faces, decimal_places=None):
-    """verts float [V,3], faces int [F,3] (0-based) -> Wavefront OBJ."""
+def save_obj(path, verts, faces, decimal_places=None, normals=None):
+    """verts float [V,3], faces int [F,3] (0-based) -> Wavefront OBJ.  normals (optional, float [V,3], one per vertex,
+    e.g. dmtet.auto_normals): written as `vn` lines and referenced as `f i//i`."""
     v = torch.as_tensor(verts).detach().cpu().numpy().astype(np.float64)
     f = torch.as_tensor(faces).detach().cpu().numpy().astype(np.int64) + 1
     fmt = "%f" if decimal_places is None else f"%.{int(decimal_places)}f"
     with open(path, "w") as fh:
         for row in v:
             fh.write("v " + " ".join(fmt % c for c in row) + "\n")
-        for row in f:
-            fh.write("f %d %d %d\n" % (row[0], row[1], row[2]))
+        if normals is not None:
+            for row in torch.as_tensor(normals).detach().cpu().numpy().astype(np.float64):
+                fh.write("vn " + " ".join(fmt % c for c in row) + "\n")
+            for row in f:
+                fh.write("f %d//%d %d//%d %d//%d\n" % (row[0], row[0], row[1], row[1], row[2], row[2]))
+        else:
+            for row in f:
+                fh.write("f %d %d %d\n" % (row[0], row[1], row[2]))
 
 
 def load_obj(path):
@@ -43,13 +50,18 @@ def load_obj(path):
                 continue
             if t[0] == "v":
                 vs.append([float(c) for c in t[1:4]])
+            elif t[0] == "vn":
+                continue
             elif t[0] == "f":
                 fs.append([int(c.split("/")[0]) - 1 for c in t[1:4]])
     return np.asarray(vs, np.float32).reshape(-1, 3), np.asarray(fs, np.int64).reshape(-1, 3)
 
 
-def samples_to_obj(samples, tet_vertices, tet_indices, out_dir, resolution=None, batch=32, device="cuda", start_index=0):
-    """samples: array [M,4,R,R,R] (or a path to the sampler's .npy).  Writes {out_dir}/{i:06d}.obj, returns their paths."""
+def samples_to_obj(samples, tet_vertices, tet_indices, out_dir, resolution=None, batch=32, device="cuda", start_index=0,
+                   with_normals=False):
+    """samples: array [M,4,R,R,R] (or a path to the sampler's .npy).  Writes {out_dir}/{i:06d}.obj, returns their paths.
+    with_normals: also write the smooth vertex normals the reference computes right after extraction
+    (eval.py:422 `mesh.auto_normals`; its own OBJ export, eval.py:436-440, drops them)."""
     if isinstance(samples, (str, os.PathLike)):
         samples = np.load(samples)
     samples = np.asarray(samples)
@@ -61,7 +73,11 @@ def samples_to_obj(samples, tet_vertices, tet_indices, out_dir, resolution=None,
         meshes = mesher(torch.from_numpy(samples[lo:lo + batch]))
         for k, (verts, faces, _face_tet) in enumerate(meshes):
             path = os.path.join(out_dir, "{:06d}.obj".format(start_index + lo + k))
-            save_obj(path, verts, faces)
+            nrm = None
+            if with_normals and verts.shape[0] > 0:
+                from .dmtet import auto_normals
+                nrm = auto_normals(verts, faces)[0]
+            save_obj(path, verts, faces, normals=nrm)
             paths.append(path)
     return paths
 
@@ -97,9 +113,10 @@ def main(argv=None):
     ap.add_argument("--tet_path", required=True, help="<R>_tets_cropped.npz (vertices, indices)")
     ap.add_argument("--out", required=True, help="directory for the .obj files")
     ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--normals", action="store_true", help="write smooth vertex normals (vn) next to the positions")
     a = ap.parse_args(argv)
     tet = np.load(a.tet_path)
-    paths = samples_to_obj(a.sample_path, tet["vertices"], tet["indices"], a.out, batch=a.batch)
+    paths = samples_to_obj(a.sample_path, tet["vertices"], tet["indices"], a.out, batch=a.batch, with_normals=a.normals)
     print(f"wrote {len(paths)} meshes to {a.out}")
 
 

@@ -68,3 +68,19 @@ def grid_to_tet_inputs(grid, tet_verts, mesh_scale=2.1, deform_scale=2.0, R=64):
     deform = np.clip(g[1:][:, idx[:, 0], idx[:, 1], idx[:, 2]].T, -1.0, 1.0).astype(np.float32)
     pos = tet_verts * np.float32(mesh_scale) + np.float32(2.0 / (2 * R)) * deform * np.float32(deform_scale)
     return pos.astype(np.float32), sdf
+
+
+def auto_normals(verts, faces):
+    """nvdiffrec/lib/render/mesh.py:200-229 (`auto_normals`) with util.dot / util.safe_normalize (util.py:20-35):
+    returns (v_nrm [V,3] float32, f_nrm [F,3] float32).  Sums in face order like torch.scatter_add_ on the CPU."""
+    v = np.asarray(verts, np.float32)
+    f = np.asarray(faces, np.int64)
+    v0, v1, v2 = v[f[:, 0]], v[f[:, 1]], v[f[:, 2]]
+    f_nrm = np.cross(v1 - v0, v2 - v0).astype(np.float32)
+    v_nrm = np.zeros_like(v)
+    for k in range(3):
+        np.add.at(v_nrm, f[:, k], f_nrm)
+    d = np.sum(v_nrm * v_nrm, -1, keepdims=True)
+    v_nrm = np.where(d > 1e-20, v_nrm, np.array([0.0, 0.0, 1.0], np.float32))
+    d = np.sum(v_nrm * v_nrm, -1, keepdims=True)
+    return (v_nrm / np.sqrt(np.maximum(d, 1e-20))).astype(np.float32), f_nrm

@@ -388,6 +388,29 @@ def dmtet_cases(verts, seed=0):
     return pos, cases
 
 
+def ref_auto_normals():
+    """The reference's `auto_normals` (nvdiffrec/lib/render/mesh.py:200-229) as a callable (verts, faces) -> (v_nrm, f_nrm):
+    its function body is compiled from the file where it lies (the module itself imports the renderer) and run against the
+    real `util` module (nvdiffrast / imageio stubbed: neither is touched by dot / safe_normalize)."""
+    import ast
+    import importlib.util
+    for name in ("nvdiffrast", "nvdiffrast.torch", "imageio"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    spec = importlib.util.spec_from_file_location("ref_render_util", os.path.join(REF, "nvdiffrec/lib/render/util.py"))
+    util = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(util)
+    tree = ast.parse(open(os.path.join(REF, "nvdiffrec/lib/render/mesh.py")).read())
+    fn = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "auto_normals"][0]
+    ns = {"torch": torch, "util": util, "Mesh": lambda *a, **k: types.SimpleNamespace(**k)}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), "mesh.py:auto_normals", "exec"), ns)
+
+    def call(verts, faces):
+        with _CudaToCpu():
+            m = ns["auto_normals"](types.SimpleNamespace(v_pos=verts, t_pos_idx=faces))
+        return m.v_nrm, m.f_nrm
+    return call
+
+
 def gen_dmtet():
     src = os.path.join(REF, "nvdiffrec/data/tets/64_tets_cropped.npz")
     shutil.copyfile(src, os.path.join(GOLD, "64_tets_cropped.npz"))
@@ -399,6 +422,7 @@ def gen_dmtet():
     assert torch.equal(grid_mask_from_tets(verts, 64), ref_mask.view(64, 64, 64)), "grid mask mismatch"
     print("[dmtet] grid_mask_from_tets == data/grid_mask_64.pt ; live cells", int(ref_mask.sum()))
     mod = import_ref_dmtet()
+    normals_ref = ref_auto_normals()
     pos, cases = dmtet_cases(verts)
     tets_t = torch.as_tensor(idx, dtype=torch.long)
     out = {}
@@ -418,6 +442,12 @@ def gen_dmtet():
             out[f"{name}_verts_sha"] = sha(v.numpy().astype(np.float32))
             out[f"{name}_uv_idx_sha"] = sha(uv_idx.numpy().astype(np.int64))
             out[f"{name}_vvi_sha"] = sha(vvi.numpy().astype(np.int64))
+            vn_ref, fn_ref = normals_ref(v, f)
+            vn_or, fn_or = dmtet_oracle.auto_normals(v.numpy(), f.numpy())
+            # (torch.cross contracts a1*b2 - a2*b1 into an fma on this host, numpy does not: 1 ulp, not bit-equal)
+            assert rel_l2(fn_or, fn_ref) < 1e-6 and np.abs(vn_or - vn_ref.numpy()).max() < 1e-6, name
+            out[f"{name}_vnrm_head"], out[f"{name}_vnrm_sum"] = vn_ref.numpy()[:256], vn_ref.double().sum(0).numpy()
+            out[f"{name}_fnrm_head"], out[f"{name}_fnrm_sum"] = fn_ref.numpy()[:256], fn_ref.double().sum(0).numpy()
             out[f"{name}_uvs_sha"] = sha(uvs.numpy().astype(np.float32))
             out[f"{name}_ftet_sha"] = sha(ftet.numpy().astype(np.int64))
             out[f"{name}_uvs_shape"] = np.array(uvs.shape)

@@ -41,6 +41,18 @@ def test_dmtet_bit_exact_vs_reference_golden(hip_lib, tet):
         assert uvs.dtype == torch.float32 and tuple(uvs.shape) == tuple(gold[f"{name}_uvs_shape"]), name
         assert _sha(uvs.cpu().numpy()) == str(gold[f"{name}_uvs_sha"]), f"{name}: uvs differ"
         assert ftet.dtype == torch.int64 and _sha(ftet.cpu().numpy()) == str(gold[f"{name}_ftet_sha"]), f"{name}: face_to_valid_tet differs"
+        # smooth vertex normals (mesh.py:200-229 `auto_normals`): face normals equal to the reference up to fma contraction (1 ulp), vertex normals up
+        # to the summation order of the splat (float atomics here, sequential scatter_add in the reference on the CPU)
+        from meshdiffusion_amd.dmtet import auto_normals
+        from oracle import dmtet_oracle
+        vn, fnrm = auto_normals(v, f)
+        fh = gold[f"{name}_fnrm_head"]
+        assert np.abs(fnrm.cpu().numpy()[:256] - fh).max() <= 1e-6 * np.abs(fh).max(), f"{name}: face normals differ"
+        assert np.abs(fnrm.double().sum(0).cpu().numpy() - gold[f"{name}_fnrm_sum"]).max() < 1e-6 * max(1.0, np.abs(gold[f"{name}_fnrm_sum"]).max())
+        assert np.abs(vn.cpu().numpy()[:256] - gold[f"{name}_vnrm_head"]).max() < 2e-6
+        assert np.abs(vn.double().sum(0).cpu().numpy() - gold[f"{name}_vnrm_sum"]).max() < 1e-3
+        vn_or, _ = dmtet_oracle.auto_normals(v.cpu().numpy(), f.cpu().numpy())
+        assert np.abs(vn.cpu().numpy() - vn_or).max() < 2e-6 and np.abs(np.linalg.norm(vn.cpu().numpy(), axis=1) - 1).max() < 1e-5
 
 
 def test_dmtet_batch32_vs_oracle(hip_lib, tet):
