@@ -84,3 +84,17 @@ def auto_normals(verts, faces):
     v_nrm = np.where(d > 1e-20, v_nrm, np.array([0.0, 0.0, 1.0], np.float32))
     d = np.sum(v_nrm * v_nrm, -1, keepdims=True)
     return (v_nrm / np.sqrt(np.maximum(d, 1e-20))).astype(np.float32), f_nrm
+
+
+def well_conditioned_normals(verts, faces, rel=1e-3):
+    """Mask [V] of the vertices whose normal is numerically meaningful: the splatted face normals do not cancel (length of
+    their sum > rel * the sum of their lengths).  At the others (a handful on noisy SDFs) the direction is decided by the
+    last bit of the summation order, so implementations with a different order (float atomics, fma) legitimately differ."""
+    v = np.asarray(verts, np.float32)
+    f = np.asarray(faces, np.int64)
+    fn = np.cross(v[f[:, 1]] - v[f[:, 0]], v[f[:, 2]] - v[f[:, 0]]).astype(np.float64)
+    s, a = np.zeros((v.shape[0], 3)), np.zeros(v.shape[0])
+    for k in range(3):
+        np.add.at(s, f[:, k], fn)
+        np.add.at(a, f[:, k], np.linalg.norm(fn, axis=1))
+    return np.linalg.norm(s, axis=1) > rel * np.maximum(a, 1e-30)
