@@ -52,7 +52,9 @@ __device__ __forceinline__ int slot_of(int hz, int hy, int hx) {
 // MFMAs cover the ds_write latency) instead of right before the barrier.
 // BF = 1 (MD_B_F32B_GN): the B operand is read as fp32 (F32B, up to two channel-concatenated parts) and GroupNorm affine
 // + SiLU + the bf16 hi/lo split are applied while the halo tile is staged: one thread = one 8-channel group (kg = tid / 128,
-// wave-uniform) x 5 halo positions; the transform runs half an item per tap at taps 16-25 of the chunk before, between MFMAs.
+// wave-uniform) x 5 halo positions; the transform runs half an item per tap at taps 16-25 of the chunk before, between MFMAs
+// (measured alternatives: a whole item per tap over 5 taps = same cost; the two waves of a SIMD taking turns, waves 0-3 at
+// taps 16-20 and waves 4-7 at taps 21-25 = 2 % slower).
 template <int ABL, int PREC, int VAR = 0, int BF = 0>
 __global__ __launch_bounds__(NTHREADS) void md_conv3_main_kernel(const MdGemmConvArgs A) {
   constexpr int PL = (PREC == MD_PREC_FP16X2) ? 1 : 2;        // activation planes staged in LDS
