@@ -144,7 +144,7 @@ def main():
         wall = time.perf_counter() - t0
         assert bool(torch.isfinite(xm).all()), "non-finite samples"
         # ---- second, UNTIMED pass of the same steps with HIP events around every GEMM / conv launch ----
-        events = None
+        events = events_unfused = None
         if not a.no_kernel_events:
             hip_ops.PROFILE = []
             t1 = time.perf_counter()
@@ -153,6 +153,19 @@ def main():
             torch.cuda.synchronize()
             wall_prof = (time.perf_counter() - t1) / min(a.steps, 5)
             events, hip_ops.PROFILE = hip_ops.PROFILE, None
+            # the same kernel WITHOUT the fused GroupNorm/SiLU/split operand transform (two-pass path), 2 steps: shows what
+            # the fusion costs inside the kernel (the step as a whole gains: see DESIGN.md section 4)
+            if hip_ops.FUSE_GN_APPLY and a.precision == "bf16x3":
+                hip_ops.FUSE_GN_APPLY = False
+                x2, _ = run.step(model_fn, x, it)                     # builds nothing new: same packed weights
+                hip_ops.PROFILE = []
+                t1 = time.perf_counter()
+                for _ in range(2):
+                    x2, _ = run.step(model_fn, x2, it)
+                torch.cuda.synchronize()
+                wall_unfused = (time.perf_counter() - t1) / 2
+                events_unfused, hip_ops.PROFILE = hip_ops.PROFILE, None
+                hip_ops.FUSE_GN_APPLY = True
 
     # ---- optional second measurement: the opt-in fp16x2 arithmetic on the same workload ----
     fast = None
@@ -194,6 +207,14 @@ def main():
         value = sample_steps / wall
         ms_per_step = wall / a.steps * 1e3
         roof = roofline(events, hip_ops, a, B, wall_prof) if events else None
+        if roof and events_unfused:
+            mu = [(f, s.elapsed_time(e) * 1e-3) for (c, f, s, e, _, _) in events_unfused if c == hip_ops.CFG_C3_128_FAST]
+            au = sum(f for f, _ in mu) / sum(t for _, t in mu) / 1e12
+            roof["two_pass_build"] = {"kernel": "md_conv3_main_kernel<0,0,0,0> (S16B operand, GroupNorm-apply as its own pass)",
+                                      "achieved": round(au, 2), "frac": round(au / PEAK_BF16_TFLOPS, 4),
+                                      "avg_launch_ms": round(sum(t for _, t in mu) / len(mu) * 1e3, 4),
+                                      "ms_per_step_instrumented": round(wall_unfused * 1e3, 2),
+                                      "ms_per_step_instrumented_fused": round(wall_prof * 1e3, 2)}
         step_flops = B * FLOPS_PER_SAMPLE_STEP
         step_bytes = B * ACT_BYTES_PER_SAMPLE_STEP + WEIGHT_BYTES_PER_STEP
         whole = {"mfma_frac_step": round(step_flops / (wall / a.steps) / (PEAK_BF16_TFLOPS * 1e12), 4),
@@ -266,7 +287,10 @@ def roofline(events, hip_ops, a, B, wall_prof):
             traffic_src = f"profiles/conv_traffic.json has no entry for kernel build {key} (batch {B}, {a.precision}): re-profile"
     except OSError:
         traffic_src = "profiles/conv_traffic.json missing"
-    return {"bound": "mfma", "kernel": "md_conv3_main_kernel<0,0> (3x3x3 conv, implicit GEMM, bf16x3 MFMA)",
+    fused = bool(hip_ops.FUSE_GN_APPLY and a.precision == "bf16x3")
+    return {"bound": "mfma", "kernel": ("md_conv3_main_kernel<0,0,0,1> (3x3x3 conv, implicit GEMM, bf16x3 MFMA; fp32 operand with GroupNorm "
+                                        "affine + SiLU + bf16 split applied in the halo loader)" if fused else
+                                        "md_conv3_main_kernel<0,0,0,0> (3x3x3 conv, implicit GEMM, bf16x3 MFMA)"),
             "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
             "frac": round(ach / PEAK_BF16_TFLOPS, 4),
             # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for
