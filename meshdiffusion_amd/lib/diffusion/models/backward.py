@@ -168,10 +168,12 @@ def dgrad_weight(layer, name, conv, cfg):
 
 
 def conv3_backward(layer, name, conv, dy, act_s16, B, S_out, ups=0, stride=1, need_dx=True, act_channels=None,
-                   bias_sums=None):
+                   bias_sums=None, shared=None):
     """Backward of y = conv k^3 (act) (+bias), k = 3 (any layer) or 5 (stem / head of ddpm_res128, stride 1).
     dy: F32B [B][co][S_out^3]; act_s16: S16B input operand of the forward (coarse grid when ups, fine grid 2*S_out
-    when stride 2).  Returns dx (F32B) or None."""
+    when stride 2).  Returns dx (F32B) or None.
+    shared: dict cache of tensors derived from `dy` (its PB16 operand, its S16B split) when another layer consumes the same
+    gradient (the ResnetBlock's Conv_1 and shortcut NIN_0 both start from the block's output gradient)."""
     from . import layers
     co, ci, ksz = conv.weight.shape[0], conv.weight.shape[1], conv.weight.shape[-1]
     taps, pad = ksz ** 3, ksz // 2
@@ -187,6 +189,10 @@ def conv3_backward(layer, name, conv, dy, act_s16, B, S_out, ups=0, stride=1, ne
     S_fine = S_out * stride
     if stride == 2:
         dy_pb = to_pb16(dy, B, co_t, S_fine, 0, stuff=1, zhalo=False)
+    elif shared is not None and pad == 1:
+        dy_pb = shared.get("dy_pb")
+        if dy_pb is None:
+            dy_pb = shared["dy_pb"] = to_pb16(dy, B, co_t, S_out, 0, pad=pad, zhalo=False)
     else:
         dy_pb = to_pb16(dy, B, co_t, S_out, 0, pad=pad, zhalo=False)
     c_src = act_channels if act_channels is not None else ci      # channels of the S16B operand tensor
@@ -215,7 +221,13 @@ def conv3_backward(layer, name, conv, dy, act_s16, B, S_out, ups=0, stride=1, ne
         dy16 = torch.zeros((B, 2, P, 8), dtype=torch.float32, device=dev)
         dy16[:, :dy.shape[1]] = dy
         dyc, co_k = dy16, 16
-    dx = layers.run_conv3(pw, split_f32b(dyc, B, co_k if cfg == k16 else co_t, P), B, S_out)
+    if shared is not None and dyc is dy:
+        dy16 = shared.get("dy_s16")
+        if dy16 is None:
+            dy16 = shared["dy_s16"] = split_f32b(dyc, B, co_t, P)
+    else:
+        dy16 = split_f32b(dyc, B, co_k if cfg == k16 else co_t, P)
+    dx = layers.run_conv3(pw, dy16, B, S_out)
     if ups:
         dx = resample(dx, B, ci, S_out // 2, 0)
     return dx
@@ -253,20 +265,31 @@ def wgrad_nin(dy_pb, xs_s16, B, co, ci, S, dw):
     wgrad(dy_pb, x_pb, B, co, ci, S, 1, dw, 1, co, 0)
 
 
-def nin_backward(nin, dy, xs_s16, B, P, S, need_dx=True, with_bias=True):
-    """Backward of y[co] = sum_ci x[ci] W[ci][co] + b.  xs_s16: S16B of the forward input."""
+def nin_backward(nin, dy, xs_s16, B, P, S, need_dx=True, with_bias=True, bias_sums=None, shared=None):
+    """Backward of y[co] = sum_ci x[ci] W[ci][co] + b.  xs_s16: S16B of the forward input.
+    bias_sums / shared: per-(sample, channel) sums and dy-derived operands already computed for another consumer of `dy`."""
     from . import layers
     ci, co = nin.W.shape
     if with_bias:
-        _grad_of(nin.b).add_(channel_sums(dy, B, co, P).sum(0))
-    dy_pb = to_pb16(dy, B, co, S, 0, zhalo=False)
+        bs = bias_sums if bias_sums is not None else channel_sums(dy, B, co, P)
+        _grad_of(nin.b).add_(bs.sum(0)[:co])
+    dy_pb = shared.get("dy_pb") if shared is not None else None
+    if dy_pb is None:
+        dy_pb = to_pb16(dy, B, co, S, 0, zhalo=False)
+        if shared is not None:
+            shared["dy_pb"] = dy_pb
     wgrad_nin(dy_pb, xs_s16, B, co, ci, S, _grad_of(nin.W))
     del dy_pb
     if not need_dx:
         return None
     cfg = ops.gemm_cfg_for(P, ci)
     pw = nin._cached(f"dgrad{cfg}", [nin.W], lambda: ops.PackedWeight(nin.W, "rows", cfg, nin.W.device))
-    return layers.run_gemm(pw, split_f32b(dy, B, co, P), B, P)
+    dy16 = shared.get("dy_s16") if shared is not None else None
+    if dy16 is None:
+        dy16 = split_f32b(dy, B, co, P)
+        if shared is not None:
+            shared["dy_s16"] = dy16
+    return layers.run_gemm(pw, dy16, B, P)
 
 
 def attn_backward(blk, sv, dy):

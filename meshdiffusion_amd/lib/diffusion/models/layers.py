@@ -422,7 +422,11 @@ class ResnetBlockDDPM(HipLayer):
         Conv_0/Conv_1/GroupNorm_0/GroupNorm_1/NIN_0 (Dense_0 is handled by the caller from dbias0)."""
         from . import backward as bw
         B, P, S, parts = sv["B"], sv["P"], sv["S"], sv["parts"]
-        d_a1 = bw.conv3_backward(self, "w1", self.Conv_1, dy, sv["a1"], B, S)
+        # Conv_1 and the shortcut NIN_0 both start from the block's output gradient: its channel sums (both biases), its PB16
+        # operand (both weight gradients) and its bf16 split (both data gradients) are computed once
+        shared = {} if self.in_ch != self.out_ch else None
+        bsum = bw.channel_sums(dy, B, self.out_ch, P)
+        d_a1 = bw.conv3_backward(self, "w1", self.Conv_1, dy, sv["a1"], B, S, bias_sums=bsum, shared=shared)
         dbias0 = torch.zeros((B, self.out_ch), dtype=torch.float32, device=dy.device)
         d_h = bw.gn_backward([(sv["h"], self.out_ch)], d_a1, sv["prm1"], self.GroupNorm_1, B, P, silu=True,
                              drop=sv.get("drop"), sums_out=dbias0)[0]     # d(bias0) = channel sums of d_h, same pass
@@ -431,7 +435,8 @@ class ResnetBlockDDPM(HipLayer):
         d_a0 = bw.conv3_backward(self, "w0", self.Conv_0, d_h, sv["a0"], B, S, bias_sums=False)
         del d_h
         if self.in_ch != self.out_ch:
-            d_xcat = bw.nin_backward(self.NIN_0, dy, sv["xs"], B, P, S)
+            d_xcat = bw.nin_backward(self.NIN_0, dy, sv["xs"], B, P, S, bias_sums=bsum, shared=shared)
+            shared.clear()
             dparts = bw.gn_backward(parts, d_a0, sv["prm0"], self.GroupNorm_0, B, P, silu=True)
             off, outs = 0, []
             for (t, c), g in zip(parts, dparts):
