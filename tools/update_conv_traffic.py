@@ -41,7 +41,7 @@ def main():
     except OSError:
         tr = {}
     key = bench.conv_source_key()
-    tr[key] = {"kernel": "md_conv3_main_kernel<0,0>", "hbm_bytes_per_launch": round(nbytes), "batch": a.batch,
+    tr[key] = {"kernel": "md_conv3_main_kernel<0,0,0,1> (the build bench.py runs by default)", "hbm_bytes_per_launch": round(nbytes), "batch": a.batch,
                "fetch_size_kib": fetch_kib, "write_size_kib": write_kib,
                "formula": "(2*FETCH_SIZE + WRITE_SIZE) KiB, mean over the launches of `python bench.py`",
                "source": f"{os.path.relpath(a.fetch, ROOT)} + {os.path.relpath(a.write, ROOT)}"}
