@@ -109,3 +109,29 @@ def test_npy_samples_to_obj_files(hip_lib, tmp_path):
         assert np.abs(v2 - v.cpu().numpy()).max() < 1e-5          # %f keeps 6 decimals
     mesh_export.main(["--sample_path", str(npy), "--tet_path", os.path.join(GOLD, "64_tets_cropped.npz"), "--out", str(tmp_path / "cli")])
     assert len(os.listdir(tmp_path / "cli")) == 3
+
+
+def test_dmtet_degenerate_sdfs_vs_oracle(hip_lib, tet):
+    """Edge cases of the extraction: no crossing at all (all-positive / all-negative SDF: the reference returns empty
+    verts / faces / uv_idx / face_to_valid_tet / valid_vert_idx and the full uv table) and a single inside vertex."""
+    from meshdiffusion_amd.dmtet import DMTet, auto_normals
+    from oracle import dmtet_oracle
+    from oracle.gen_golden import dmtet_cases
+    verts, idx = tet
+    pos, _ = dmtet_cases(verts)
+    tets_t = torch.as_tensor(idx, dtype=torch.long).cuda()
+    n = len(verts)
+    dm = DMTet()
+    for name, sdf in (("all_pos", torch.ones(n)), ("all_neg", -torch.ones(n)),
+                      ("one_vertex", torch.where(torch.arange(n) == 12345, torch.ones(()), -torch.ones(())))):
+        v, f, uvs, uv_idx, ftet, vvi = dm(pos.cuda(), sdf.cuda(), tets_t)
+        vo, fo, fto = dmtet_oracle.marching_tets(pos.numpy(), sdf.numpy(), idx)
+        assert tuple(v.shape) == vo.shape and tuple(f.shape) == fo.shape and f.dtype == torch.int64, name
+        assert np.array_equal(f.cpu().numpy(), fo) and np.array_equal(v.cpu().numpy(), vo) and np.array_equal(ftet.cpu().numpy(), fto), name
+        assert tuple(uv_idx.shape) == (fo.shape[0], 3) and uvs.shape[1] == 2 and uvs.shape[0] > 0, name
+        if name == "one_vertex":
+            assert (v.shape[0], f.shape[0], vvi.shape[0]) == (14, 24, 15)        # what the unmodified reference returns
+            vn, _ = auto_normals(v, f)
+            assert bool(torch.isfinite(vn).all())
+        else:
+            assert v.shape[0] == 0 and f.shape[0] == 0 and vvi.numel() == 0 and ftet.numel() == 0

@@ -317,3 +317,35 @@ def test_config1_res64_10_steps_vs_reference_golden(env):
     e_sum = float((np.abs(mine["sums"] - gold["sums"]) / mine["l1"]).max())
     print(f"config #1 (res64, 10 steps) vs reference: live cells {e_live:.3e} row {e_row:.3e} norm {e_norm:.3e} sums {e_sum:.3e}")
     assert e_live < TOL_SAMPLE and e_row < TOL_SAMPLE and e_norm < TOL_SAMPLE and e_sum < TOL_SAMPLE
+
+
+def test_odd_batch_sampler_and_fused_attention(env):
+    """A batch that is no multiple of anything (B = 3): 4 ancestral steps of the small model vs the oracle, and the fused
+    attention kernel (its sample-to-XCD mapping is `block % batch`) at C = 256, N = 512 vs the oracle."""
+    from meshdiffusion_amd.lib.diffusion import sampling, sde_lib
+    cfg, model, sd = _small_model(env)
+    R, B = cfg.data.image_size, 3
+    synth, uo = env["synth"], env["uo"]
+    sde = sde_lib.VPSDE(cfg.model.beta_min, cfg.model.beta_max, cfg.model.num_scales, device="cuda")
+    mask = synth.synthetic_grid_mask(R).view(1, R, R, R)
+    st = sampling.AncestralStepper(sde, (B, 4, R, R, R), device="cuda", grid_mask=mask.cuda())
+    fn = env["mutils"].get_model_fn(model, train=False)
+    x = (synth.synthetic_inputs(B, 4, R, seed=21) * mask).cuda()
+    xo = x.cpu()
+    g = torch.Generator().manual_seed(22)
+    ts = torch.linspace(1.0, 1e-3, 1000)
+    with torch.no_grad():
+        for i in range(4):
+            z = torch.randn((B, 4, R, R, R), generator=g)
+            x, xm = st.step(fn, x, i, draw=lambda _t: z.cuda())
+            e = uo.unet_res64_forward(sd, synth.oracle_cfg(cfg), xo, torch.ones(B) * ts[i] * 999)
+            xo, xmo = uo.ancestral_step(xo, e, z, ts[i], mask)
+    assert rel_l2(xm.cpu(), xmo) < TOL_EVAL
+    blk = env["layers"].AttnBlock(channels=256)
+    sda = _layer_sd(blk, 4)
+    blk.load_state_dict(sda); blk = blk.cuda().eval()
+    xa = _randn((B, 256, 8, 8, 8), 6)
+    with torch.no_grad():
+        y = blk(xa.cuda()).cpu()
+        ref = uo.attn_block(sda, xa)
+    assert rel_l2(y - xa, ref - xa) < 5e-4
