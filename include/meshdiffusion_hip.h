@@ -57,9 +57,9 @@ enum {
   MD_CFG_C3_128_V2 = 8,  /* C3_128 + conflict-free halo layout + software-pipelined loads     */
   MD_CFG_C3_128_SW = 9,  /* (A/B) conflict-free halo layout only                              */
   MD_CFG_C3_128_PIPE = 10, /* (A/B) pipelined loads only                                       */
-  MD_CFG_C3_128_V3 = 11, /* weights L2->registers (no LDS weight tiles, no per-tap barrier), 4x2 waves */
-  MD_CFG_C3_128_V3B = 12, /* same, 2x4 wave grid                                              */
-  MD_CFG_C3_128_V4 = 13, /* C3_128_V2 with the barrier between the two K=16 half-steps (LDS latency hidden) */
+  MD_CFG_C3_128_V3 = 11, /* retired r01 experiment (weights L2->registers): MD_ERR_UNSUPPORTED                */
+  MD_CFG_C3_128_V3B = 12, /* retired                                                         */
+  MD_CFG_C3_128_V4 = 13, /* retired (its mid-step barrier lives on in MD_CFG_C3_128_FAST)                    */
   MD_CFG_C3_128_FAST = 14, /* dedicated kernel for the hot conv: C3_128_V2 layout, taps unrolled, F32B out */
   MD_CFG_C5_128_K16 = 15, /* 5x5x5 s1 pad 2, tile 4x8x8, NT=128, KC=16 (ddpm_res128 stem / mask_layer)  */
   MD_CFG_C5_32_K16 = 16,  /* 5x5x5 s1 pad 2, tile 4x8x8, NT=32,  KC=16 (ddpm_res128 head)               */

@@ -53,7 +53,7 @@ struct GCfg {
   static constexpr int A_ITEMS = KG * 2 * HPOS;  // uint4 items loaded per activation halo tile
   static constexpr int W_PER_THREAD = (W_ITEMS + NTHREADS - 1) / NTHREADS;
   static constexpr int A_PER_THREAD = (A_ITEMS + NTHREADS - 1) / NTHREADS;
-  static constexpr int W_LDS_ITEMS = (PIPE_ == 2) ? 0 : 2 * W_ITEMS;  // PIPE=2 keeps weights out of LDS
+  static constexpr int W_LDS_ITEMS = 2 * W_ITEMS;
   static constexpr int LDS_ITEMS = W_LDS_ITEMS + KG * 2 * HS;
   static constexpr int LDS_BYTES = LDS_ITEMS * 16;
   static constexpr int PADLO = (STRIDE == 2) ? 0 : (KSZ - 1) / 2;  // 'same' padding; Downsample pads (0,1)
@@ -334,139 +334,6 @@ __global__ __launch_bounds__(C::NTHREADS) void md_gemm_conv_kernel(const MdGemmC
       compute(buf, dz, dy, dx);
       cc = ncc_; tap = ntap; dz = ndz; dy = ndy; dx = ndx;
     }
-  } else if constexpr (C::PIPE == 3) {
-    // Mid-step barrier pipeline (KC = 32 = two K=16 half-steps per tap).  Fragment set F0 serves the
-    // first half-step, F1 the second.  The single barrier of a step sits BETWEEN the two MFMA groups:
-    //   read F1(s)  | MFMA F0(s) | commit W(s+1), request W(s+2) | barrier | read F0(s+1) | MFMA F1(s)
-    // so every LDS read is issued one MFMA group (12 MFMAs ~ 400-800 cycles) before its first use and
-    // no LDS latency is exposed behind the barrier.
-    static_assert(C::KC == 32, "PIPE=3 needs two K=16 half-steps per step");
-    struct Frags { bf16x8 ahi[C::RM], alo[C::RM], bhi[C::CM], blo[C::CM]; };
-    Frags F0, F1;
-    auto load_frags = [&](Frags& F, int buf, int ks, int dz_, int dy_, int dx_) {
-      const bf16x8* wb = wlf + buf * C::W_ITEMS;
-      const int g = ks * 2 + h;
-#pragma unroll
-      for (int rm = 0; rm < C::RM; ++rm) {
-        F.ahi[rm] = wb[(g * 2 + 0) * C::NT + a_row[rm]];
-        F.alo[rm] = wb[(g * 2 + 1) * C::NT + a_row[rm]];
-      }
-#pragma unroll
-      for (int cm = 0; cm < C::CM; ++cm) {
-        const int bs = C::slot_of(bz[cm] + dz_, by[cm] + dy_, bx[cm] + dx_);
-        F.bhi[cm] = alf[(g * 2 + 0) * C::HS + bs];
-        F.blo[cm] = alf[(g * 2 + 1) * C::HS + bs];
-      }
-    };
-    auto mma = [&](const Frags& F) {
-#pragma unroll
-      for (int rm = 0; rm < C::RM; ++rm)
-#pragma unroll
-        for (int cm = 0; cm < C::CM; ++cm) {
-          acc[rm][cm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.alo[rm], F.bhi[cm], acc[rm][cm], 0, 0, 0);
-          acc[rm][cm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.ahi[rm], F.blo[cm], acc[rm][cm], 0, 0, 0);
-          acc[rm][cm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.ahi[rm], F.bhi[cm], acc[rm][cm], 0, 0, 0);
-        }
-    };
-    constexpr int PF = (C::TAPS >= 3) ? C::TAPS - 3 : 0;
-    int c1 = 0, t1 = 0, z1 = 0, y1 = 0, x1 = 0;  // coordinates of step s+2 (for w_issue)
-    w_issue(0, 0);
-    act_issue(0);
-    act_commit();
-    w_commit(0);
-    advance(c1, t1, z1, y1, x1);
-    if (nsteps > 1) w_issue(c1, t1);
-    advance(c1, t1, z1, y1, x1);
-    __syncthreads();
-    load_frags(F0, 0, 0, 0, 0, 0);
-    for (int s = 0; s < nsteps; ++s) {
-      load_frags(F1, s & 1, 1, dz, dy, dx);
-      mma(F0);
-      if (s + 1 < nsteps) w_commit((s + 1) & 1);
-      if (s + 2 < nsteps) w_issue(c1, t1);
-      advance(c1, t1, z1, y1, x1);
-      const bool more = cc + 1 < ncc;
-      if (tap == PF && more) act_issue(cc + 1);
-      if (tap == C::TAPS - 1 && more) {
-        __syncthreads();  // every wave has finished reading this chunk's halo tile
-        act_commit();
-      }
-      __syncthreads();
-      advance(cc, tap, dz, dy, dx);
-      if (s + 1 < nsteps) load_frags(F0, (s + 1) & 1, 0, dz, dy, dx);
-      mma(F1);
-    }
-  } else if constexpr (C::PIPE == 2) {
-    // Weight fragments go L2 -> registers directly (the WPK tile is already in fragment order: lanes
-    // 0-31 / 32-63 each read 512 contiguous bytes), one step ahead of their use; only the activation
-    // halo tile lives in LDS.  No per-tap barrier: wavefronts free-run through the 27 taps of a K chunk
-    // and meet only when the halo tile is swapped, so the two wavefronts of a SIMD drift out of phase
-    // and keep the matrix pipe fed while the partner waits on LDS.
-    constexpr int KS = C::KC / 16;
-    constexpr int PF = (C::TAPS >= 3) ? C::TAPS - 3 : 0;
-    bf16x8 fa0[C::RM][KS][2], fa1[C::RM][KS][2];
-    auto a_issue = [&](bf16x8 (&af)[C::RM][KS][2], int cc_, int tap_) {
-      const bf16x8* tile = (const bf16x8*)(aptr + ((int64_t)(rt * ncc_total + cc_lo + cc_) * C::TAPS + tap_) * C::W_ITEMS);
-#pragma unroll
-      for (int rm = 0; rm < C::RM; ++rm)
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-          for (int part = 0; part < 2; ++part)
-            af[rm][ks][part] = tile[((ks * 2 + h) * 2 + part) * C::NT + a_row[rm]];
-    };
-    auto mma = [&](bf16x8 (&af)[C::RM][KS][2], int dz_, int dy_, int dx_) {
-      int bs[C::CM];
-#pragma unroll
-      for (int cm = 0; cm < C::CM; ++cm) bs[cm] = C::slot_of(bz[cm] + dz_, by[cm] + dy_, bx[cm] + dx_);
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        const int g = ks * 2 + h;
-        bf16x8 bhi[C::CM], blo[C::CM];
-#pragma unroll
-        for (int cm = 0; cm < C::CM; ++cm) {
-          bhi[cm] = alf[(g * 2 + 0) * C::HS + bs[cm]];
-          blo[cm] = alf[(g * 2 + 1) * C::HS + bs[cm]];
-        }
-#pragma unroll
-        for (int rm = 0; rm < C::RM; ++rm) {
-#pragma unroll
-          for (int cm = 0; cm < C::CM; ++cm)
-            acc[rm][cm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[rm][ks][1], bhi[cm], acc[rm][cm], 0, 0, 0);
-#pragma unroll
-          for (int cm = 0; cm < C::CM; ++cm)
-            acc[rm][cm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[rm][ks][0], blo[cm], acc[rm][cm], 0, 0, 0);
-#pragma unroll
-          for (int cm = 0; cm < C::CM; ++cm)
-            acc[rm][cm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[rm][ks][0], bhi[cm], acc[rm][cm], 0, 0, 0);
-        }
-      }
-    };
-    int s = 0;
-    auto step = [&](bf16x8 (&use)[C::RM][KS][2], bf16x8 (&nxt)[C::RM][KS][2]) {
-      int ncc_ = cc, ntap = tap, ndz = dz, ndy = dy, ndx = dx;
-      advance(ncc_, ntap, ndz, ndy, ndx);
-      if (s + 1 < nsteps) a_issue(nxt, ncc_, ntap);
-      const bool more = cc + 1 < ncc;
-      if (tap == PF && more) act_issue(cc + 1);
-      mma(use, dz, dy, dx);
-      if (tap == C::TAPS - 1 && more) {
-        __syncthreads();  // everyone finished reading this chunk's halo tile
-        act_commit();
-        __syncthreads();
-      }
-      cc = ncc_; tap = ntap; dz = ndz; dy = ndy; dx = ndx;
-      ++s;
-    };
-    a_issue(fa0, 0, 0);
-    act_issue(0);
-    act_commit();
-    __syncthreads();
-    while (s < nsteps) {
-      step(fa0, fa1);
-      if (s >= nsteps) break;
-      step(fa1, fa0);
-    }
   } else {
     // Software pipeline: W(s+1) is written to LDS and W(s+2) is requested from L2 *inside* step s,
     // the next K-chunk's halo tile is requested 3 taps early into registers, and there is exactly
@@ -583,9 +450,6 @@ using Cfg_C3_128 = GCfg<128, 32, 4, 8, 8, 27, 1, 2, 4>;
 using Cfg_C3_128_V2 = GCfg<128, 32, 4, 8, 8, 27, 1, 2, 4, 1, 1>;
 using Cfg_C3_128_SW = GCfg<128, 32, 4, 8, 8, 27, 1, 2, 4, 1, 0>;
 using Cfg_C3_128_PIPE = GCfg<128, 32, 4, 8, 8, 27, 1, 2, 4, 0, 1>;
-using Cfg_C3_128_V3 = GCfg<128, 32, 4, 8, 8, 27, 1, 4, 2, 1, 2>;   // weights L2->registers, no per-tap barrier
-using Cfg_C3_128_V3B = GCfg<128, 32, 4, 8, 8, 27, 1, 2, 4, 1, 2>;  // same with the 2x4 wave grid
-using Cfg_C3_128_V4 = GCfg<128, 32, 4, 8, 8, 27, 1, 2, 4, 1, 3>;   // mid-step barrier pipeline
 using Cfg_C5_128_K16 = GCfg<128, 16, 4, 8, 8, 125, 1, 2, 4>;  // 5x5x5 stem of ddpm_res128 (Cin<=16)
 using Cfg_C5_32_K16 = GCfg<32, 16, 4, 8, 8, 125, 1, 1, 8>;    // 5x5x5 head of ddpm_res128 (Cout<=32)
 using Cfg_ABL1 = GCfg<128, 32, 4, 8, 8, 27, 1, 2, 4, 1, 1, 1>;
@@ -683,10 +547,9 @@ static int launch_cfg(const MdGemmConvArgs& a, hipStream_t stream) {
         (a.b_split & 7) || a.b_split <= 0 || (a.b_split < a.kdim && a.b2 == nullptr))
       return MD_ERR_UNSUPPORTED;
   }
-  if (C::PIPE == 2 && a.a_src != MD_A_PACKED) return MD_ERR_UNSUPPORTED;
   const int row_tiles = (a.rows + C::NT - 1) / C::NT;
   const int ks = a.ksplit > 1 ? a.ksplit : 1;
-  if (ks > 1 && (a.partial == nullptr || a.out_mode != MD_OUT_F32B || ks > a.kdim / C::KC || C::PIPE == 2)) return MD_ERR_BAD_ARG;
+  if (ks > 1 && (a.partial == nullptr || a.out_mode != MD_OUT_F32B || ks > a.kdim / C::KC)) return MD_ERR_BAD_ARG;
   dim3 grid((unsigned)(tiles * a.batch), (unsigned)row_tiles, (unsigned)ks);
   MD_HIP_CLEAR_ERROR();
   hipLaunchKernelGGL(md_gemm_conv_kernel<C>, grid, dim3(C::NTHREADS), 0, stream, a);
@@ -705,7 +568,7 @@ static void cfg_info(int32_t* nt, int32_t* kc, int32_t* cols, int32_t* taps, int
   if (thr) *thr = C::NTHREADS;
 }
 
-// Production configurations; the A/B baselines of tools/bench_conv.py (V2/SW/PIPE/V3/V3B/V4/W4 and the timing-only ABL
+// Production configurations; the A/B baselines of tools/bench_conv.py (V2/SW/PIPE/W4 and the timing-only ABL
 // variants) are instantiated only with -DMD_BUILD_ABLATIONS (MD_BUILD_ABLATIONS=1 python -m meshdiffusion_amd.build --force).
 #define MD_CFG_CASES_PROD(F, ...)                                   \
     case MD_CFG_C3_128: F<Cfg_C3_128>(__VA_ARGS__); break;          \
@@ -728,9 +591,6 @@ static void cfg_info(int32_t* nt, int32_t* kc, int32_t* cols, int32_t* taps, int
     case MD_CFG_C3_128_V2: F<Cfg_C3_128_V2>(__VA_ARGS__); break;    \
     case MD_CFG_C3_128_SW: F<Cfg_C3_128_SW>(__VA_ARGS__); break;    \
     case MD_CFG_C3_128_PIPE: F<Cfg_C3_128_PIPE>(__VA_ARGS__); break; \
-    case MD_CFG_C3_128_V3: F<Cfg_C3_128_V3>(__VA_ARGS__); break;    \
-    case MD_CFG_C3_128_V3B: F<Cfg_C3_128_V3B>(__VA_ARGS__); break;  \
-    case MD_CFG_C3_128_V4: F<Cfg_C3_128_V4>(__VA_ARGS__); break;    \
     case 101: F<Cfg_ABL1>(__VA_ARGS__); break;                      \
     case 102: F<Cfg_ABL2>(__VA_ARGS__); break;                      \
     case 103: F<Cfg_ABL3>(__VA_ARGS__); break;                      \
