@@ -168,13 +168,14 @@ __global__ __launch_bounds__(C::NTHREADS) void md_gemm_conv_kernel(const MdGemmC
 
   // ---- activation halo tile: global -> registers -> LDS (zero fill outside the grid) ----
   uint4 hreg[C::A_PER_THREAD];
+  uint4 hreg2[C::A_PER_THREAD];   // second staging set of the deep-prefetch GEMM loop (PIPE = 4); unused otherwise
   // MD_B_F32B_GN on a 1x1x1 configuration (the ResnetBlock shortcut NIN_0 reading the raw block input, layers.py:688):
   // one thread = (8-channel group, position) pairs; two fp32 uint4 in, the hi and the lo plane item out.  No affine /
   // SiLU here (b_ac must be NULL): the shortcut takes the un-normalised input.
   const bool bf32 = (C::TAPS == 1) && A.b_mode == MD_B_F32B_GN;
   const uint4* bf_p1 = (const uint4*)A.b + (int64_t)b * (A.b_bstride / 4);
   const uint4* bf_p2 = (const uint4*)A.b2 + (int64_t)b * (A.b2_bstride / 4);
-  auto act_issue_f32 = [&](int cc) {
+  auto act_issue_f32 = [&](auto& hr, int cc) {
     if constexpr (C::TAPS == 1 && (C::A_PER_THREAD % 2) == 0) {
 #pragma unroll
       for (int i = 0; i < C::A_PER_THREAD / 2; ++i) {
@@ -189,24 +190,24 @@ __global__ __launch_bounds__(C::NTHREADS) void md_gemm_conv_kernel(const MdGemmC
         uint32_t hi[4], lo[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) md_split2(v[2 * e], v[2 * e + 1], hi[e], lo[e]);
-        hreg[2 * i] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
-        hreg[2 * i + 1] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+        hr[2 * i] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+        hr[2 * i + 1] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
       }
     }
   };
-  auto act_commit_f32 = [&]() {
+  auto act_commit_f32 = [&](auto& hr) {
     if constexpr (C::TAPS == 1 && (C::A_PER_THREAD % 2) == 0) {
 #pragma unroll
       for (int i = 0; i < C::A_PER_THREAD / 2; ++i) {
         const int q = tid + i * C::NTHREADS;
         const int kg = q / C::HPOS, r = q % C::HPOS;
-        al[(kg * 2) * C::HS + r] = hreg[2 * i];
-        al[(kg * 2 + 1) * C::HS + r] = hreg[2 * i + 1];
+        al[(kg * 2) * C::HS + r] = hr[2 * i];
+        al[(kg * 2 + 1) * C::HS + r] = hr[2 * i + 1];
       }
     }
   };
-  auto act_issue = [&](int cc) {
-    if (bf32) { act_issue_f32(cc); return; }
+  auto act_issue = [&](auto& hr, int cc) {
+    if (bf32) { act_issue_f32(hr, cc); return; }
 #pragma unroll
     for (int i = 0; i < C::A_PER_THREAD; ++i) {
       const int item = tid + i * C::NTHREADS;
@@ -232,11 +233,11 @@ __global__ __launch_bounds__(C::NTHREADS) void md_gemm_conv_kernel(const MdGemmC
         }
         if (inb) v = bptr[((int64_t)((cc_lo + cc) * C::KG + (gp >> 1)) * 2 + (gp & 1)) * Pin + src];
       }
-      hreg[i] = v;
+      hr[i] = v;
     }
   };
-  auto act_commit = [&]() {
-    if (bf32) { act_commit_f32(); return; }
+  auto act_commit = [&](auto& hr) {
+    if (bf32) { act_commit_f32(hr); return; }
 #pragma unroll
     for (int i = 0; i < C::A_PER_THREAD; ++i) {
       const int item = tid + i * C::NTHREADS;
@@ -244,7 +245,7 @@ __global__ __launch_bounds__(C::NTHREADS) void md_gemm_conv_kernel(const MdGemmC
         const int gp = item / C::HPOS, r = item % C::HPOS;
         int slot = r;
         if constexpr (C::TAPS > 1) slot = C::slot_of(r / (C::XH * C::YH), (r / C::XH) % C::YH, r % C::XH);
-        al[gp * C::HS + slot] = hreg[i];
+        al[gp * C::HS + slot] = hr[i];
       }
     }
   };
@@ -322,8 +323,8 @@ __global__ __launch_bounds__(C::NTHREADS) void md_gemm_conv_kernel(const MdGemmC
     for (int s = 0; s < nsteps; ++s) {
       if (tap == 0) {
         __syncthreads();  // everyone finished reading the previous halo tile
-        act_issue(cc);
-        act_commit();
+        act_issue(hreg, cc);
+        act_commit(hreg);
       }
       const int buf = s & 1;
       w_commit(buf);
@@ -334,6 +335,31 @@ __global__ __launch_bounds__(C::NTHREADS) void md_gemm_conv_kernel(const MdGemmC
       compute(buf, dz, dy, dx);
       cc = ncc_; tap = ntap; dz = ndz; dy = ndy; dx = ndx;
     }
+  } else if constexpr (C::PIPE == 4) {
+    // 1x1x1 / GEMM with TWO activation tiles in flight (the HBM-bound launches are limited by bytes in flight per CU, not by
+    // bandwidth): tile s in LDS, tile s+1 in one register set, tile s+2 requested into the other during chunk s.  Even tiles
+    // travel through `hreg`, odd ones through `hreg2`; weights as in the PIPE = 1 loop (one step = one K chunk).
+    static_assert(C::TAPS == 1, "PIPE=4 is the GEMM loop");
+    w_issue(0, 0);
+    act_issue(hreg, 0);
+    act_commit(hreg);
+    w_commit(0);
+    if (ncc > 1) { w_issue(1, 0); act_issue(hreg2, 1); }
+    __syncthreads();
+    auto chunk = [&](auto& next_tile, auto& refill, int s) {
+      if (s + 1 < ncc) w_commit((s + 1) & 1);
+      if (s + 2 < ncc) { w_issue(s + 2, 0); act_issue(refill, s + 2); }
+      compute(s & 1, 0, 0, 0);
+      if (s + 1 < ncc) {
+        __syncthreads();  // everyone finished reading tile s
+        act_commit(next_tile);
+      }
+      __syncthreads();
+    };
+    for (int s = 0; s < ncc; s += 2) {
+      chunk(hreg2, hreg, s);
+      if (s + 1 < ncc) chunk(hreg, hreg2, s + 1);
+    }
   } else {
     // Software pipeline: W(s+1) is written to LDS and W(s+2) is requested from L2 *inside* step s,
     // the next K-chunk's halo tile is requested 3 taps early into registers, and there is exactly
@@ -341,8 +367,8 @@ __global__ __launch_bounds__(C::NTHREADS) void md_gemm_conv_kernel(const MdGemmC
     constexpr int PF = (C::TAPS >= 3) ? C::TAPS - 3 : 0;
     int c1 = 0, t1 = 0, z1 = 0, y1 = 0, x1 = 0;  // coordinates of step s+2 (for w_issue)
     w_issue(0, 0);
-    act_issue(0);
-    act_commit();
+    act_issue(hreg, 0);
+    act_commit(hreg);
     w_commit(0);
     advance(c1, t1, z1, y1, x1);
     if (nsteps > 1) w_issue(c1, t1);
@@ -353,11 +379,11 @@ __global__ __launch_bounds__(C::NTHREADS) void md_gemm_conv_kernel(const MdGemmC
       if (C::ABL != 4 && C::ABL != 5 && s + 2 < nsteps) w_issue(c1, t1);
       advance(c1, t1, z1, y1, x1);
       const bool more = cc + 1 < ncc;
-      if (C::ABL != 5 && tap == PF && more) act_issue(cc + 1);
+      if (C::ABL != 5 && tap == PF && more) act_issue(hreg, cc + 1);
       compute(s & 1, dz, dy, dx);
       if (C::ABL != 5 && tap == C::TAPS - 1 && more) {
         __syncthreads();  // everyone finished reading this chunk's halo tile
-        act_commit();
+        act_commit(hreg);
       }
       if constexpr (C::ABL != 3 && C::ABL != 5) __syncthreads();
       advance(cc, tap, dz, dy, dx);
@@ -470,12 +496,14 @@ using Cfg_C3_LOW = GCfg<128, 32, 4, 4, 4, 27, 1, 4, 2, 0, 1>;   // PIPE=1: weigh
 using Cfg_C3_128_W4 = GCfg<128, 32, 4, 4, 8, 27, 1, 2, 2>;
 using Cfg_C3_S2 = GCfg<128, 32, 4, 4, 4, 27, 2, 4, 2, 0, 1>;
 // PIPE=1: next chunk's weight and activation tiles are requested before the MFMAs of the current one (the 1x1x1 / GEMM
-// launches are HBM-bound: the unpipelined loop left the memory system idle during every compute phase)
-using Cfg_G1_128 = GCfg<128, 32, 1, 1, 256, 1, 1, 2, 4, 0, 1>;
+// launches are HBM-bound: the unpipelined loop left the memory system idle during every compute phase); PIPE=4: two
+// activation tiles ahead
+using Cfg_G1_128 = GCfg<128, 32, 1, 1, 256, 1, 1, 2, 4, 0, 4>;
 using Cfg_G1_128_LOW = GCfg<128, 32, 1, 1, 64, 1, 1, 4, 2, 0, 1>;
 // 128 columns per workgroup (48 KB of LDS: three workgroups per CU): the HBM-bound ResnetBlock shortcut at 64^3 / 32^3 --
 // one workgroup's output burst (64 KB) overlaps the other workgroups' loads
-using Cfg_G1_128_N128 = GCfg<128, 32, 1, 1, 128, 1, 1, 2, 4, 0, 1>;
+using Cfg_G1_128_N128 = GCfg<128, 32, 1, 1, 128, 1, 1, 2, 4, 0, 4>;
+using Cfg_G1_128_N128_P1 = GCfg<128, 32, 1, 1, 128, 1, 1, 2, 4, 0, 1>;   // A/B baseline: one tile ahead
 using Cfg_G1_64_LOW = GCfg<64, 32, 1, 1, 64, 1, 1, 2, 2, 0, 1>;
 
 // ---- split-K finish: out = alpha * sum_z partial[z] + bias + residual (slices added in order) ----
@@ -583,6 +611,7 @@ static void cfg_info(int32_t* nt, int32_t* kc, int32_t* cols, int32_t* taps, int
     case MD_CFG_G1_128: F<Cfg_G1_128>(__VA_ARGS__); break;          \
     case MD_CFG_G1_128_LOW: F<Cfg_G1_128_LOW>(__VA_ARGS__); break;  \
     case MD_CFG_G1_128_N128: F<Cfg_G1_128_N128>(__VA_ARGS__); break; \
+    case 23: F<Cfg_G1_128_N128_P1>(__VA_ARGS__); break;              \
     case MD_CFG_G1_64_LOW: F<Cfg_G1_64_LOW>(__VA_ARGS__); break;    \
     case MD_CFG_C5_128_K16: F<Cfg_C5_128_K16>(__VA_ARGS__); break;  \
     case MD_CFG_C5_32_K16: F<Cfg_C5_32_K16>(__VA_ARGS__); break;
