@@ -23,7 +23,7 @@ CFG_NT_KC = {
     CFG_C3_128: (128, 32), CFG_C3_128_K16: (128, 16), CFG_C3_32: (32, 32), CFG_C3_LOW: (128, 32),
     CFG_C3_S2: (128, 32), CFG_G1_128: (128, 32), CFG_G1_128_LOW: (128, 32), CFG_G1_64_LOW: (64, 32),
     CFG_C3_128_V2: (128, 32), CFG_C3_128_SW: (128, 32), CFG_C3_128_PIPE: (128, 32),
-    CFG_C3_128_FAST: (128, 32), CFG_C5_128_K16: (128, 16), CFG_C5_32_K16: (32, 16), CFG_C3_128_W4: (128, 32), CFG_C3X_32: (32, 32), CFG_C5X_32_K16: (32, 16), CFG_C3X_128_K16: (128, 16), CFG_C5X_128: (128, 32), CFG_G1_128_N128: (128, 32), 23: (128, 32),
+    CFG_C3_128_FAST: (128, 32), CFG_C5_128_K16: (128, 16), CFG_C5_32_K16: (32, 16), CFG_C3_128_W4: (128, 32), CFG_C3X_32: (32, 32), CFG_C5X_32_K16: (32, 16), CFG_C3X_128_K16: (128, 16), CFG_C5X_128: (128, 32), CFG_G1_128_N128: (128, 32),
     101: (128, 32), 102: (128, 32), 103: (128, 32), 104: (128, 32), 105: (128, 32), 111: (128, 32), 113: (128, 32), 114: (128, 32), 116: (128, 32), 117: (128, 32), 118: (128, 32), 122: (128, 32),   # timing-only ablations of C3_128_V2
 }
 

@@ -168,7 +168,6 @@ __global__ __launch_bounds__(C::NTHREADS) void md_gemm_conv_kernel(const MdGemmC
 
   // ---- activation halo tile: global -> registers -> LDS (zero fill outside the grid) ----
   uint4 hreg[C::A_PER_THREAD];
-  uint4 hreg2[C::A_PER_THREAD];   // second staging set of the deep-prefetch GEMM loop (PIPE = 4); unused otherwise
   // MD_B_F32B_GN on a 1x1x1 configuration (the ResnetBlock shortcut NIN_0 reading the raw block input, layers.py:688):
   // one thread = (8-channel group, position) pairs; two fp32 uint4 in, the hi and the lo plane item out.  No affine /
   // SiLU here (b_ac must be NULL): the shortcut takes the un-normalised input.
@@ -335,31 +334,6 @@ __global__ __launch_bounds__(C::NTHREADS) void md_gemm_conv_kernel(const MdGemmC
       compute(buf, dz, dy, dx);
       cc = ncc_; tap = ntap; dz = ndz; dy = ndy; dx = ndx;
     }
-  } else if constexpr (C::PIPE == 4) {
-    // 1x1x1 / GEMM with TWO activation tiles in flight (the HBM-bound launches are limited by bytes in flight per CU, not by
-    // bandwidth): tile s in LDS, tile s+1 in one register set, tile s+2 requested into the other during chunk s.  Even tiles
-    // travel through `hreg`, odd ones through `hreg2`; weights as in the PIPE = 1 loop (one step = one K chunk).
-    static_assert(C::TAPS == 1, "PIPE=4 is the GEMM loop");
-    w_issue(0, 0);
-    act_issue(hreg, 0);
-    act_commit(hreg);
-    w_commit(0);
-    if (ncc > 1) { w_issue(1, 0); act_issue(hreg2, 1); }
-    __syncthreads();
-    auto chunk = [&](auto& next_tile, auto& refill, int s) {
-      if (s + 1 < ncc) w_commit((s + 1) & 1);
-      if (s + 2 < ncc) { w_issue(s + 2, 0); act_issue(refill, s + 2); }
-      compute(s & 1, 0, 0, 0);
-      if (s + 1 < ncc) {
-        __syncthreads();  // everyone finished reading tile s
-        act_commit(next_tile);
-      }
-      __syncthreads();
-    };
-    for (int s = 0; s < ncc; s += 2) {
-      chunk(hreg2, hreg, s);
-      if (s + 1 < ncc) chunk(hreg, hreg2, s + 1);
-    }
   } else {
     // Software pipeline: W(s+1) is written to LDS and W(s+2) is requested from L2 *inside* step s,
     // the next K-chunk's halo tile is requested 3 taps early into registers, and there is exactly
@@ -496,14 +470,13 @@ using Cfg_C3_LOW = GCfg<128, 32, 4, 4, 4, 27, 1, 4, 2, 0, 1>;   // PIPE=1: weigh
 using Cfg_C3_128_W4 = GCfg<128, 32, 4, 4, 8, 27, 1, 2, 2>;
 using Cfg_C3_S2 = GCfg<128, 32, 4, 4, 4, 27, 2, 4, 2, 0, 1>;
 // PIPE=1: next chunk's weight and activation tiles are requested before the MFMAs of the current one (the 1x1x1 / GEMM
-// launches are HBM-bound: the unpipelined loop left the memory system idle during every compute phase); PIPE=4: two
-// activation tiles ahead
-using Cfg_G1_128 = GCfg<128, 32, 1, 1, 256, 1, 1, 2, 4, 0, 4>;
+// launches are HBM-bound: the unpipelined loop left the memory system idle during every compute phase).  Two activation
+// tiles in flight instead of one measured the same (3.72 ms per step for the four 256->128 @64^3 shortcuts either way)
+using Cfg_G1_128 = GCfg<128, 32, 1, 1, 256, 1, 1, 2, 4, 0, 1>;
 using Cfg_G1_128_LOW = GCfg<128, 32, 1, 1, 64, 1, 1, 4, 2, 0, 1>;
 // 128 columns per workgroup (48 KB of LDS: three workgroups per CU): the HBM-bound ResnetBlock shortcut at 64^3 / 32^3 --
 // one workgroup's output burst (64 KB) overlaps the other workgroups' loads
-using Cfg_G1_128_N128 = GCfg<128, 32, 1, 1, 128, 1, 1, 2, 4, 0, 4>;
-using Cfg_G1_128_N128_P1 = GCfg<128, 32, 1, 1, 128, 1, 1, 2, 4, 0, 1>;   // A/B baseline: one tile ahead
+using Cfg_G1_128_N128 = GCfg<128, 32, 1, 1, 128, 1, 1, 2, 4, 0, 1>;
 using Cfg_G1_64_LOW = GCfg<64, 32, 1, 1, 64, 1, 1, 2, 2, 0, 1>;
 
 // ---- split-K finish: out = alpha * sum_z partial[z] + bias + residual (slices added in order) ----
@@ -611,7 +584,6 @@ static void cfg_info(int32_t* nt, int32_t* kc, int32_t* cols, int32_t* taps, int
     case MD_CFG_G1_128: F<Cfg_G1_128>(__VA_ARGS__); break;          \
     case MD_CFG_G1_128_LOW: F<Cfg_G1_128_LOW>(__VA_ARGS__); break;  \
     case MD_CFG_G1_128_N128: F<Cfg_G1_128_N128>(__VA_ARGS__); break; \
-    case 23: F<Cfg_G1_128_N128_P1>(__VA_ARGS__); break;              \
     case MD_CFG_G1_64_LOW: F<Cfg_G1_64_LOW>(__VA_ARGS__); break;    \
     case MD_CFG_C5_128_K16: F<Cfg_C5_128_K16>(__VA_ARGS__); break;  \
     case MD_CFG_C5_32_K16: F<Cfg_C5_32_K16>(__VA_ARGS__); break;

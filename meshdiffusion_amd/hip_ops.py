@@ -454,7 +454,7 @@ NIN_N128 = os.environ.get("MD_NIN_N128", "1") == "1"   # A/B: 128-column GEMM ti
 def gemm_cfg_for(ncols, nrows, hbm_bound=False):
     """hbm_bound: a 1x1x1 layer over a big grid with few channels (ResnetBlock shortcut): prefer the 128-column tile."""
     if hbm_bound and NIN_N128 and ncols % 128 == 0 and ncols >= 32768:
-        return 23 if os.environ.get("MD_NIN_P1") == "1" else CFG_G1_128_N128      # 23: A/B baseline (one tile ahead)
+        return CFG_G1_128_N128
     if ncols % 256 == 0:
         return CFG_G1_128
     return CFG_G1_128_LOW if nrows % 128 == 0 else CFG_G1_64_LOW
