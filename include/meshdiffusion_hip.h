@@ -239,6 +239,19 @@ int md_softmax_keys(const float* s, void* p, int32_t batch, int32_t n_keys, int3
                     void* stream);
 
 /*
+ * md_nin_f32: the ResnetBlock shortcut NIN_0 (1x1x1 channel mixing, layers.py:573-582 used at :667,:688) for the HBM-bound
+ * shapes, as a persistent, barrier-free streaming kernel: the whole WPK weight matrix (MD_CFG_G1_128 tiles, K <= 256) is
+ * resident in LDS, the fp32 input goes HBM -> registers -> bf16 split -> MFMA.
+ *   x1, x2 : F32B [B][c1/8][P][8], [B][c2/8][P][8]: the channel parts of torch.cat([h, skip], 1) (x2 NULL when c2 = 0)
+ *   wpk    : md_pack_weights(W, rows = cout, kdim = c1 + c2, taps = 1, nt = 128, kc = 32)
+ *   out    : F32B [B][cout/8][P][8] = W^T x + bias
+ * Supported: cout == 128, c1 + c2 in {128, 256}, c1 % 16 == c2 % 16 == 0, P % 256 == 0; otherwise MD_ERR_UNSUPPORTED
+ * (md_gemm_conv handles every shape).  n_cu: workgroups to launch (0 = 256, one per CU).
+ */
+int md_nin_f32(const float* x1, const float* x2, int32_t c1, int32_t c2, const void* wpk, const float* bias,
+               float* out, int32_t batch, int32_t cout, int64_t P, int32_t n_cu, void* stream);
+
+/*
  * md_attn_fwd: fused single-head self-attention (AttnBlock.forward, layers.py:595-608: the two einsums :602,:606 and the
  * softmax :604) -- QK^T, online softmax over the keys and PV in one kernel, bf16x3 MFMA for both contractions; the
  * [B][N][N] score matrix is never materialised.

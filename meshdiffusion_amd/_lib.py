@@ -66,6 +66,7 @@ SIGNATURES = {
     "md_f32b_to_ncdhw": (C.c_int, [_P, _P, _I32, _I32, _I64, _P]),
     "md_ncdhw_to_f32b": (C.c_int, [_P, _P, _I32, _I32, _I64, _P]),
     "md_s16b_to_ncdhw": (C.c_int, [_P, _P, _I32, _I32, _I64, _P]),
+    "md_nin_f32": (C.c_int, [_P, _P, _I32, _I32, _P, _P, _P, _I32, _I32, _I64, _I32, _P]),
     "md_attn_fwd": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _F, _P]),
     "md_softmax_keys": (C.c_int, [_P, _P, _I32, _I32, _I32, _P]),
     "md_ancestral_step": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I64, _P]),

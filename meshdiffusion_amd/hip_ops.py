@@ -356,6 +356,25 @@ def s16b_to_ncdhw(x, spatial):
     return out
 
 
+NIN_STREAM = os.environ.get("MD_NIN_STREAM", "1") == "1"   # persistent streaming kernel for the HBM-bound shortcut NINs
+
+
+def nin_stream_ok(parts, rows, P):
+    k = sum(c for _, c in parts)
+    return (NIN_STREAM and rows == 128 and k in (128, 256) and len(parts) <= 2 and all(c % 16 == 0 for _, c in parts)
+            and P % 256 == 0 and P >= 32768)
+
+
+def nin_f32(parts, pw, bias, B, P):
+    """out F32B [B][128][P] = NIN(cat(parts)) with `pw` = PackedWeight(W, "nin", CFG_G1_128 / _N128) -- md_nin_f32."""
+    lib = _lib.load()
+    out = f32b_empty(B, 128, P, parts[0][0].device)
+    x2, c2 = (parts[1][0], parts[1][1]) if len(parts) == 2 else (None, 0)
+    check(lib.md_nin_f32(_ptr(parts[0][0]), _ptr(x2), parts[0][1], c2, _ptr(pw.data), _ptr(bias), _ptr(out), B, 128, P, 0,
+                         _stream()), "md_nin_f32")
+    return out
+
+
 FUSE_ATTN = os.environ.get("MD_FUSE_ATTN", "1") == "1"   # fused QK^T / online softmax / PV kernel where it applies (inference)
 
 

@@ -369,7 +369,9 @@ class ResnetBlockDDPM(HipLayer):
                           b_f32=dict(parts=parts, ac=ac0, silu=True))
             if need_nin:
                 pwn = self.NIN_0.packed(P, hbm_bound=True)
-                if pwn.cfg in (ops.CFG_G1_128, ops.CFG_G1_128_N128) and pwn.kdim == cin:   # the shortcut GEMM splits the raw fp32 parts itself
+                if pwn.kdim == cin and ops.nin_stream_ok(parts, self.out_ch, P):   # weights resident in LDS, input streamed once
+                    res = ops.nin_f32(parts, pwn, self.NIN_0.b, B, P)
+                elif pwn.cfg in (ops.CFG_G1_128, ops.CFG_G1_128_N128) and pwn.kdim == cin:   # the shortcut GEMM splits the raw fp32 parts itself
                     res = run_gemm(pwn, None, B, P, bias=self.NIN_0.b, b_f32=dict(parts=parts, ac=None, silu=False))
                 else:                                               # small grids: one raw split pass of the block input
                     xs = ops.gn_apply(parts, None, B, P, norm=False, silu=False)

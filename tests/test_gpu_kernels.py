@@ -405,3 +405,25 @@ def test_nin_gemm_fp32_parts_operand(ops, cfg_name):
     assert torch.equal(out, out2)
     ref = torch.einsum("bcdhw,co->bodhw", torch.cat(xs, 1), W) + bias[None, :, None, None, None]
     assert rel_l2(ops.f32b_to_ncdhw(out, (S, S, S)).cpu(), ref) < TOL_MFMA
+
+
+@pytest.mark.parametrize("cs", [[128], [128, 128], [96, 32], [208, 48]])
+def test_nin_stream_kernel(ops, cs):
+    """md_nin_f32 (weights resident in LDS, fp32 input streamed HBM -> registers): bit-identical to md_gemm_conv on the
+    pre-split operand (same bf16x3 products, same accumulation order over K), on one- and two-part inputs, more tiles than
+    workgroups (B * P / 256 = 512 tiles on 256 workgroups) and a ragged tile count."""
+    cin, cout = sum(cs), 128
+    for B, S in ((4, 32), (3, 16)):       # 512 tiles; 48 tiles (fewer than workgroups)
+        P = S ** 3
+        xs = [_rand((B, c, S, S, S), 50 + i) for i, c in enumerate(cs)]
+        W, bias = _rand((cin, cout), 52, 0.1), _rand((cout,), 53)
+        parts = [(ops.ncdhw_to_f32b(t.cuda()), c) for t, c in zip(xs, cs)]
+        pw = ops.PackedWeight(W.cuda(), "nin", ops.CFG_G1_128, "cuda")
+        out = ops.nin_f32(parts, pw, bias.cuda(), B, P)
+        a16 = ops.gn_apply(parts, None, B, P, norm=False, silu=False)
+        out2 = ops.f32b_empty(B, cout, P, "cuda")
+        ops.gemm_conv(cfg=ops.CFG_G1_128, a=pw.data, b=a16, out=out2, batch=B, rows=cout, rows_alloc=cout, kdim=cin,
+                      dims=(1, 1, P), bias=bias.cuda())
+        assert torch.equal(out, out2), (cs, B, S)
+        ref = torch.einsum("bcdhw,co->bodhw", torch.cat(xs, 1), W) + bias[None, :, None, None, None]
+        assert rel_l2(ops.f32b_to_ncdhw(out, (S, S, S)).cpu(), ref) < TOL_MFMA
