@@ -42,7 +42,7 @@ extern "C" {
 #define MD_ERR_UNSUPPORTED (-2)
 #define MD_ERR_NO_DEVICE (-3)
 
-#define MD_ABI_VERSION 7
+#define MD_ABI_VERSION 8
 
 /* ---- tile configurations of md_gemm_conv (compile-time instantiations) ---- */
 enum {
@@ -250,6 +250,30 @@ int md_softmax_keys(const float* s, void* p, int32_t batch, int32_t n_keys, int3
  */
 int md_nin_f32(const float* x1, const float* x2, int32_t c1, int32_t c2, const void* wpk, const float* bias,
                float* out, int32_t batch, int32_t cout, int64_t P, int32_t n_cu, void* stream);
+
+/*
+ * Winograd F(2,3)-along-w path of the 3x3x3 stride-1 convolution (inference): nn.GroupNorm + nn.SiLU + nn.Conv3d
+ * (layers.py:676-681, :118-124), on torch.cat([h, skip], 1) (ddpm_res64.py:174-176) or on the nearest-x2 upsampled input
+ * (layers.py:618-623).  2/3 of the matrix-core work of the direct form; bf16x3 products, fp32 accumulation.
+ *
+ * md_wino_prep: fp32 parts -> T[B][C/8][4][2][D][H][W/2][8 bf16]  (C = c1 + c2; 4 = transformed inputs d0-d2, d1+d2, d2-d1,
+ *   d1-d3 of the output pair (2i, 2i+1), d_k = activated input at x = 2i-1+k, zero outside the grid; 2 = bf16 hi / lo plane)
+ *   x1, x2 : F32B [B][c1/8][Pin][8], [B][c2/8][Pin][8] (x2 NULL when c2 = 0); Pin = D*H*W, or D*H*W/8 with ups = 1
+ *   ac     : [B][C][2] folded GroupNorm affine of md_gn_finalize (y = x*ac[c][0] + ac[c][1]), or NULL: no affine, no SiLU
+ *   D, H, W: OUTPUT grid of the convolution (W even); md_wino_operand_bytes gives the size of T
+ * md_wino_pack_weights: Conv3d weight [Cout][Cin][3][3][3] fp32 -> transformed, split tiles in fragment order
+ *   [Cout/128][Cin/16][kd*3+kh][4][row tile 4][plane 2][k-group 2][row 32][8 bf16]  (md_wino_weight_bytes)
+ * md_conv3_wino: out F32B [B][cout/8][P][8] = conv(T, wpk) + bias[b*bias_bstride + co] + residual; stats as in MdGemmConvArgs
+ *   Supported: cout % 128 == 0, cin % 32 == 0, D % 4 == 0, H % 8 == 0, W % 8 == 0, D*H*W < 2^28; else MD_ERR_UNSUPPORTED.
+ */
+int64_t md_wino_operand_bytes(int32_t batch, int32_t cin, int32_t D, int32_t H, int32_t W);
+int md_wino_prep(const float* x1, const float* x2, int32_t c1, int32_t c2, const float* ac, int32_t silu, int32_t ups,
+                 void* t_out, int32_t batch, int32_t D, int32_t H, int32_t W, void* stream);
+int64_t md_wino_weight_bytes(int32_t cout, int32_t cin);
+int md_wino_pack_weights(const float* w, void* wpk, int32_t cout, int32_t cin, void* stream);
+int md_conv3_wino(const void* t_in, const void* wpk, float* out, const float* bias, int64_t bias_bstride,
+                  const float* residual, int64_t res_bstride, double* stats, int32_t batch, int32_t cin, int32_t cout,
+                  int32_t D, int32_t H, int32_t W, void* stream);
 
 /*
  * md_attn_fwd: fused single-head self-attention (AttnBlock.forward, layers.py:595-608: the two einsums :602,:606 and the

@@ -1,0 +1,473 @@
+// 3x3x3 stride-1 convolution through a 1-D Winograd F(2,3) transform along the innermost (w) axis, for the inference path.
+//
+// Reference op: nn.Conv3d 3x3x3 pad 1 (lib/diffusion/models/layers.py:118-124) behind nn.GroupNorm + nn.SiLU
+// (layers.py:676-681), optionally on torch.cat([h, skip], 1) (ddpm_res64.py:174-176) or on the nearest-x2 upsampled
+// input (layers.py:618-623).
+//
+// For one output pair (x = 2i, 2i+1) with inputs d0..d3 = in[2i-1 .. 2i+2] and taps g0 g1 g2 along w:
+//     m0 = (d0 - d2) g0          m1 = (d1 + d2) (g0+g1+g2)/2       m2 = (d2 - d1) (g0-g1+g2)/2       m3 = (d1 - d3) g2
+//     y0 = m0 + m1 + m2          y1 = m1 - m2 - m3
+// 4 products per 2 outputs instead of 6: the 27-tap contraction becomes 9 (kd, kh) taps x 4 "frequencies" on half the
+// columns = 2/3 of the matrix-core work, still in bf16x3 (hi*hi + hi*lo + lo*hi) with fp32 accumulation; the
+// transforms are exact-ish fp32 adds (measured error of one conv vs fp64: 5.5e-6, direct bf16x3: 4.5e-6).
+//
+// Three kernels:
+//   md_wino_prep         fp32 F32B parts -> (GroupNorm affine, SiLU, zero pad, input transform, bf16 hi/lo split)
+//                        -> T[B][C/8][f=4][plane=2][D][H][W/2][8 bf16]        (HBM-bound: reads 4 B, writes 8 B / element)
+//   md_wino_pack_weights [Cout][Cin][3][3][3] fp32 -> G-transformed split tiles in MFMA A-fragment order
+//   md_conv3_wino        the contraction.  One workgroup = 128 output channels x (4 x 8 x 8) positions = 128 rows x 128
+//                        pairs x 4 frequencies of accumulators = the whole register file of a CU (4 waves x 512
+//                        registers, 256 of them AccVGPRs).  WAVE f OWNS FREQUENCY f: its 128 x 128 tile needs only the
+//                        freq-f slice of T (LDS-DMA into a private double-buffered halo, 2 x 15 KB) and the freq-f weight
+//                        fragments (1 KB contiguous each, straight from L2 into registers -- no other wave wants them), so
+//                        the main loop has NO barrier and no VALU work at all: per (kd, kh) step and 16-channel chunk a wave
+//                        issues 48 MFMAs, 8 ds_read_b128 (0.17 per MFMA; conv3_main: 0.67) and 8 global loads.
+//                        Only the epilogue meets: accumulators cross through LDS (m0..m3 of a pair live in 4 waves),
+//                        y0 / y1 + bias + residual + GroupNorm sums as in md_conv3_main_kernel.
+#include "md_common.h"
+
+namespace {
+constexpr int WN_THREADS = 256;
+constexpr int WN_TZ = 4, WN_TY = 8, WN_TX = 8;          // output tile; 4 pairs along w
+constexpr int WN_TPOS = 6 * 10 * 4;                      // 240 transformed halo entries (dz, hy, pair) per (k-group, plane)
+constexpr int WN_HBUF = 4 * WN_TPOS * 16;                // 15360 B: [h 2][plane 2][240][16 B] = one chunk of one frequency
+constexpr int WN_NDMA = WN_HBUF / 1024;                  // 15 LDS-DMA instructions (1 KB each) per chunk and wave
+constexpr int WN_XSTRIDE = 36;                           // floats per (freq, column) row of the exchange area (32 + pad)
+constexpr int WN_XREGION = 4 * 128 * WN_XSTRIDE;         // floats: [f 4][col 128][36]
+constexpr int WN_RED = 4 * 2 * 32 * 2;                   // floats: [wave][DPP row of a half wave][channel][sum, sumsq]
+constexpr int WN_WSLOT = 8192;                           // one step of one frequency's weight fragments
+constexpr int WN_WAVE_LDS = WN_WSLOT + 2 * WN_HBUF;      // 38912 B private to a wave: weight slot + two halo buffers
+constexpr int WN_EPI_BYTES = 2 * WN_XREGION * 4 + 2 * WN_RED * 4;                                   // 151552 B
+constexpr int WN_LDS_BYTES = 4 * WN_WAVE_LDS > WN_EPI_BYTES ? 4 * WN_WAVE_LDS : WN_EPI_BYTES;       // 155648 B
+
+typedef __attribute__((address_space(3))) void* wn_lds_t;
+__device__ const uint4 wn_zero16 = {0u, 0u, 0u, 0u};     // source of halo entries outside the grid
+
+// One LDS-DMA: 64 lanes x 16 B from per-lane global addresses to LDS [dst, dst + 1024).  Hidden from the compiler's wait
+// bookkeeping on purpose (a visible LDS-DMA makes hipcc drain vmcnt(0) before every later ds_read): ordered by the
+// in-order completion of VMEM -- see the wait notes in the main loop.
+__device__ __forceinline__ void wn_dma16(const void* gsrc, uint32_t lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+// Same with a wave-uniform base in SGPRs and a 32-bit per-lane byte offset (the weight stream: base + lane * 16).
+__device__ __forceinline__ void wn_dma16_s(const void* sbase, uint32_t voff, uint32_t lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------------------------
+// md_wino_prep: one thread = one (sample, 8-channel group, z, y, pair)
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void md_wino_prep_kernel(const float* __restrict__ x1, const float* __restrict__ x2,
+                                                           int c1, int c2, const float* __restrict__ ac, int silu, int ups,
+                                                           uint4* __restrict__ T, int batch, int D, int H, int W) {
+  const int Wp = W >> 1;
+  const int64_t Ph = (int64_t)D * H * Wp;
+  const int CG = (c1 + c2) >> 3;
+  const int64_t n = (int64_t)batch * CG * Ph;
+  const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (id >= n) return;
+  const int64_t pos2 = id % Ph;
+  const int cg = (int)((id / Ph) % CG);
+  const int b = (int)(id / (Ph * CG));
+  const int pr = (int)(pos2 % Wp), y = (int)((pos2 / Wp) % H), z = (int)(pos2 / ((int64_t)Wp * H));
+  int Di = D, Hi = H, Wi = W, zs = z, ys = y;
+  if (ups) { Di >>= 1; Hi >>= 1; Wi >>= 1; zs >>= 1; ys >>= 1; }
+  const int64_t Pin = (int64_t)Di * Hi * Wi;
+  const float* src = (cg * 8 < c1) ? x1 + ((int64_t)b * (c1 >> 3) + cg) * Pin * 8
+                                   : x2 + ((int64_t)b * (c2 >> 3) + (cg - (c1 >> 3))) * Pin * 8;
+  float a[8], c[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { a[e] = 1.f; c[e] = 0.f; }
+  if (ac != nullptr) {
+    const f32x4* ap = (const f32x4*)(ac + ((int64_t)b * (c1 + c2) + cg * 8) * 2);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 v = ap[q];
+      a[2 * q] = v[0]; c[2 * q] = v[1]; a[2 * q + 1] = v[2]; c[2 * q + 1] = v[3];
+    }
+  }
+  float d[4][8];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int xw = 2 * pr - 1 + q;
+    const bool live = xw >= 0 && xw < W;             // the conv pads the ACTIVATED tensor with zeros
+    f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
+    if (live) {
+      const int xs = ups ? (xw >> 1) : xw;
+      const f32x4* p = (const f32x4*)(src + (((int64_t)zs * Hi + ys) * Wi + xs) * 8);
+      v0 = p[0]; v1 = p[1];
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float yv = e < 4 ? v0[e] : v1[e - 4];
+      if (ac != nullptr) {
+        yv = yv * a[e] + c[e];
+        if (silu) yv = yv * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(yv * -1.4426950408889634f));
+      }
+      d[q][e] = live ? yv : 0.f;
+    }
+  }
+  uint4* out = T + ((int64_t)b * CG + cg) * 8 * Ph + pos2;       // [f][plane][Ph] items of 16 B
+#pragma unroll
+  for (int f = 0; f < 4; ++f) {
+    float t[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      t[e] = f == 0 ? d[0][e] - d[2][e] : f == 1 ? d[1][e] + d[2][e] : f == 2 ? d[2][e] - d[1][e] : d[1][e] - d[3][e];
+    uint32_t hw[4], lw[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) md_split2(t[2 * q], t[2 * q + 1], hw[q], lw[q]);
+    out[(int64_t)(f * 2) * Ph] = make_uint4(hw[0], hw[1], hw[2], hw[3]);
+    out[(int64_t)(f * 2 + 1) * Ph] = make_uint4(lw[0], lw[1], lw[2], lw[3]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// md_wino_pack_weights: one thread = one 16-byte item (8 consecutive input channels of one output row, one plane)
+//   layout [cout/128][cin/16][tap (kd,kh) 9][f 4][row tile 4][plane 2][h 2][row 32][8 bf16]
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void md_wino_pack_weights_kernel(const float* __restrict__ w, uint4* __restrict__ wpk,
+                                                                   int cout, int cin) {
+  const int64_t n = (int64_t)cout * cin * 36 / 4;        // items: cout * cin * 36 values * 2 planes / 8
+  const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (id >= n) return;
+  int64_t r = id;
+  const int row = (int)(r % 32); r /= 32;
+  const int h = (int)(r % 2); r /= 2;
+  const int plane = (int)(r % 2); r /= 2;
+  const int rtile = (int)(r % 4); r /= 4;
+  const int f = (int)(r % 4); r /= 4;
+  const int tap = (int)(r % 9); r /= 9;
+  const int nchunk = cin / 16;
+  const int chunk = (int)(r % nchunk); r /= nchunk;
+  const int ct = (int)r;
+  const int co = (ct * 4 + rtile) * 32 + row;
+  uint32_t word[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    uint32_t half[2];
+#pragma unroll
+    for (int e2 = 0; e2 < 2; ++e2) {
+      const int ci = chunk * 16 + h * 8 + 2 * q + e2;
+      const float* g = w + (((int64_t)co * cin + ci) * 9 + tap) * 3;
+      const float g0 = g[0], g1 = g[1], g2 = g[2];
+      const float G = f == 0 ? g0 : f == 1 ? (g0 + g1 + g2) * 0.5f : f == 2 ? (g0 - g1 + g2) * 0.5f : g2;
+      uint32_t hi, lo;
+      md_split(G, hi, lo);
+      half[e2] = plane ? lo : hi;
+    }
+    word[q] = half[0] | (half[1] << 16);
+  }
+  wpk[id] = make_uint4(word[0], word[1], word[2], word[3]);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// md_conv3_wino
+// ------------------------------------------------------------------------------------------------------------------
+struct WnArgs {
+  const uint4* T;          // [B][cin/8][4][2][D][H][W/2] items of 16 B
+  const uint4* wpk;
+  float* out;              // F32B [B][cout/8][P][8]
+  const float* bias;       // may be null; per sample with stride bias_bstride (0 = shared)
+  const float* residual;   // F32B like out, may be null
+  double* stats;           // may be null
+  int64_t bias_bstride, res_bstride;
+  int batch, cin, cout, D, H, W;
+};
+
+__global__ __launch_bounds__(WN_THREADS) void md_conv3_wino_kernel(const WnArgs A) {
+  __shared__ __attribute__((aligned(16))) unsigned char wn_smem[WN_LDS_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);       // = frequency f of this wave
+  const int j = lane & 31, h = lane >> 5;
+
+  const int D = A.D, H = A.H, W = A.W, Wp = W >> 1;
+  const int64_t P = (int64_t)D * H * W, Ph = P >> 1;
+  const int ntx = W / WN_TX, nty = H / WN_TY, ntz = D / WN_TZ;
+  const int tiles = ntx * nty * ntz;
+  int bid = blockIdx.x;     // XCD-aware order: one contiguous run of tiles per XCD (block b runs on XCD b % 8)
+  if ((gridDim.x & 7) == 0) bid = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  const int b = bid / tiles, t = bid % tiles;
+  const int x0 = (t % ntx) * WN_TX, y0 = ((t / ntx) % nty) * WN_TY, z0 = (t / (ntx * nty)) * WN_TZ;
+  const int rtb = blockIdx.y;                                      // 128-row block of output channels
+  const int CG = A.cin >> 3, nchunk = A.cin >> 4;
+  const int nsteps = nchunk * 9;
+
+  // ---- this wave's private LDS: [weight slot 8 KB][halo buffer 0][halo buffer 1] ------------------------------------
+  unsigned char* my_smem = wn_smem + wid * WN_WAVE_LDS;
+  const uint32_t my_lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(wn_lds_t)wn_smem + (uint32_t)wid * WN_WAVE_LDS);
+
+  // ---- halo DMA descriptors: entry e = k * 64 + lane of the linear image [h][plane][dz][hy][pair] ------------------
+  int doff[WN_NDMA];                       // source offset in 16-byte items relative to the (sample, chunk, freq) base, -1 = zero
+#pragma unroll
+  for (int k = 0; k < WN_NDMA; ++k) {
+    const int e = k * 64 + lane;
+    const int hp = e / WN_TPOS, tp = e % WN_TPOS;
+    const int dz = tp / 40, hy = (tp >> 2) % 10, pr = tp & 3;
+    const int z = z0 + dz - 1, y = y0 + hy - 1;
+    const bool live = (z >= 0) & (z < D) & (y >= 0) & (y < H);
+    // cg = 2 chunk + (hp >> 1); inside a cg: [f][plane][Ph]; the f term is in the base
+    doff[k] = live ? (int)((int64_t)(hp >> 1) * 8 * Ph + (int64_t)(hp & 1) * Ph + ((int64_t)z * H + y) * Wp + (x0 >> 1) + pr) : -1;
+  }
+  const uint4* tbase = A.T + ((int64_t)b * CG * 8 + wid * 2) * Ph;                              // + chunk * 16 * Ph
+  const void* zsrc = (const void*)&wn_zero16;
+  // pieces [k0, k1) of chunk `chunk` -> halo buffer `buf`
+  auto dma_halo = [&](int chunk, int buf, int k0, int k1) {
+    const uint4* cb = tbase + (int64_t)chunk * 16 * Ph;
+#pragma unroll
+    for (int k = 0; k < WN_NDMA; ++k)
+      if (k >= k0 && k < k1) {
+        const void* src = doff[k] >= 0 ? (const void*)(cb + doff[k]) : zsrc;
+        wn_dma16(src, my_lds + (uint32_t)(WN_WSLOT + buf * WN_HBUF + k * 1024));
+      }
+  };
+  // weights: step s = chunk * 9 + tap; this wave's 8 fragments (row tile 4 x plane 2) of step s are 8 KB contiguous
+  const unsigned char* wbase = (const unsigned char*)(A.wpk + (((int64_t)rtb * nsteps) * 4 + wid) * 512);   // + s * 32 KB
+  const uint32_t lane16 = (uint32_t)lane * 16;
+  auto dma_weights = [&](int s) {
+    const unsigned char* p = wbase + (int64_t)s * 32768;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) wn_dma16_s(p + i * 1024, lane16, my_lds + (uint32_t)(i * 1024));
+  };
+
+  // ---- fragment reads: one VGPR base each, the rest immediates ---------------------------------------------------------
+  const unsigned char* vA = my_smem + lane * 16;                                          // fragment i at + i * 1024
+  // halo fragment of column tile ct (= output plane z0 + ct), tap (kd, kh):  entry (ct + kd) * 40 + kh * 4 + j
+  const unsigned char* vB = my_smem + WN_WSLOT + h * 2 * WN_TPOS * 16 + j * 16;
+
+  f32x16 acc[4][4];
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[rt][ct][r] = 0.f;
+      asm volatile("" : "+a"(acc[rt][ct]));          // the 256 accumulator registers are the AccVGPR half of the file
+    }
+
+  bf16x8 Af[2][8];      // [step parity][rt * 2 + plane]
+  bf16x8 Bf[2][8];      // [step parity][ct * 2 + plane]
+  auto read_A = [&](bf16x8 (&dst)[8]) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dst[i] = *(const bf16x8*)(vA + i * 1024);
+  };
+  auto read_B = [&](int tap, int buf, bf16x8 (&dst)[8]) {
+    const int kd = tap / 3, kh = tap % 3;
+    const unsigned char* p = vB + buf * WN_HBUF + (kd * 40 + kh * 4) * 16;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+      dst[ct * 2] = *(const bf16x8*)(p + ct * 40 * 16);
+      dst[ct * 2 + 1] = *(const bf16x8*)(p + WN_TPOS * 16 + ct * 40 * 16);
+    }
+  };
+#define WN_MMA_PASS(AI, BI, a, bq)                                                                                    \
+  _Pragma("unroll") for (int rt = 0; rt < 4; ++rt) _Pragma("unroll") for (int ct = 0; ct < 4; ++ct)                  \
+    acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[rt * 2 + (AI)], bq[ct * 2 + (BI)], acc[rt][ct], 0, 0, 0);
+
+  // ---- prologue ---------------------------------------------------------------------------------------------------
+  dma_halo(0, 0, 0, WN_NDMA);
+  dma_weights(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // a wave reads only what its own DMAs wrote: its vmcnt orders them
+  read_A(Af[0]);
+  read_B(0, 0, Bf[0]);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // the weight slot is in registers: refill it
+  dma_weights(nsteps > 1 ? 1 : 0);
+
+  // ---- main loop: two chunks (18 steps) per iteration so that every register-set index is a compile-time constant ----
+  // All global traffic of the loop is LDS-DMA issued from inline asm; the compiler sees ds_reads and MFMAs only, so every
+  // vmcnt is placed here.  VMEM retires in order.  Step s, in program order:
+  //   W1  wait until the weights of step s+1 are in the slot        (requested in step s-1, BEFORE that step's halo pieces)
+  //   R   16 ds_reads: weights and halo fragments of step s+1  ||  first MFMA pass of step s (16 MFMAs)
+  //   W2  lgkmcnt(0): the slot is in registers
+  //   D   DMA: weights of step s+2 -> slot (8 x 1 KB), then 3 halo pieces of the NEXT chunk (taps 0..4 only: 15 pieces)
+  //   M   the other two MFMA passes (32 MFMAs)
+  // W1 leaves the halo pieces of step s-1 in flight (vmcnt(3) at taps 1..5, else 0): a piece has until W1 of the step
+  // after next.  The last pieces (tap 4) are covered by the vmcnt(0) of tap 6; the next chunk's first fragment read is
+  // at tap 8.  A halo buffer is rewritten from tap 0 on; its last reads (tap 7 of the chunk before) returned at tap 8.
+  for (int c0 = 0; c0 < nchunk; c0 += 2) {
+#pragma unroll
+    for (int u = 0; u < 18; ++u) {
+      const int tap = u % 9, cpar = u / 9;             // chunk c0 + cpar lives in halo buffer cpar
+      const int s = c0 * 9 + u;
+      if (tap >= 1 && tap <= 5) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      read_A(Af[(u + 1) & 1]);
+      if (tap < 8) read_B(tap + 1, cpar, Bf[(u + 1) & 1]);
+      else read_B(0, cpar ^ 1, Bf[(u + 1) & 1]);
+      WN_MMA_PASS(1, 0, Af[u & 1], Bf[u & 1])
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {                   // one LDS read in the shadow of each MFMA of the first pass
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      {
+        const int sw = s + 2 < nsteps ? s + 2 : nsteps - 1;      // clamped: the redundant tail requests are never read
+        dma_weights(sw);
+      }
+      if (tap <= 4) {
+        const int cn = c0 + cpar + 1 < nchunk ? c0 + cpar + 1 : nchunk - 1;   // clamped likewise (keeps the vmcnt counts uniform)
+        dma_halo(cn, cpar ^ 1, tap * 3, tap * 3 + 3);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      WN_MMA_PASS(0, 1, Af[u & 1], Bf[u & 1])
+      WN_MMA_PASS(0, 0, Af[u & 1], Bf[u & 1])
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+#undef WN_MMA_PASS
+
+  // ---- epilogue: the four frequencies of an output pair meet through LDS, one 32-row tile per round ----------------------
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the clamped tail requests: nothing may land in LDS after this point
+  __syncthreads();                                       // every wave is done with its private buffers
+  float* xreg = (float*)wn_smem;
+  float* red = xreg + 2 * WN_XREGION;
+  const int rows_total = A.cout;
+  float* outp = A.out + (int64_t)b * rows_total * P;
+  const float* resp = A.residual ? A.residual + (int64_t)b * A.res_bstride : nullptr;
+  const float* biasp = A.bias ? A.bias + (int64_t)b * A.bias_bstride : nullptr;
+  const bool want_stats = A.stats != nullptr;
+  // this wave finishes column tile `wid`: output plane z0 + wid, row y0 + (j >> 2), x = x0 + 2 (j & 3) + {0, 1}
+  const int64_t gp0 = ((int64_t)(z0 + wid) * H + (y0 + (j >> 2))) * W + x0 + 2 * (j & 3);
+  auto row_sum = [](float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
+    return v;
+  };
+  auto flush_stats = [&](int r) {     // after the barrier that follows round r's red[] writes: 64 fp64 atomics
+    if (tid < 64) {
+      const int ch = tid >> 1, which = tid & 1;
+      const float* rb = red + (r & 1) * WN_RED;
+      float sum = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) sum += rb[(k * 32 + ch) * 2 + which];
+      const int row = rtb * 128 + r * 32 + ch;
+      atomicAdd(A.stats + ((int64_t)b * rows_total + row) * 2 + which, (double)sum);
+    }
+  };
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float* xr = xreg + (r & 1) * WN_XREGION;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[r][ct][q * 4 + e];
+        *(f32x4*)(xr + ((wid * 128 + ct * 32 + j) * WN_XSTRIDE + 8 * q + 4 * h)) = v;
+      }
+    __syncthreads();
+    if (want_stats && r > 0) flush_stats(r - 1);
+    f32x4 m[4][4];
+#pragma unroll
+    for (int ff = 0; ff < 4; ++ff)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) m[ff][q] = *(const f32x4*)(xr + ((ff * 128 + wid * 32 + j) * WN_XSTRIDE + 8 * q + 4 * h));
+    float s1[4][4], s2[4][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int row = rtb * 128 + r * 32 + 8 * q + 4 * h;
+      f32x4 bv = {0.f, 0.f, 0.f, 0.f}, r0 = bv, r1 = bv;
+      if (biasp != nullptr) bv = *(const f32x4*)(biasp + row);
+      float* op = outp + ((int64_t)(row >> 3) * P + gp0) * 8 + (row & 7);
+      if (resp != nullptr) {
+        const float* rp = resp + ((int64_t)(row >> 3) * P + gp0) * 8 + (row & 7);
+        r0 = *(const f32x4*)rp; r1 = *(const f32x4*)(rp + 8);
+      }
+      f32x4 o0, o1;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float v0 = (m[0][q][e] + m[1][q][e]) + m[2][q][e];
+        float v1 = (m[1][q][e] - m[2][q][e]) - m[3][q][e];
+        v0 += bv[e]; v1 += bv[e];
+        v0 += r0[e]; v1 += r1[e];
+        o0[e] = v0; o1[e] = v1;
+        s1[q][e] = v0 + v1;
+        s2[q][e] = v0 * v0 + v1 * v1;
+      }
+      *(f32x4*)op = o0;
+      *(f32x4*)(op + 8) = o1;
+    }
+    if (want_stats) {
+      float* rb = red + (r & 1) * WN_RED;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float a1 = row_sum(s1[q][e]), a2 = row_sum(s2[q][e]);
+          if ((lane & 15) == 0) {
+            const int jr = (lane >> 4) & 1, ch = 8 * q + 4 * h + e;
+            rb[((wid * 2 + jr) * 32 + ch) * 2] = a1;
+            rb[((wid * 2 + jr) * 32 + ch) * 2 + 1] = a2;
+          }
+        }
+    }
+  }
+  if (want_stats) {
+    __syncthreads();
+    flush_stats(3);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+extern "C" int64_t md_wino_operand_bytes(int32_t batch, int32_t cin, int32_t D, int32_t H, int32_t W) {
+  if (batch <= 0 || cin <= 0 || (cin & 7) || D <= 0 || H <= 0 || W <= 0 || (W & 1)) return MD_ERR_BAD_ARG;
+  return (int64_t)batch * (cin / 8) * 8 * ((int64_t)D * H * (W / 2)) * 16;
+}
+
+extern "C" int md_wino_prep(const float* x1, const float* x2, int32_t c1, int32_t c2, const float* ac, int32_t silu,
+                            int32_t ups, void* t_out, int32_t batch, int32_t D, int32_t H, int32_t W, void* stream) {
+  if (!x1 || !t_out || batch <= 0 || c1 <= 0 || c2 < 0 || (c1 & 7) || (c2 & 7) || (c2 > 0 && !x2)) return MD_ERR_BAD_ARG;
+  if (D <= 0 || H <= 0 || W <= 0 || (W & 1) || (ups && ((D | H | W) & 1))) return MD_ERR_BAD_ARG;
+  const int64_t n = (int64_t)batch * ((c1 + c2) / 8) * D * H * (W / 2);
+  const int64_t blocks = (n + 255) / 256;
+  if (blocks > 0x7fffffff) return MD_ERR_UNSUPPORTED;
+  MD_HIP_CLEAR_ERROR();
+  hipLaunchKernelGGL(md_wino_prep_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x1, x2, c1, c2, ac, silu,
+                     ups, (uint4*)t_out, batch, D, H, W);
+  MD_HIP_CHECK_LAUNCH();
+  return MD_OK;
+}
+
+extern "C" int64_t md_wino_weight_bytes(int32_t cout, int32_t cin) {
+  if (cout <= 0 || cin <= 0 || (cout % 128) || (cin % 32)) return MD_ERR_BAD_ARG;
+  return (int64_t)cout * cin * 36 * 4;
+}
+
+extern "C" int md_wino_pack_weights(const float* w, void* wpk, int32_t cout, int32_t cin, void* stream) {
+  if (!w || !wpk || cout <= 0 || cin <= 0 || (cout % 128) || (cin % 32)) return MD_ERR_BAD_ARG;
+  const int64_t n = (int64_t)cout * cin * 9;
+  MD_HIP_CLEAR_ERROR();
+  hipLaunchKernelGGL(md_wino_pack_weights_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w,
+                     (uint4*)wpk, cout, cin);
+  MD_HIP_CHECK_LAUNCH();
+  return MD_OK;
+}
+
+extern "C" int md_conv3_wino(const void* t_in, const void* wpk, float* out, const float* bias, int64_t bias_bstride,
+                             const float* residual, int64_t res_bstride, double* stats, int32_t batch, int32_t cin,
+                             int32_t cout, int32_t D, int32_t H, int32_t W, void* stream) {
+  if (!t_in || !wpk || !out || batch <= 0) return MD_ERR_BAD_ARG;
+  if (cin <= 0 || cout <= 0 || (cin % 32) || (cout % 128)) return MD_ERR_UNSUPPORTED;
+  if (D <= 0 || H <= 0 || W <= 0 || (D % WN_TZ) || (H % WN_TY) || (W % WN_TX)) return MD_ERR_UNSUPPORTED;
+  if ((int64_t)D * H * W * 8 >= (int64_t)1 << 31) return MD_ERR_UNSUPPORTED;       // 32-bit halo offsets (16 Ph items)
+  WnArgs a;
+  a.T = (const uint4*)t_in; a.wpk = (const uint4*)wpk; a.out = out; a.bias = bias; a.residual = residual; a.stats = stats;
+  a.bias_bstride = bias_bstride; a.res_bstride = res_bstride;
+  a.batch = batch; a.cin = cin; a.cout = cout; a.D = D; a.H = H; a.W = W;
+  const int tiles = (D / WN_TZ) * (H / WN_TY) * (W / WN_TX);
+  MD_HIP_CLEAR_ERROR();
+  hipLaunchKernelGGL(md_conv3_wino_kernel, dim3((unsigned)(tiles * batch), (unsigned)(cout / 128)), dim3(WN_THREADS), 0,
+                     (hipStream_t)stream, a);
+  MD_HIP_CHECK_LAUNCH();
+  return MD_OK;
+}

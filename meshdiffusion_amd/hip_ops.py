@@ -208,6 +208,82 @@ def gemm_conv(*, cfg, a, b, out, batch, rows, rows_alloc, kdim, dims, bias=None,
 
 
 # ---------------------------------------------------------------------------------------------
+# Winograd F(2,3)-along-w path of the 3x3x3 convolution (inference)
+# ---------------------------------------------------------------------------------------------
+WINO = os.environ.get("MD_WINO", "1") == "1"   # A/B switch: md_wino_prep + md_conv3_wino instead of the fused direct kernel
+
+
+class WinoWeight:
+    """Conv3d weight [Co][Ci][3][3][3] -> G-transformed split-bf16 fragment tiles (md_wino_pack_weights)."""
+
+    def __init__(self, w, device):
+        lib = _lib.load()
+        w = w.detach().to(device=device, dtype=torch.float32).contiguous()
+        _require_cuda(w, "weight")
+        assert w.dim() == 5 and tuple(w.shape[2:]) == (3, 3, 3)
+        self.rows, self.kdim = w.shape[0], w.shape[1]
+        nbytes = lib.md_wino_weight_bytes(self.rows, self.kdim)
+        if nbytes <= 0:
+            raise _lib.MeshDiffusionHipError("md_wino_weight_bytes: unsupported weight shape")
+        self.data = torch.empty(nbytes // 2, dtype=torch.bfloat16, device=device)
+        check(lib.md_wino_pack_weights(_ptr(w), _ptr(self.data), self.rows, self.kdim, _stream()), "md_wino_pack_weights")
+
+
+def wino_ok(rows, kdim, S, B):
+    """Shapes md_conv3_wino takes AND fills the chip with (one workgroup per CU, 128 rows x 4x8x8 positions each)."""
+    return (WINO and PRECISION == "bf16x3" and rows % 128 == 0 and kdim % 32 == 0 and S % 8 == 0
+            and B * (S ** 3 // 256) * (rows // 128) >= 256)
+
+
+def wino_prep(parts, ac, silu, ups, B, S):
+    """fp32 F32B parts (+ folded GroupNorm affine, SiLU, nearest-x2 upsampling) -> transformed split operand T."""
+    lib = _lib.load()
+    cin = sum(c for _, c in parts)
+    assert 1 <= len(parts) <= 2
+    nbytes = lib.md_wino_operand_bytes(B, cin, S, S, S)
+    if nbytes <= 0:
+        raise _lib.MeshDiffusionHipError("md_wino_operand_bytes: unsupported operand shape")
+    t = torch.empty(nbytes // 2, dtype=torch.bfloat16, device=parts[0][0].device)
+    x2, c2 = (parts[1][0], parts[1][1]) if len(parts) == 2 else (None, 0)
+    ev = _prof_begin()
+    check(lib.md_wino_prep(_ptr(parts[0][0]), _ptr(x2), parts[0][1], c2, _ptr(ac), 1 if silu else 0, 1 if ups else 0,
+                           _ptr(t), B, S, S, S, _stream()), "md_wino_prep")
+    _prof_end(ev, "wino_prep", 0.0, 4.0 * B * cin * (S ** 3 // (8 if ups else 1)) + 8.0 * B * cin * S ** 3,   # fp32 in, 2 x bf16 x 2 out
+              f"{cin}@{S}x{S}x{S}" + ("/ups" if ups else ""))
+    return t
+
+
+def conv3_wino(ww, t, B, S, *, bias=None, bias_bstride=0, residual=None, res_bstride=0, stats=None, out=None):
+    lib = _lib.load()
+    P = S ** 3
+    if out is None:
+        out = f32b_empty(B, ww.rows, P, t.device)
+    ev = _prof_begin()
+    check(lib.md_conv3_wino(_ptr(t), _ptr(ww.data), _ptr(out), _ptr(bias), bias_bstride, _ptr(residual), res_bstride,
+                            _ptr(stats), B, ww.kdim, ww.rows, S, S, S, _stream()), "md_conv3_wino")
+    _prof_end(ev, "wino", 2.0 * B * ww.rows * ww.kdim * 27 * P,
+              4.0 * (2 * B * ww.kdim * P + ww.rows * ww.kdim * 36 + B * ww.rows * P * (2 if residual is not None else 1)),
+              f"{ww.kdim}->{ww.rows}@{S}x{S}x{S}" + ("/res" if residual is not None else "") + ("/stats" if stats is not None else ""))
+    return out
+
+
+def _prof_begin():
+    if PROFILE is None:
+        return None
+    e0 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    return e0
+
+
+def _prof_end(e0, cfg, flops, abytes, tag):
+    if e0 is None:
+        return
+    e1 = torch.cuda.Event(enable_timing=True)
+    e1.record()
+    PROFILE.append((cfg, flops, e0, e1, abytes, tag))
+
+
+# ---------------------------------------------------------------------------------------------
 # GroupNorm (+SiLU) + split, with concatenated sources
 # ---------------------------------------------------------------------------------------------
 FUSE_GN_APPLY = os.environ.get("MD_FUSE_GN_APPLY", "1") == "1"   # GroupNorm affine + SiLU + split inside the conv's halo loader (inference)

@@ -110,6 +110,11 @@ def conv3_packed(layer, name, conv, cfg):
                          lambda: ops.PackedWeight(conv.weight, "conv", cfg, conv.weight.device, prec))
 
 
+def conv3_wino_packed(layer, name, conv):
+    """Lazy builder of the Winograd-transformed weight tiles of `conv` (cached like conv3_packed)."""
+    return lambda: layer._cached(f"{name}/wino", [conv.weight], lambda: ops.WinoWeight(conv.weight, conv.weight.device))
+
+
 def fused_operand_ok(pw):
     """True when a conv on packed weights `pw` can take its input as fp32 F32B parts and apply GroupNorm + SiLU + the
     bf16 split itself (MD_B_F32B_GN: dedicated kernel, bf16x3 arithmetic)."""
@@ -117,11 +122,13 @@ def fused_operand_ok(pw):
 
 
 def run_conv3(pw, act_s16, B, S_out, *, bias=None, bias_bstride=0, residual=None, res_bstride=None, ups=0,
-              out=None, out_mode=ops.OUT_F32B, rows_alloc=None, want_stats=False, b_f32=None):
+              out=None, out_mode=ops.OUT_F32B, rows_alloc=None, want_stats=False, b_f32=None, wino=None):
     """3x3x3 conv of an S16B activation tensor with packed weights `pw` on an S_out^3 output grid.
     want_stats: the output feeds a GroupNorm -- when the launch allows it (dedicated kernel, no split-K) its
     epilogue also accumulates the per-(sample, channel) sums, attached to the result as `_md_sums`.
-    b_f32 (see hip_ops.gemm_conv): fp32 parts + folded GroupNorm affine instead of `act_s16` (fused_operand_ok)."""
+    b_f32 (see hip_ops.gemm_conv): fp32 parts + folded GroupNorm affine instead of `act_s16` (fused_operand_ok).
+    wino (with b_f32): builder of the layer's WinoWeight (conv3_wino_packed); where hip_ops.wino_ok says so the conv runs as
+    md_wino_prep + md_conv3_wino (Winograd F(2,3) along w: 2/3 of the matrix-core work) instead of the direct kernel."""
     P = S_out ** 3
     dev = act_s16.device if act_s16 is not None else b_f32["parts"][0][0].device
     rows_alloc = rows_alloc if rows_alloc is not None else ((pw.rows + 7) // 8) * 8
@@ -129,6 +136,17 @@ def run_conv3(pw, act_s16, B, S_out, *, bias=None, bias_bstride=0, residual=None
         out = ops.f32b_empty(B, rows_alloc, P, dev)
     if residual is not None and res_bstride is None:
         res_bstride = rows_alloc * P
+    if (b_f32 is not None and wino is not None and out_mode == ops.OUT_F32B and rows_alloc == pw.rows
+            and pw.prec == ops.PREC_BF16X3 and ops.wino_ok(pw.rows, pw.kdim, S_out, B)):
+        stats = torch.zeros((B, rows_alloc, 2), dtype=torch.float64, device=dev) if want_stats and ops.FUSE_GN_STATS else None
+        t = ops.wino_prep(b_f32["parts"], b_f32.get("ac"), b_f32.get("silu"), ups, B, S_out)
+        ops.conv3_wino(wino(), t, B, S_out, bias=bias, bias_bstride=bias_bstride, residual=residual,
+                       res_bstride=res_bstride or 0, stats=stats, out=out)
+        if stats is not None:
+            out._md_sums = stats
+        elif hasattr(out, "_md_sums"):
+            del out._md_sums
+        return out
     ksplit = ops.ksplit_for(pw.cfg, B, pw.rows, pw.kdim, S_out) if out_mode == ops.OUT_F32B else 1
     stats = None
     if (want_stats and ops.FUSE_GN_STATS and pw.cfg == ops.CFG_C3_128_FAST and ksplit == 1
@@ -272,7 +290,7 @@ class Upsample(HipLayer):
         pw = conv3_packed(self, "w", self.Conv_0, ops.conv_cfg_for(s_out))
         if tape is None and fused_operand_ok(pw) and pw.kdim == Cc:   # the conv splits the raw fp32 input while loading it
             return run_conv3(pw, None, B, s_out, bias=self.Conv_0.bias, ups=1, want_stats=True,
-                             b_f32=dict(parts=[(x, Cc)], ac=None, silu=False))
+                             b_f32=dict(parts=[(x, Cc)], ac=None, silu=False), wino=conv3_wino_packed(self, "w", self.Conv_0))
         act = ops.gn_apply([(x, Cc)], None, B, P, norm=False, silu=False, fp16=pw.prec == ops.PREC_FP16X2)
         if tape is not None:
             assert pw.prec == ops.PREC_BF16X3
@@ -366,7 +384,7 @@ class ResnetBlockDDPM(HipLayer):
                 else:
                     bias0, bias0_stride = self.Conv_0.bias, 0
             h = run_conv3(pw0, None, B, S, bias=bias0, bias_bstride=bias0_stride, want_stats=True,
-                          b_f32=dict(parts=parts, ac=ac0, silu=True))
+                          b_f32=dict(parts=parts, ac=ac0, silu=True), wino=conv3_wino_packed(self, "w0", self.Conv_0))
             if need_nin:
                 pwn = self.NIN_0.packed(P, hbm_bound=True)
                 if pwn.kdim == cin and ops.nin_stream_ok(parts, self.out_ch, P):   # weights resident in LDS, input streamed once
@@ -380,7 +398,7 @@ class ResnetBlockDDPM(HipLayer):
                 res = parts[0][0]
             _, ac1 = ops.gn_params([(h, self.out_ch)], g1.weight, g1.bias, B, P, eps=g1.eps, groups=g1.num_groups, want_ac=True)
             return run_conv3(pw1, None, B, S, bias=self.Conv_1.bias, residual=res, want_stats=True,
-                             b_f32=dict(parts=[(h, self.out_ch)], ac=ac1, silu=True))
+                             b_f32=dict(parts=[(h, self.out_ch)], ac=ac1, silu=True), wino=conv3_wino_packed(self, "w1", self.Conv_1))
         prm = ops.gn_params(parts, g0.weight, g0.bias, B, P, eps=g0.eps, groups=g0.num_groups)
         a0 = ops.gn_apply(parts, prm, B, P, norm=True, silu=True, fp16=f16, want_raw=need_nin)
         xs = None

@@ -1,0 +1,141 @@
+"""Winograd F(2,3)-along-w path of the 3x3x3 convolution (md_wino_prep + md_wino_pack_weights + md_conv3_wino) against
+PyTorch fp32 on the CPU: nn.GroupNorm + nn.SiLU + nn.Conv3d (lib/diffusion/models/layers.py:676-681, :118-124), the channel
+concat of two parts (ddpm_res64.py:174-176) and the nearest-x2 upsampled input (layers.py:618-623).  Tolerance: the bf16x3
+budget of the direct kernels (3e-5 rel-L2); the transform adds ~1e-6 (oracle-side measurement in DESIGN.md)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+TOL_MFMA = 3e-5
+
+
+@pytest.fixture(scope="module")
+def ops(hip_lib):
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from meshdiffusion_amd import hip_ops
+    return hip_ops
+
+
+def _rand(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(shape, generator=g) * scale
+
+
+def _split_bf16(x):
+    hi = x.to(torch.bfloat16)
+    lo = (x - hi.float()).to(torch.bfloat16)
+    return hi, lo
+
+
+def test_wino_prep_layout_and_values(ops):
+    """T[b][c/8][f][plane][z][y][pair][8]: the four transformed inputs of every output pair, zero padded AFTER the
+    activation, split into bf16 hi / lo exactly like md_split2 (RNE) -- bit-exact against the same arithmetic in torch."""
+    B, S, cs = 2, 8, [16, 8]
+    cin = sum(cs)
+    xs = [_rand((B, c, S, S, S), 30 + i) for i, c in enumerate(cs)]
+    parts = [(ops.ncdhw_to_f32b(t.cuda()), c) for t, c in zip(xs, cs)]
+    t = ops.wino_prep(parts, None, False, False, B, S).cpu()
+    t = t.view(B, cin // 8, 4, 2, S, S, S // 2, 8)
+    x = torch.cat(xs, 1)
+    xp = F.pad(x, (1, 1))                                    # w only: d_k = x[2i - 1 + k]
+    d = [xp[..., k:k + S:2] for k in range(4)]               # each [B, C, S, S, S/2]
+    tr = [d[0] - d[2], d[1] + d[2], d[2] - d[1], d[1] - d[3]]
+    for f in range(4):
+        hi, lo = _split_bf16(tr[f])
+        for plane, ref in enumerate((hi, lo)):
+            got = t[:, :, f, plane]                          # [B, C/8, S, S, S/2, 8]
+            want = ref.view(B, cin // 8, 8, S, S, S // 2).permute(0, 1, 3, 4, 5, 2)
+            assert torch.equal(got.view(torch.int16), want.contiguous().view(torch.int16)), (f, plane)
+
+
+@pytest.mark.parametrize("case", ["plain_128", "two_parts_gn_silu_res_stats", "ups_256rows", "gn_no_silu_k64"])
+def test_conv3_wino_vs_torch(ops, case):
+    cfgs = {
+        "plain_128": dict(cs=[128], cout=128, S=16, B=2, gn=False, silu=False, ups=False, res=False, stats=False),
+        "two_parts_gn_silu_res_stats": dict(cs=[96, 32], cout=128, S=16, B=2, gn=True, silu=True, ups=False, res=True, stats=True),
+        "ups_256rows": dict(cs=[64], cout=256, S=16, B=1, gn=False, silu=False, ups=True, res=False, stats=True),
+        "gn_no_silu_k64": dict(cs=[32, 32], cout=128, S=8, B=3, gn=True, silu=False, ups=False, res=True, stats=False),
+    }
+    c = cfgs[case]
+    cs, cout, S, B = c["cs"], c["cout"], c["S"], c["B"]
+    cin = sum(cs)
+    Sin = S // 2 if c["ups"] else S
+    xs = [_rand((B, k, Sin, Sin, Sin), 40 + i) * (1.0 + i) + 0.3 * i for i, k in enumerate(cs)]
+    x = torch.cat(xs, 1)
+    gamma, beta = 1.0 + 0.2 * _rand((cin,), 50), 0.5 * _rand((cin,), 51)
+    w = _rand((cout, cin, 3, 3, 3), 52, 0.05)
+    bias = _rand((B, cout), 53)
+    res = _rand((B, cout, S, S, S), 54) if c["res"] else None
+    parts = [(ops.ncdhw_to_f32b(t.cuda()), k) for t, k in zip(xs, cs)]
+    ac = None
+    ref_in = x
+    if c["gn"]:
+        _, ac = ops.gn_params(parts, gamma.cuda(), beta.cuda(), B, Sin ** 3, want_ac=True)
+        ref_in = F.group_norm(x, 32, gamma, beta, eps=1e-6)
+        ref_in = F.silu(ref_in) if c["silu"] else ref_in
+    if c["ups"]:
+        ref_in = F.interpolate(ref_in, scale_factor=2, mode="nearest")
+    ww = ops.WinoWeight(w.cuda(), "cuda")
+    t = ops.wino_prep(parts, ac, c["silu"], c["ups"], B, S)
+    stats = torch.zeros((B, cout, 2), dtype=torch.float64, device="cuda") if c["stats"] else None
+    res_f = ops.ncdhw_to_f32b(res.cuda()) if res is not None else None
+    out = ops.conv3_wino(ww, t, B, S, bias=bias.cuda(), bias_bstride=cout, residual=res_f,
+                         res_bstride=cout * S ** 3 if res is not None else 0, stats=stats)
+    y = ops.f32b_to_ncdhw(out, (S, S, S)).cpu()
+    ref = F.conv3d(ref_in, w, padding=1) + bias[:, :, None, None, None]
+    if res is not None:
+        ref = ref + res
+    e = rel_l2(y, ref)
+    print(f"wino conv ({case}): vs torch fp32 {e:.2e}")
+    assert e < TOL_MFMA
+    if stats is not None:
+        st = stats.cpu()
+        yd = y.double()
+        assert rel_l2(st[..., 0], yd.sum(dim=(2, 3, 4))) < 1e-6
+        assert rel_l2(st[..., 1], (yd * yd).sum(dim=(2, 3, 4))) < 1e-6
+
+
+def test_conv3_wino_full_tiles_bitwise_repeatable_and_vs_direct(ops):
+    """256 -> 128 at 32^3, B = 2 (512 workgroups, two per CU in sequence): against the direct fused kernel on the same
+    inputs (both bf16x3: they differ only by the transform rounding) and bit-identical between two launches (no atomics,
+    no races between the private LDS-DMA buffers of the four waves)."""
+    B, S, cs, cout = 2, 32, [128, 128], 128
+    cin = sum(cs)
+    xs = [_rand((B, k, S, S, S), 60 + i) for i, k in enumerate(cs)]
+    gamma, beta = 1.0 + 0.2 * _rand((cin,), 62), 0.5 * _rand((cin,), 63)
+    w = _rand((cout, cin, 3, 3, 3), 64, 0.03)
+    bias = _rand((B, cout), 65)
+    parts = [(ops.ncdhw_to_f32b(t.cuda()), k) for t, k in zip(xs, cs)]
+    _, ac = ops.gn_params(parts, gamma.cuda(), beta.cuda(), B, S ** 3, want_ac=True)
+    ww = ops.WinoWeight(w.cuda(), "cuda")
+    outs = []
+    for _ in range(2):
+        t = ops.wino_prep(parts, ac, True, False, B, S)
+        outs.append(ops.conv3_wino(ww, t, B, S, bias=bias.cuda(), bias_bstride=cout).clone())
+    assert torch.equal(outs[0], outs[1])
+    pw = ops.PackedWeight(w.cuda(), "conv", ops.CFG_C3_128_FAST, "cuda")
+    direct = ops.f32b_empty(B, cout, S ** 3, "cuda")
+    ops.gemm_conv(cfg=ops.CFG_C3_128_FAST, a=pw.data, b=None, out=direct, batch=B, rows=cout, rows_alloc=cout, kdim=cin,
+                  dims=(S, S, S), bias=bias.cuda(), bias_bstride=cout, b_f32=dict(parts=parts, ac=ac, silu=True))
+    e = rel_l2(outs[0].cpu(), direct.cpu())
+    print(f"wino vs direct fused kernel: {e:.2e}")
+    assert e < 2e-5
+
+
+def test_conv3_wino_rejects_unsupported_shapes(ops):
+    from meshdiffusion_amd import _lib
+    lib = _lib.load()
+    assert lib.md_wino_weight_bytes(96, 64) < 0          # cout % 128
+    assert lib.md_wino_weight_bytes(128, 48) < 0         # cin % 32
+    assert lib.md_wino_operand_bytes(1, 32, 8, 8, 7) < 0
+    t = torch.zeros(16, device="cuda")
+    rc = lib.md_conv3_wino(t.data_ptr(), t.data_ptr(), t.data_ptr(), None, 0, None, 0, None, 1, 32, 128, 6, 8, 8, None)
+    assert rc == -2          # MD_ERR_UNSUPPORTED
+
+
+_ = np
