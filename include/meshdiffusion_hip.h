@@ -265,6 +265,7 @@ int md_nin_f32(const float* x1, const float* x2, int32_t c1, int32_t c2, const v
  *   [Cout/128][Cin/16][kd*3+kh][4][row tile 4][plane 2][k-group 2][row 32][8 bf16]  (md_wino_weight_bytes)
  * md_conv3_wino: out F32B [B][cout/8][P][8] = conv(T, wpk) + bias[b*bias_bstride + co] + residual; stats as in MdGemmConvArgs
  *   Supported: cout % 128 == 0, cin % 32 == 0, D % 4 == 0, H % 8 == 0, W % 8 == 0, D*H*W < 2^28; else MD_ERR_UNSUPPORTED.
+ *   variant: 0 (others are A/B schedules and timing-only ablations of tools/bench_wino.py).
  */
 int64_t md_wino_operand_bytes(int32_t batch, int32_t cin, int32_t D, int32_t H, int32_t W);
 int md_wino_prep(const float* x1, const float* x2, int32_t c1, int32_t c2, const float* ac, int32_t silu, int32_t ups,
@@ -273,7 +274,7 @@ int64_t md_wino_weight_bytes(int32_t cout, int32_t cin);
 int md_wino_pack_weights(const float* w, void* wpk, int32_t cout, int32_t cin, void* stream);
 int md_conv3_wino(const void* t_in, const void* wpk, float* out, const float* bias, int64_t bias_bstride,
                   const float* residual, int64_t res_bstride, double* stats, int32_t batch, int32_t cin, int32_t cout,
-                  int32_t D, int32_t H, int32_t W, void* stream);
+                  int32_t D, int32_t H, int32_t W, int32_t variant, void* stream);
 
 /*
  * md_attn_fwd: fused single-head self-attention (AttnBlock.forward, layers.py:595-608: the two einsums :602,:606 and the

@@ -51,6 +51,16 @@ __device__ __forceinline__ void wn_dma16(const void* gsrc, uint32_t lds_dst) {
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
+typedef uint32_t wn_u32x4 __attribute__((ext_vector_type(4)));
+// 16-byte load through the GLOBAL address space (a pointer that went through a select loses it and becomes a flat load,
+// which also counts against lgkmcnt)
+__device__ __forceinline__ uint4 wn_gload16(const void* p) {
+  return __builtin_bit_cast(uint4, *(__attribute__((address_space(1))) const wn_u32x4*)(uintptr_t)p);
+}
+template <int N>
+__device__ __forceinline__ void wn_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+template <int N>
+__device__ __forceinline__ void wn_wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
 // Same with a wave-uniform base in SGPRs and a 32-bit per-lane byte offset (the weight stream: base + lane * 16).
 __device__ __forceinline__ void wn_dma16_s(const void* sbase, uint32_t voff, uint32_t lds_dst) {
   unsigned keep;
@@ -180,6 +190,12 @@ struct WnArgs {
   int batch, cin, cout, D, H, W;
 };
 
+// SCHED 1: weights through a private LDS slot (LDS-DMA, recycled fragment by fragment, every DMA between MFMAs).
+// SCHED 2: weights by plain loads straight into a ring of three register sets, requested two steps ahead.
+// SCHED 3: as 2, and the halo pieces go through registers as well (plain loads + ds_write_b128): no LDS-DMA in the loop.
+// ABL (timing only, results invalid; -DMD_BUILD_ABLATIONS): bit 0 no halo DMA, bit 1 no weight DMA, bit 2 no vmcnt waits,
+//   bit 3 no LDS fragment reads, bit 4 no epilogue, bit 5 every halo DMA reads the same L2-resident 30 KB.
+template <int SCHED, int ABL>
 __global__ __launch_bounds__(WN_THREADS) void md_conv3_wino_kernel(const WnArgs A) {
   __shared__ __attribute__((aligned(16))) unsigned char wn_smem[WN_LDS_BYTES];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -202,17 +218,22 @@ __global__ __launch_bounds__(WN_THREADS) void md_conv3_wino_kernel(const WnArgs 
   unsigned char* my_smem = wn_smem + wid * WN_WAVE_LDS;
   const uint32_t my_lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(wn_lds_t)wn_smem + (uint32_t)wid * WN_WAVE_LDS);
 
-  // ---- halo DMA descriptors: entry e = k * 64 + lane of the linear image [h][plane][dz][hy][pair] ------------------
-  int doff[WN_NDMA];                       // source offset in 16-byte items relative to the (sample, chunk, freq) base, -1 = zero
-#pragma unroll
-  for (int k = 0; k < WN_NDMA; ++k) {
+  // ---- halo descriptors: entry e = k * 64 + lane of the linear image [h][plane][dz][hy][pair] --------------------------
+  // (measured alternative: hi / lo planes side by side in T, so that a (dz, hy) row is one whole 128-byte line and a piece
+  // 8 lines instead of 16 half lines: conv +4 %, prep +20 % slower -- reverted)
+  auto halo_off = [&](int k) -> int {
     const int e = k * 64 + lane;
     const int hp = e / WN_TPOS, tp = e % WN_TPOS;
     const int dz = tp / 40, hy = (tp >> 2) % 10, pr = tp & 3;
     const int z = z0 + dz - 1, y = y0 + hy - 1;
     const bool live = (z >= 0) & (z < D) & (y >= 0) & (y < H);
     // cg = 2 chunk + (hp >> 1); inside a cg: [f][plane][Ph]; the f term is in the base
-    doff[k] = live ? (int)((int64_t)(hp >> 1) * 8 * Ph + (int64_t)(hp & 1) * Ph + ((int64_t)z * H + y) * Wp + (x0 >> 1) + pr) : -1;
+    return live ? (int)((int64_t)(hp >> 1) * 8 * Ph + (int64_t)(hp & 1) * Ph + ((int64_t)z * H + y) * Wp + (x0 >> 1) + pr) : -1;
+  };
+  int doff[SCHED == 3 ? 1 : WN_NDMA];      // source offset in 16-byte items relative to the (sample, chunk, freq) base, -1 = zero
+  if constexpr (SCHED != 3) {              // SCHED 3 recomputes the offset of a piece where it is used (15 registers less)
+#pragma unroll
+    for (int k = 0; k < WN_NDMA; ++k) doff[k] = halo_off(k);
   }
   const uint4* tbase = A.T + ((int64_t)b * CG * 8 + wid * 2) * Ph;                              // + chunk * 16 * Ph
   const void* zsrc = (const void*)&wn_zero16;
@@ -221,18 +242,24 @@ __global__ __launch_bounds__(WN_THREADS) void md_conv3_wino_kernel(const WnArgs 
     const uint4* cb = tbase + (int64_t)chunk * 16 * Ph;
 #pragma unroll
     for (int k = 0; k < WN_NDMA; ++k)
-      if (k >= k0 && k < k1) {
-        const void* src = doff[k] >= 0 ? (const void*)(cb + doff[k]) : zsrc;
+      if (k >= k0 && k < k1 && !(ABL & 1)) {
+        const int dk = SCHED == 3 ? halo_off(k) : doff[SCHED == 3 ? 0 : k];
+        const void* src = dk >= 0 ? (const void*)(cb + dk) : zsrc;
+        if constexpr (ABL & 32) src = (const void*)(A.T + k * 64 + lane + (chunk & 1) * 1024);   // timing only: 30 KB that stay in L2
+        if constexpr (ABL & 64)      // timing only: a private contiguous 15 KB per (workgroup, wave, chunk): HBM stream, full lines
+          src = (const void*)(A.T + ((((((int64_t)bid * 4 + wid) * nchunk + chunk) * 960) & (((int64_t)1 << 26) - 1)) + k * 64 + lane));   // 128 ch @ 64^3, B = 8 only
         wn_dma16(src, my_lds + (uint32_t)(WN_WSLOT + buf * WN_HBUF + k * 1024));
       }
   };
   // weights: step s = chunk * 9 + tap; this wave's 8 fragments (row tile 4 x plane 2) of step s are 8 KB contiguous
   const unsigned char* wbase = (const unsigned char*)(A.wpk + (((int64_t)rtb * nsteps) * 4 + wid) * 512);   // + s * 32 KB
   const uint32_t lane16 = (uint32_t)lane * 16;
+  auto dma_weight_frag = [&](int s, int i) {       // fragment i (row tile i / 2, plane i & 1) of step s -> its place in the slot
+    if constexpr (!(ABL & 2)) wn_dma16_s(wbase + (int64_t)s * 32768 + i * 1024, lane16, my_lds + (uint32_t)(i * 1024));
+  };
   auto dma_weights = [&](int s) {
-    const unsigned char* p = wbase + (int64_t)s * 32768;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) wn_dma16_s(p + i * 1024, lane16, my_lds + (uint32_t)(i * 1024));
+    for (int i = 0; i < 8; ++i) dma_weight_frag(s, i);
   };
 
   // ---- fragment reads: one VGPR base each, the rest immediates ---------------------------------------------------------
@@ -250,82 +277,219 @@ __global__ __launch_bounds__(WN_THREADS) void md_conv3_wino_kernel(const WnArgs 
       asm volatile("" : "+a"(acc[rt][ct]));          // the 256 accumulator registers are the AccVGPR half of the file
     }
 
-  bf16x8 Af[2][8];      // [step parity][rt * 2 + plane]
+  bf16x8 Af[2][8];      // SCHED 1: [step parity][rt * 2 + plane]
+  bf16x8 Ar[3][8];      // SCHED 2: [step % 3][rt * 2 + plane]
   bf16x8 Bf[2][8];      // [step parity][ct * 2 + plane]
-  auto read_A = [&](bf16x8 (&dst)[8]) {
+  uint4 hst[2][3];      // SCHED 3: halo pieces on their way from global memory to LDS: [tap parity][piece of the step]
+  auto read_A = [&](bf16x8 (&dst)[8], int i0, int i1, bool force) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) dst[i] = *(const bf16x8*)(vA + i * 1024);
+    for (int i = 0; i < 8; ++i)
+      if (i >= i0 && i < i1 && (force || !(ABL & 8))) dst[i] = *(const bf16x8*)(vA + i * 1024);
   };
-  auto read_B = [&](int tap, int buf, bf16x8 (&dst)[8]) {
+  auto read_B = [&](int tap, int buf, bf16x8 (&dst)[8], bool force) {
     const int kd = tap / 3, kh = tap % 3;
     const unsigned char* p = vB + buf * WN_HBUF + (kd * 40 + kh * 4) * 16;
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct) {
-      dst[ct * 2] = *(const bf16x8*)(p + ct * 40 * 16);
-      dst[ct * 2 + 1] = *(const bf16x8*)(p + WN_TPOS * 16 + ct * 40 * 16);
-    }
+    for (int ct = 0; ct < 4; ++ct)
+      if (force || !(ABL & 8)) {
+        dst[ct * 2] = *(const bf16x8*)(p + ct * 40 * 16);
+        dst[ct * 2 + 1] = *(const bf16x8*)(p + WN_TPOS * 16 + ct * 40 * 16);
+      }
   };
-#define WN_MMA_PASS(AI, BI, a, bq)                                                                                    \
-  _Pragma("unroll") for (int rt = 0; rt < 4; ++rt) _Pragma("unroll") for (int ct = 0; ct < 4; ++ct)                  \
-    acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[rt * 2 + (AI)], bq[ct * 2 + (BI)], acc[rt][ct], 0, 0, 0);
-
   // ---- prologue ---------------------------------------------------------------------------------------------------
   dma_halo(0, 0, 0, WN_NDMA);
-  dma_weights(0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // a wave reads only what its own DMAs wrote: its vmcnt orders them
-  read_A(Af[0]);
-  read_B(0, 0, Bf[0]);
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // the weight slot is in registers: refill it
-  dma_weights(nsteps > 1 ? 1 : 0);
+  if constexpr (SCHED == 1) {
+    dma_weights(0);
+    wn_wait_vm<0>();                                // a wave reads only what its own DMAs wrote: its vmcnt orders them
+    read_A(Af[0], 0, 8, true);
+    read_B(0, 0, Bf[0], true);
+    wn_wait_lgkm<0>();                              // the weight slot is in registers: refill it
+    dma_weights(nsteps > 1 ? 1 : 0);
+  } else {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const uint4* wp = (const uint4*)(wbase + (int64_t)(q < nsteps ? q : nsteps - 1) * 32768) + lane;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) Ar[q][i] = __builtin_bit_cast(bf16x8, wp[i * 64]);
+    }
+    wn_wait_vm<0>();
+    read_B(0, 0, Bf[0], true);
+  }
 
   // ---- main loop: two chunks (18 steps) per iteration so that every register-set index is a compile-time constant ----
   // All global traffic of the loop is LDS-DMA issued from inline asm; the compiler sees ds_reads and MFMAs only, so every
-  // vmcnt is placed here.  VMEM retires in order.  Step s, in program order:
-  //   W1  wait until the weights of step s+1 are in the slot        (requested in step s-1, BEFORE that step's halo pieces)
-  //   R   16 ds_reads: weights and halo fragments of step s+1  ||  first MFMA pass of step s (16 MFMAs)
-  //   W2  lgkmcnt(0): the slot is in registers
-  //   D   DMA: weights of step s+2 -> slot (8 x 1 KB), then 3 halo pieces of the NEXT chunk (taps 0..4 only: 15 pieces)
-  //   M   the other two MFMA passes (32 MFMAs)
-  // W1 leaves the halo pieces of step s-1 in flight (vmcnt(3) at taps 1..5, else 0): a piece has until W1 of the step
-  // after next.  The last pieces (tap 4) are covered by the vmcnt(0) of tap 6; the next chunk's first fragment read is
-  // at tap 8.  A halo buffer is rewritten from tap 0 on; its last reads (tap 7 of the chunk before) returned at tap 8.
+  // vmcnt is placed here.  VMEM retires in order.
+#define WN_MFMA(PASS, IDX, a, bq)                                                                                       \
+  acc[(IDX) >> 2][(IDX) & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[((IDX) >> 2) * 2 + ((PASS) == 0 ? 1 : 0)],   \
+                                                                       bq[((IDX) & 3) * 2 + ((PASS) == 1 ? 1 : 0)],    \
+                                                                       acc[(IDX) >> 2][(IDX) & 3], 0, 0, 0)
+  // pass 0: a_lo * b_hi, pass 1: a_hi * b_lo, pass 2: a_hi * b_hi; same accumulator every 16 MFMAs
+#define WN_PAIR_DS(n)                                                       \
+  _Pragma("unroll") for (int i_ = 0; i_ < (n); ++i_) {                      \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                      \
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                      \
+  }
   for (int c0 = 0; c0 < nchunk; c0 += 2) {
 #pragma unroll
     for (int u = 0; u < 18; ++u) {
       const int tap = u % 9, cpar = u / 9;             // chunk c0 + cpar lives in halo buffer cpar
       const int s = c0 * 9 + u;
-      if (tap >= 1 && tap <= 5) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      read_A(Af[(u + 1) & 1]);
-      if (tap < 8) read_B(tap + 1, cpar, Bf[(u + 1) & 1]);
-      else read_B(0, cpar ^ 1, Bf[(u + 1) & 1]);
-      WN_MMA_PASS(1, 0, Af[u & 1], Bf[u & 1])
+      const int sw = s + 2 < nsteps ? s + 2 : nsteps - 1;                     // clamped: the redundant tail requests are never read
+      const int cn = c0 + cpar + 1 < nchunk ? c0 + cpar + 1 : nchunk - 1;     // clamped likewise (keeps the vmcnt counts uniform)
+      bf16x8 (&Ac)[8] = Af[u & 1], (&Bc)[8] = Bf[u & 1], (&An)[8] = Af[(u + 1) & 1], (&Bn)[8] = Bf[(u + 1) & 1];
+      (void)Ac; (void)An;
+      if constexpr (SCHED == 1) {
+        // Step s = 48 MFMA slots.  The weight slot is recycled fragment by fragment:
+        //   slots  0-3    wait: fragments 0-3 of step s+1 landed        | read them          (requested at slots 16-25 of step s-1)
+        //   slots  4-11                                                  | read the 8 halo fragments of step s+1
+        //   slots 12-15   wait: fragments 4-7 landed                     | read them          (requested at slots 28-37)
+        //   slots 16-27   lgkmcnt(12): fragments 0-3 are in registers    | DMA fragment i of step s+2 before slots 16, 19, 22, 25
+        //   slots 28-39   lgkmcnt(0)                                     | DMA fragments 4-7 before slots 28, 31, 34, 37
+        //   slots 40-47   taps 0..4: one halo piece of the NEXT chunk before slots 40, 43, 46
+        // so a DMA is never issued back to back with another one and a fragment has >= 26 slots (830 cycles) to land.
+        // hp = halo pieces issued by the previous step (they are the newest requests and may stay in flight); pieces of step
+        // s are forced out by the first wait of step s+2 (they precede the weights requested in step s+1).
+        const bool hp = tap >= 1 && tap <= 5;
+        if constexpr (!(ABL & 4)) { if (hp) wn_wait_vm<7>(); else wn_wait_vm<4>(); }
+        read_A(An, 0, 4, false);
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {                   // one LDS read in the shadow of each MFMA of the first pass
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        for (int m = 0; m < 4; ++m) WN_MFMA(0, m, Ac, Bc);
+        WN_PAIR_DS(4)
+        __builtin_amdgcn_sched_barrier(0);
+        if (tap < 8) read_B(tap + 1, cpar, Bn, false);
+        else read_B(0, cpar ^ 1, Bn, false);
+#pragma unroll
+        for (int m = 4; m < 12; ++m) WN_MFMA(0, m, Ac, Bc);
+        WN_PAIR_DS(8)
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (!(ABL & 4)) { if (hp) wn_wait_vm<3>(); else wn_wait_vm<0>(); }
+        read_A(An, 4, 8, false);
+#pragma unroll
+        for (int m = 12; m < 16; ++m) WN_MFMA(0, m, Ac, Bc);
+        WN_PAIR_DS(4)
+        __builtin_amdgcn_sched_barrier(0);
+        wn_wait_lgkm<12>();
+#pragma unroll
+        for (int g = 0; g < 10; ++g) {                 // 10 groups of 3 MFMAs (slots 16..45), one DMA in front of each but the last two...
+          if (g == 4) wn_wait_lgkm<0>();
+          if (g < 8) dma_weight_frag(sw, g);
+          else if (tap <= 4) dma_halo(cn, cpar ^ 1, tap * 3 + (g - 8), tap * 3 + (g - 8) + 1);
+#pragma unroll
+          for (int m = 3 * g; m < 3 * g + 3; ++m) {
+            if (m < 16) WN_MFMA(1, m, Ac, Bc); else WN_MFMA(2, m - 16, Ac, Bc);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (tap <= 4) dma_halo(cn, cpar ^ 1, tap * 3 + 2, tap * 3 + 3);
+        WN_MFMA(2, 14, Ac, Bc);
+        WN_MFMA(2, 15, Ac, Bc);
+        __builtin_amdgcn_sched_barrier(0);
       }
-      __builtin_amdgcn_sched_barrier(0);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      {
-        const int sw = s + 2 < nsteps ? s + 2 : nsteps - 1;      // clamped: the redundant tail requests are never read
-        dma_weights(sw);
+      if constexpr (SCHED >= 2) {
+        // Weights bypass LDS: fragment = 1 KB contiguous = one global_load_dwordx4 per lane, ring of three register sets,
+        // requested two steps ahead by PLAIN loads (hipcc counts them).  The halo pieces stay hidden LDS-DMAs, issued
+        // AFTER this step's weight loads: hipcc's wait for the weights of step s+2 (before the MFMAs of step s+2) lets
+        // 8 + x younger requests stay in flight by its own count and so forces everything older -- the pieces of step s
+        // included -- to have landed: a piece has ~1.7 steps (a fragment 2), not ~1.1 as with the LDS weight slot.
+        // The halo buffer of the next chunk is free from tap 0 on (its last reads returned at tap 8 of the chunk before).
+        bf16x8 (&Aw)[8] = Ar[u % 3], (&Aw2)[8] = Ar[(u + 2) % 3];
+        {
+          const uint4* wp = (const uint4*)(wbase + (int64_t)sw * 32768) + lane;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) Aw2[i] = __builtin_bit_cast(bf16x8, wp[i * 64]);
+        }
+        if (tap < 8) read_B(tap + 1, cpar, Bn, false);
+        else read_B(0, cpar ^ 1, Bn, false);
+#pragma unroll
+        for (int m = 0; m < 16; ++m) WN_MFMA(0, m, Aw, Bc);
+#pragma unroll
+        for (int i_ = 0; i_ < 8; ++i_) {               // 8 LDS reads and 8 global loads under the 16 MFMAs of the first pass
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (SCHED == 2) {
+          // hidden LDS-DMA halo, 3 pieces per step at taps 0..4 (measured: all 15 at tap 0 is no better, 3.11 vs 3.03 ms)
+#pragma unroll
+          for (int g = 0; g < 10; ++g) {
+            if (tap <= 4 && g % 3 == 0 && g < 9) dma_halo(cn, cpar ^ 1, tap * 3 + g / 3, tap * 3 + g / 3 + 1);
+#pragma unroll
+            for (int m = 3 * g; m < 3 * g + 3; ++m) {
+              if (m < 16) WN_MFMA(1, m, Aw, Bc); else WN_MFMA(2, m - 16, Aw, Bc);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          WN_MFMA(2, 14, Aw, Bc);
+          WN_MFMA(2, 15, Aw, Bc);
+          __builtin_amdgcn_sched_barrier(0);
+        } else {
+          // SCHED 3: the halo goes through registers too (an LDS-DMA costs the wave 150-230 cycles of issue, measured; a plain
+          // load + ds_write_b128 a fraction of that) and every request is visible to hipcc's wait counting: 3 pieces are
+          // requested per step at taps 0..4 AFTER this step's weight loads and stored to the other halo buffer two steps
+          // later (taps 2..6) at the END of the step, i.e. ~2.7 steps after the request and behind nothing they do not need.
+          if (tap >= 2 && tap <= 6) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+              const int k = (tap - 2) * 3 + q;
+              if constexpr (ABL & 128) {      // timing only: loads kept alive, no LDS store
+                asm volatile("" ::"v"(hst[tap & 1][q].x), "v"(hst[tap & 1][q].y), "v"(hst[tap & 1][q].z), "v"(hst[tap & 1][q].w));
+              } else if constexpr (!(ABL & 1)) {
+                *(uint4*)(my_smem + WN_WSLOT + (cpar ^ 1) * WN_HBUF + k * 1024 + lane * 16) = hst[tap & 1][q];
+              }
+            }
+          }
+          if (tap <= 4) {
+            const uint4* cb = tbase + (int64_t)cn * 16 * Ph;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+              const int dk = halo_off(tap * 3 + q);
+              const uint4* src = dk >= 0 ? cb + dk : (const uint4*)zsrc;
+              if constexpr (ABL & 32)      // timing only: a private 30 KB per workgroup slot and wave that stays in L2 (no hot spot)
+                src = A.T + (((blockIdx.x & 255) * 4 + wid) * 2 + (cn & 1)) * 960 + (tap * 3 + q) * 64 + lane;
+              if constexpr (ABL & 64)      // timing only: a private contiguous 15 KB per (workgroup, wave, chunk): HBM, whole lines
+                src = A.T + ((((((int64_t)bid * 4 + wid) * nchunk + cn) * 960) & (((int64_t)1 << 26) - 1)) + (tap * 3 + q) * 64 + lane);
+              if constexpr (ABL & 256) hst[tap & 1][q] = make_uint4(lane, tap, q, 0);      // timing only: LDS stores without loads
+              else if constexpr (!(ABL & 1)) hst[tap & 1][q] = wn_gload16(src);
+            }
+          }
+#pragma unroll
+          for (int m = 0; m < 32; ++m) {
+            if (m < 16) WN_MFMA(1, m, Aw, Bc); else WN_MFMA(2, m - 16, Aw, Bc);
+          }
+          // order inside the region: loads early (after the first MFMAs), stores late
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 20, 0);
+          __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
-      if (tap <= 4) {
-        const int cn = c0 + cpar + 1 < nchunk ? c0 + cpar + 1 : nchunk - 1;   // clamped likewise (keeps the vmcnt counts uniform)
-        dma_halo(cn, cpar ^ 1, tap * 3, tap * 3 + 3);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      WN_MMA_PASS(0, 1, Af[u & 1], Bf[u & 1])
-      WN_MMA_PASS(0, 0, Af[u & 1], Bf[u & 1])
-      __builtin_amdgcn_sched_barrier(0);
     }
   }
-#undef WN_MMA_PASS
+#undef WN_MFMA
+#undef WN_PAIR_DS
 
   // ---- epilogue: the four frequencies of an output pair meet through LDS, one 32-row tile per round ----------------------
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the clamped tail requests: nothing may land in LDS after this point
-  __syncthreads();                                       // every wave is done with its private buffers
+  wn_wait_vm<0>();                                       // the clamped tail requests: nothing may land in LDS after this point
+  if constexpr (ABL & 16) {                              // timing only: keep the accumulators alive, write nothing
+    float keep = 0.f;
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) keep += acc[rt][ct][0];
+    if (keep == 123.456f) A.out[tid] = keep;
+    return;
+  }
   float* xreg = (float*)wn_smem;
   float* red = xreg + 2 * WN_XREGION;
   const int rows_total = A.cout;
@@ -353,6 +517,26 @@ __global__ __launch_bounds__(WN_THREADS) void md_conv3_wino_kernel(const WnArgs 
       atomicAdd(A.stats + ((int64_t)b * rows_total + row) * 2 + which, (double)sum);
     }
   };
+  // bias / residual of round r are requested one round ahead (round 0: before the first barrier): the rounds are short and a
+  // load issued where it is used would expose one HBM latency per round
+  f32x4 pbias[2][4], pres[2][4][2];
+  auto prefetch = [&](int r) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int row = rtb * 128 + r * 32 + 8 * q + 4 * h;
+      f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      pbias[r & 1][q] = biasp != nullptr ? *(const f32x4*)(biasp + row) : z;
+      if (resp != nullptr) {
+        const float* rp = resp + ((int64_t)(row >> 3) * P + gp0) * 8 + (row & 7);
+        pres[r & 1][q][0] = *(const f32x4*)rp;
+        pres[r & 1][q][1] = *(const f32x4*)(rp + 8);
+      } else {
+        pres[r & 1][q][0] = z; pres[r & 1][q][1] = z;
+      }
+    }
+  };
+  prefetch(0);
+  __syncthreads();                                       // every wave is done with its private buffers (the exchange area aliases them)
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     float* xr = xreg + (r & 1) * WN_XREGION;
@@ -365,6 +549,7 @@ __global__ __launch_bounds__(WN_THREADS) void md_conv3_wino_kernel(const WnArgs 
         for (int e = 0; e < 4; ++e) v[e] = acc[r][ct][q * 4 + e];
         *(f32x4*)(xr + ((wid * 128 + ct * 32 + j) * WN_XSTRIDE + 8 * q + 4 * h)) = v;
       }
+    if (r < 3) prefetch(r + 1);
     __syncthreads();
     if (want_stats && r > 0) flush_stats(r - 1);
     f32x4 m[4][4];
@@ -376,13 +561,8 @@ __global__ __launch_bounds__(WN_THREADS) void md_conv3_wino_kernel(const WnArgs 
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int row = rtb * 128 + r * 32 + 8 * q + 4 * h;
-      f32x4 bv = {0.f, 0.f, 0.f, 0.f}, r0 = bv, r1 = bv;
-      if (biasp != nullptr) bv = *(const f32x4*)(biasp + row);
+      const f32x4 bv = pbias[r & 1][q], r0 = pres[r & 1][q][0], r1 = pres[r & 1][q][1];
       float* op = outp + ((int64_t)(row >> 3) * P + gp0) * 8 + (row & 7);
-      if (resp != nullptr) {
-        const float* rp = resp + ((int64_t)(row >> 3) * P + gp0) * 8 + (row & 7);
-        r0 = *(const f32x4*)rp; r1 = *(const f32x4*)(rp + 8);
-      }
       f32x4 o0, o1;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -455,7 +635,7 @@ extern "C" int md_wino_pack_weights(const float* w, void* wpk, int32_t cout, int
 
 extern "C" int md_conv3_wino(const void* t_in, const void* wpk, float* out, const float* bias, int64_t bias_bstride,
                              const float* residual, int64_t res_bstride, double* stats, int32_t batch, int32_t cin,
-                             int32_t cout, int32_t D, int32_t H, int32_t W, void* stream) {
+                             int32_t cout, int32_t D, int32_t H, int32_t W, int32_t variant, void* stream) {
   if (!t_in || !wpk || !out || batch <= 0) return MD_ERR_BAD_ARG;
   if (cin <= 0 || cout <= 0 || (cin % 32) || (cout % 128)) return MD_ERR_UNSUPPORTED;
   if (D <= 0 || H <= 0 || W <= 0 || (D % WN_TZ) || (H % WN_TY) || (W % WN_TX)) return MD_ERR_UNSUPPORTED;
@@ -466,8 +646,30 @@ extern "C" int md_conv3_wino(const void* t_in, const void* wpk, float* out, cons
   a.batch = batch; a.cin = cin; a.cout = cout; a.D = D; a.H = H; a.W = W;
   const int tiles = (D / WN_TZ) * (H / WN_TY) * (W / WN_TX);
   MD_HIP_CLEAR_ERROR();
-  hipLaunchKernelGGL(md_conv3_wino_kernel, dim3((unsigned)(tiles * batch), (unsigned)(cout / 128)), dim3(WN_THREADS), 0,
-                     (hipStream_t)stream, a);
+  const dim3 grid((unsigned)(tiles * batch), (unsigned)(cout / 128));
+#define WN_LAUNCH(S_, A_) hipLaunchKernelGGL((md_conv3_wino_kernel<S_, A_>), grid, dim3(WN_THREADS), 0, (hipStream_t)stream, a)
+  switch (variant) {
+    case 0: WN_LAUNCH(1, 0); break;
+    case 200: WN_LAUNCH(2, 0); break;
+    case 300: WN_LAUNCH(3, 0); break;
+#ifdef MD_BUILD_ABLATIONS      // timing-only variants for tools/bench_wino.py
+    case 1: WN_LAUNCH(1, 1); break;
+    case 16: WN_LAUNCH(1, 16); break;
+    case 201: WN_LAUNCH(2, 1); break;
+    case 216: WN_LAUNCH(2, 16); break;
+    case 232: WN_LAUNCH(2, 32); break;
+    case 264: WN_LAUNCH(2, 64); break;
+    case 301: WN_LAUNCH(3, 1); break;
+    case 316: WN_LAUNCH(3, 16); break;
+    case 332: WN_LAUNCH(3, 32); break;
+    case 428: WN_LAUNCH(3, 128); break;
+    case 556: WN_LAUNCH(3, 256); break;
+    case 364: WN_LAUNCH(3, 64); break;
+    case 32: WN_LAUNCH(1, 32); break;
+#endif
+    default: return MD_ERR_UNSUPPORTED;
+  }
+#undef WN_LAUNCH
   MD_HIP_CHECK_LAUNCH();
   return MD_OK;
 }

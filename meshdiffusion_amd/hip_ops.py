@@ -253,14 +253,18 @@ def wino_prep(parts, ac, silu, ups, B, S):
     return t
 
 
-def conv3_wino(ww, t, B, S, *, bias=None, bias_bstride=0, residual=None, res_bstride=0, stats=None, out=None):
+WINO_VARIANT = int(os.environ.get("MD_WINO_VARIANT", "0"))
+
+
+def conv3_wino(ww, t, B, S, *, bias=None, bias_bstride=0, residual=None, res_bstride=0, stats=None, out=None, variant=None):
     lib = _lib.load()
     P = S ** 3
     if out is None:
         out = f32b_empty(B, ww.rows, P, t.device)
     ev = _prof_begin()
     check(lib.md_conv3_wino(_ptr(t), _ptr(ww.data), _ptr(out), _ptr(bias), bias_bstride, _ptr(residual), res_bstride,
-                            _ptr(stats), B, ww.kdim, ww.rows, S, S, S, _stream()), "md_conv3_wino")
+                            _ptr(stats), B, ww.kdim, ww.rows, S, S, S, WINO_VARIANT if variant is None else variant, _stream()),
+          "md_conv3_wino")
     _prof_end(ev, "wino", 2.0 * B * ww.rows * ww.kdim * 27 * P,
               4.0 * (2 * B * ww.kdim * P + ww.rows * ww.kdim * 36 + B * ww.rows * P * (2 if residual is not None else 1)),
               f"{ww.kdim}->{ww.rows}@{S}x{S}x{S}" + ("/res" if residual is not None else "") + ("/stats" if stats is not None else ""))

@@ -134,7 +134,7 @@ def test_conv3_wino_rejects_unsupported_shapes(ops):
     assert lib.md_wino_weight_bytes(128, 48) < 0         # cin % 32
     assert lib.md_wino_operand_bytes(1, 32, 8, 8, 7) < 0
     t = torch.zeros(16, device="cuda")
-    rc = lib.md_conv3_wino(t.data_ptr(), t.data_ptr(), t.data_ptr(), None, 0, None, 0, None, 1, 32, 128, 6, 8, 8, None)
+    rc = lib.md_conv3_wino(t.data_ptr(), t.data_ptr(), t.data_ptr(), None, 0, None, 0, None, 1, 32, 128, 6, 8, 8, 0, None)
     assert rc == -2          # MD_ERR_UNSUPPORTED
 
 

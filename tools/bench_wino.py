@@ -1,0 +1,71 @@
+"""Microbenchmark of md_conv3_wino (and md_wino_prep) on the hot shapes: production schedule, the A/B schedule and the
+timing-only ablations (library built with MD_BUILD_ABLATIONS=1).  HIP events on the launch stream, median of `--reps`.
+
+    MD_BUILD_ABLATIONS=1 python -m meshdiffusion_amd.build --force && python tools/bench_wino.py
+"""
+import argparse
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from meshdiffusion_amd import hip_ops as ops  # noqa: E402
+
+VARIANTS = {0: "production (interleaved DMAs)", 100: "first schedule (DMAs back to back)", 1: "abl: no halo DMA",
+            6: "abl: no weight DMA, no vmcnt waits", 7: "abl: no DMA at all, no waits", 15: "abl: + no LDS reads (MFMA only)",
+            16: "abl: no epilogue", 31: "abl: MFMA loop only, no epilogue", 107: "first schedule, abl: no DMA, no waits"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reps", type=int, default=7)
+    ap.add_argument("--variants", default="0,100,1,6,7,15,16,31,107")
+    ap.add_argument("--shapes", default="128:128:64:8,256:128:64:8,256:256:32:8,512:256:16:8")
+    ap.add_argument("--out", default=None)
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    rows = []
+    for sh in a.shapes.split(","):
+        cin, cout, S, B = [int(v) for v in sh.split(":")]
+        g = torch.Generator().manual_seed(1)
+        x = ops.ncdhw_to_f32b(torch.randn((B, cin, S, S, S), generator=g).to(dev))
+        w = (torch.randn((cout, cin, 3, 3, 3), generator=g) * 0.03).to(dev)
+        bias = torch.randn((B, cout), generator=g).to(dev)
+        res = ops.f32b_empty(B, cout, S ** 3, dev).normal_()
+        ac = torch.stack([1.0 + 0.1 * torch.randn((B, cin), generator=g), 0.1 * torch.randn((B, cin), generator=g)], -1).contiguous().to(dev)
+        ww = ops.WinoWeight(w, dev)
+        out = ops.f32b_empty(B, cout, S ** 3, dev)
+        stats = torch.zeros((B, cout, 2), dtype=torch.float64, device=dev)
+        flops = 2.0 * B * cout * cin * 27 * S ** 3
+
+        def timed(fn):
+            ts = []
+            for _ in range(a.reps):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(); fn(); e1.record(); torch.cuda.synchronize()
+                ts.append(e0.elapsed_time(e1))
+            return sorted(ts)[len(ts) // 2]
+
+        t = ops.wino_prep([(x, cin)], ac, True, False, B, S)
+        ms_prep = timed(lambda: ops.wino_prep([(x, cin)], ac, True, False, B, S))
+        rows.append(dict(shape=sh, kernel="md_wino_prep", ms=round(ms_prep, 4), gbs=round(12.0 * B * cin * S ** 3 / ms_prep / 1e6, 1)))
+        print(json.dumps(rows[-1]), flush=True)
+        for v in [int(k) for k in a.variants.split(",")]:
+            try:
+                ms = timed(lambda: ops.conv3_wino(ww, t, B, S, bias=bias, bias_bstride=cout, residual=res, res_bstride=cout * S ** 3,
+                                                  stats=stats, out=out, variant=v))
+            except Exception as e:  # variant not built
+                print(f"variant {v}: {e}", flush=True)
+                continue
+            rows.append(dict(shape=sh, kernel="md_conv3_wino", variant=v, what=VARIANTS.get(v, "?"), ms=round(ms, 4),
+                             tflops_alg=round(flops / ms / 1e9, 1), issued_frac_of_peak=round(flops * 2 / 3 * 3 / ms / 1e9 / 2500.0, 4)))
+            print(json.dumps(rows[-1]), flush=True)
+    if a.out:
+        with open(a.out, "w") as f:
+            json.dump(rows, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()
