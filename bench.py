@@ -153,11 +153,11 @@ def main():
             torch.cuda.synchronize()
             wall_prof = (time.perf_counter() - t1) / min(a.steps, 5)
             events, hip_ops.PROFILE = hip_ops.PROFILE, None
-            # the same kernel WITHOUT the fused GroupNorm/SiLU/split operand transform (two-pass path), 2 steps: shows what
-            # the fusion costs inside the kernel (the step as a whole gains: see DESIGN.md section 4)
-            if hip_ops.FUSE_GN_APPLY and a.precision == "bf16x3":
-                hip_ops.FUSE_GN_APPLY = False
-                x2, _ = run.step(model_fn, x, it)                     # builds nothing new: same packed weights
+            # the same convolutions through the DIRECT 27-tap kernel (fused operand loader, no Winograd transform), 2 steps:
+            # the r02 mid-round build, measured in the same process on the same box
+            if hip_ops.WINO and a.precision == "bf16x3":
+                hip_ops.WINO = False
+                x2, _ = run.step(model_fn, x, it)                     # packs the direct kernel's weight tiles (untimed)
                 hip_ops.PROFILE = []
                 t1 = time.perf_counter()
                 for _ in range(2):
@@ -165,7 +165,7 @@ def main():
                 torch.cuda.synchronize()
                 wall_unfused = (time.perf_counter() - t1) / 2
                 events_unfused, hip_ops.PROFILE = hip_ops.PROFILE, None
-                hip_ops.FUSE_GN_APPLY = True
+                hip_ops.WINO = True
 
     # ---- optional second measurement: the opt-in fp16x2 arithmetic on the same workload ----
     fast = None
@@ -210,11 +210,12 @@ def main():
         if roof and events_unfused:
             mu = [(f, s.elapsed_time(e) * 1e-3) for (c, f, s, e, _, _) in events_unfused if c == hip_ops.CFG_C3_128_FAST]
             au = sum(f for f, _ in mu) / sum(t for _, t in mu) / 1e12
-            roof["two_pass_build"] = {"kernel": "md_conv3_main_kernel<0,0,0,0> (S16B operand, GroupNorm-apply as its own pass)",
-                                      "achieved": round(au, 2), "frac": round(au / PEAK_BF16_TFLOPS, 4),
-                                      "avg_launch_ms": round(sum(t for _, t in mu) / len(mu) * 1e3, 4),
-                                      "ms_per_step_instrumented": round(wall_unfused * 1e3, 2),
-                                      "ms_per_step_instrumented_fused": round(wall_prof * 1e3, 2)}
+            roof["direct_build"] = {"kernel": "md_conv3_main_kernel<0,0,0,1> (direct 27-tap implicit GEMM, GroupNorm affine + SiLU + split "
+                                              "in the halo loader): every 3x3x3 conv of the step with MD_WINO=0",
+                                    "achieved": round(au, 2), "frac": round(au / PEAK_BF16_TFLOPS, 4),
+                                    "avg_launch_ms": round(sum(t for _, t in mu) / len(mu) * 1e3, 4),
+                                    "ms_per_step_instrumented": round(wall_unfused * 1e3, 2),
+                                    "ms_per_step_instrumented_winograd": round(wall_prof * 1e3, 2)}
         step_flops = B * FLOPS_PER_SAMPLE_STEP
         step_bytes = B * ACT_BYTES_PER_SAMPLE_STEP + WEIGHT_BYTES_PER_STEP
         whole = {"mfma_frac_step": round(step_flops / (wall / a.steps) / (PEAK_BF16_TFLOPS * 1e12), 4),
@@ -248,11 +249,11 @@ def main():
         dist.destroy_process_group()
 
 
-def conv_source_key():
+def conv_source_key(src="conv3_wino.hip"):
     """Identifies the build of the dominant kernel: sha256 of its source files (the PMC traffic figure in
     profiles/conv_traffic.json was measured on one such build and goes stale when the kernel changes)."""
     h = hashlib.sha256()
-    for f in ("conv3_main.hip", "md_common.h"):
+    for f in (src, "md_common.h"):
         with open(os.path.join(ROOT, "meshdiffusion_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
@@ -260,7 +261,11 @@ def conv_source_key():
 
 def roofline(events, hip_ops, a, B, wall_prof):
     """Dominant kernel from the HIP events of the untimed second pass (events on the launch stream)."""
-    main = [(f, s.elapsed_time(e) * 1e-3, ab) for (c, f, s, e, ab, _) in events if c == hip_ops.CFG_C3_128_FAST]
+    wino = any(c == "wino" for (c, *_rest) in events)
+    dom = "wino" if wino else hip_ops.CFG_C3_128_FAST
+    main = [(f, s.elapsed_time(e) * 1e-3, ab) for (c, f, s, e, ab, _) in events if c == dom]
+    prep_t = sum(s.elapsed_time(e) * 1e-3 for (c, _, s, e, _, _) in events if c == "wino_prep")
+    prep_b = sum(ab for (c, _, _, _, ab, _) in events if c == "wino_prep")
     tot_f, tot_t = sum(f for f, _, _ in main), sum(t for _, t, _ in main)
     alg_bytes = sum(ab for _, _, ab in main) / max(len(main), 1)
     allt = sum(s.elapsed_time(e) * 1e-3 for (_, _, s, e, _, _) in events)
@@ -276,7 +281,7 @@ def roofline(events, hip_ops, a, B, wall_prof):
     n_steps = min(a.steps, 5)
     ach = tot_f / tot_t / 1e12
     traffic, traffic_src = None, None
-    key = conv_source_key()
+    key = conv_source_key("conv3_wino.hip" if wino else "conv3_main.hip")
     try:
         with open(TRAFFIC_FILE) as fh:
             tr = json.load(fh)
@@ -288,9 +293,15 @@ def roofline(events, hip_ops, a, B, wall_prof):
     except OSError:
         traffic_src = "profiles/conv_traffic.json missing"
     fused = bool(hip_ops.FUSE_GN_APPLY and a.precision == "bf16x3")
-    return {"bound": "mfma", "kernel": ("md_conv3_main_kernel<0,0,0,1> (3x3x3 conv, implicit GEMM, bf16x3 MFMA; fp32 operand with GroupNorm "
-                                        "affine + SiLU + bf16 split applied in the halo loader)" if fused else
-                                        "md_conv3_main_kernel<0,0,0,0> (3x3x3 conv, implicit GEMM, bf16x3 MFMA)"),
+    if wino:
+        kname = ("md_conv3_wino_kernel<0> (3x3x3 conv as Winograd F(2,3) along w: 9 taps x 4 frequencies, bf16x3 MFMA, one frequency "
+                 "per wave; operand prepared by md_wino_prep)")
+    elif fused:
+        kname = ("md_conv3_main_kernel<0,0,0,1> (3x3x3 conv, implicit GEMM, bf16x3 MFMA; fp32 operand with GroupNorm "
+                 "affine + SiLU + bf16 split applied in the halo loader)")
+    else:
+        kname = "md_conv3_main_kernel<0,0,0,0> (3x3x3 conv, implicit GEMM, bf16x3 MFMA)"
+    return {"bound": "mfma", "kernel": kname,
             "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
             "frac": round(ach / PEAK_BF16_TFLOPS, 4),
             # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for
@@ -300,10 +311,18 @@ def roofline(events, hip_ops, a, B, wall_prof):
             "launches": len(main), "avg_launch_ms": round(tot_t / max(len(main), 1) * 1e3, 4),
             "kernel_time_share_of_step": round(tot_t / n_steps / wall_prof, 4),
             "all_gemm_conv_time_share_of_step": round(allt / n_steps / wall_prof, 4),
+            # the Winograd path's operand pass (GroupNorm affine + SiLU + input transform + split), HBM-bound, priced separately;
+            # `with_prep` = the same algorithmic flops over conv + prep time
+            "operand_prep": ({"kernel": "md_wino_prep", "bound": "hbm", "ms_per_step": round(prep_t / n_steps * 1e3, 3),
+                              "achieved": round(prep_b / prep_t / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                              "frac": round(prep_b / prep_t / 1e9 / PEAK_HBM_GBS, 4),
+                              "conv_plus_prep_tflops": round(tot_f / (tot_t + prep_t) / 1e12, 2),
+                              "conv_plus_prep_frac": round(tot_f / (tot_t + prep_t) / 1e12 / PEAK_BF16_TFLOPS, 4)} if wino and prep_t > 0 else None),
             "per_shape": per_shape,
-            "note": "achieved = algorithmic 2*M*N*K flops (1x, not the 3 bf16 MFMAs issued per product) / HIP-event "
-                    "time of every launch of this kernel in an untimed pass right after the timed region (the timed "
-                    "region itself carries no events); ceiling of the bf16x3 scheme is 1/3 of peak"}
+            "note": "achieved = algorithmic 2*27*Cin*Cout*P flops of the convolution (1x: not the 3 bf16 MFMAs issued per product, "
+                    "and not reduced by the Winograd factor 2/3) / HIP-event time of every launch of this kernel in an untimed "
+                    "pass right after the timed region (the timed region itself carries no events); the kernel ISSUES "
+                    "achieved * 3 * 2/3 = 2 * achieved of bf16 MFMA work"}
 
 
 def train_step_bench(a, cfg, model, rank, world, dev, dist, barrier):

@@ -31,41 +31,21 @@ constexpr int WN_THREADS = 256;
 constexpr int WN_TZ = 4, WN_TY = 8, WN_TX = 8;          // output tile; 4 pairs along w
 constexpr int WN_TPOS = 6 * 10 * 4;                      // 240 transformed halo entries (dz, hy, pair) per (k-group, plane)
 constexpr int WN_HBUF = 4 * WN_TPOS * 16;                // 15360 B: [h 2][plane 2][240][16 B] = one chunk of one frequency
-constexpr int WN_NDMA = WN_HBUF / 1024;                  // 15 LDS-DMA instructions (1 KB each) per chunk and wave
+constexpr int WN_NDMA = WN_HBUF / 1024;                  // 15 pieces of 1 KB (64 lanes x 16 B) per chunk and wave
 constexpr int WN_XSTRIDE = 36;                           // floats per (freq, column) row of the exchange area (32 + pad)
 constexpr int WN_XREGION = 4 * 128 * WN_XSTRIDE;         // floats: [f 4][col 128][36]
 constexpr int WN_RED = 4 * 2 * 32 * 2;                   // floats: [wave][DPP row of a half wave][channel][sum, sumsq]
-constexpr int WN_WSLOT = 8192;                           // one step of one frequency's weight fragments
-constexpr int WN_WAVE_LDS = WN_WSLOT + 2 * WN_HBUF;      // 38912 B private to a wave: weight slot + two halo buffers
+constexpr int WN_WAVE_LDS = 2 * WN_HBUF;                 // 30720 B private to a wave: two halo buffers
 constexpr int WN_EPI_BYTES = 2 * WN_XREGION * 4 + 2 * WN_RED * 4;                                   // 151552 B
-constexpr int WN_LDS_BYTES = 4 * WN_WAVE_LDS > WN_EPI_BYTES ? 4 * WN_WAVE_LDS : WN_EPI_BYTES;       // 155648 B
+constexpr int WN_LDS_BYTES = 4 * WN_WAVE_LDS > WN_EPI_BYTES ? 4 * WN_WAVE_LDS : WN_EPI_BYTES;       // 151552 B
 
-typedef __attribute__((address_space(3))) void* wn_lds_t;
 __device__ const uint4 wn_zero16 = {0u, 0u, 0u, 0u};     // source of halo entries outside the grid
 
-// One LDS-DMA: 64 lanes x 16 B from per-lane global addresses to LDS [dst, dst + 1024).  Hidden from the compiler's wait
-// bookkeeping on purpose (a visible LDS-DMA makes hipcc drain vmcnt(0) before every later ds_read): ordered by the
-// in-order completion of VMEM -- see the wait notes in the main loop.
-__device__ __forceinline__ void wn_dma16(const void* gsrc, uint32_t lds_dst) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-}
 typedef uint32_t wn_u32x4 __attribute__((ext_vector_type(4)));
 // 16-byte load through the GLOBAL address space (a pointer that went through a select loses it and becomes a flat load,
 // which also counts against lgkmcnt)
 __device__ __forceinline__ uint4 wn_gload16(const void* p) {
   return __builtin_bit_cast(uint4, *(__attribute__((address_space(1))) const wn_u32x4*)(uintptr_t)p);
-}
-template <int N>
-__device__ __forceinline__ void wn_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-template <int N>
-__device__ __forceinline__ void wn_wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
-// Same with a wave-uniform base in SGPRs and a 32-bit per-lane byte offset (the weight stream: base + lane * 16).
-__device__ __forceinline__ void wn_dma16_s(const void* sbase, uint32_t voff, uint32_t lds_dst) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
 }
 }  // namespace
 
@@ -190,12 +170,11 @@ struct WnArgs {
   int batch, cin, cout, D, H, W;
 };
 
-// SCHED 1: weights through a private LDS slot (LDS-DMA, recycled fragment by fragment, every DMA between MFMAs).
-// SCHED 2: weights by plain loads straight into a ring of three register sets, requested two steps ahead.
-// SCHED 3: as 2, and the halo pieces go through registers as well (plain loads + ds_write_b128): no LDS-DMA in the loop.
-// ABL (timing only, results invalid; -DMD_BUILD_ABLATIONS): bit 0 no halo DMA, bit 1 no weight DMA, bit 2 no vmcnt waits,
-//   bit 3 no LDS fragment reads, bit 4 no epilogue, bit 5 every halo DMA reads the same L2-resident 30 KB.
-template <int SCHED, int ABL>
+// ABL (timing only, results invalid; -DMD_BUILD_ABLATIONS, tools/bench_wino.py): bit 0 no halo traffic, bit 3 no LDS fragment
+//   reads, bit 4 no epilogue, bit 5 halo read from a private L2-resident 30 KB, bit 6 halo read as a private contiguous
+//   HBM stream.  NOTE: with bit 0 / 3 the MFMAs run on constant operands and the chip clocks higher (data-dependent power):
+//   such runs bound the MFMA time from below, they do not price the removed traffic.
+template <int ABL>
 __global__ __launch_bounds__(WN_THREADS) void md_conv3_wino_kernel(const WnArgs A) {
   __shared__ __attribute__((aligned(16))) unsigned char wn_smem[WN_LDS_BYTES];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -214,11 +193,12 @@ __global__ __launch_bounds__(WN_THREADS) void md_conv3_wino_kernel(const WnArgs 
   const int CG = A.cin >> 3, nchunk = A.cin >> 4;
   const int nsteps = nchunk * 9;
 
-  // ---- this wave's private LDS: [weight slot 8 KB][halo buffer 0][halo buffer 1] ------------------------------------
+  // ---- this wave's private LDS: two halo buffers (one chunk of one frequency each) -------------------------------------
   unsigned char* my_smem = wn_smem + wid * WN_WAVE_LDS;
-  const uint32_t my_lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(wn_lds_t)wn_smem + (uint32_t)wid * WN_WAVE_LDS);
 
-  // ---- halo descriptors: entry e = k * 64 + lane of the linear image [h][plane][dz][hy][pair] --------------------------
+  // ---- halo pieces: piece k = entries [64 k, 64 k + 64) of the linear image [h][plane][dz][hy][pair], one entry per lane;
+  // source offset in 16-byte items relative to the (sample, chunk, freq) base, -1 = outside the grid (zero).  Recomputed
+  // where a piece is requested (a table would hold 15 registers for the whole kernel).
   // (measured alternative: hi / lo planes side by side in T, so that a (dz, hy) row is one whole 128-byte line and a piece
   // 8 lines instead of 16 half lines: conv +4 %, prep +20 % slower -- reverted)
   auto halo_off = [&](int k) -> int {
@@ -230,62 +210,32 @@ __global__ __launch_bounds__(WN_THREADS) void md_conv3_wino_kernel(const WnArgs 
     // cg = 2 chunk + (hp >> 1); inside a cg: [f][plane][Ph]; the f term is in the base
     return live ? (int)((int64_t)(hp >> 1) * 8 * Ph + (int64_t)(hp & 1) * Ph + ((int64_t)z * H + y) * Wp + (x0 >> 1) + pr) : -1;
   };
-  int doff[SCHED == 3 ? 1 : WN_NDMA];      // source offset in 16-byte items relative to the (sample, chunk, freq) base, -1 = zero
-  if constexpr (SCHED != 3) {              // SCHED 3 recomputes the offset of a piece where it is used (15 registers less)
-#pragma unroll
-    for (int k = 0; k < WN_NDMA; ++k) doff[k] = halo_off(k);
-  }
   const uint4* tbase = A.T + ((int64_t)b * CG * 8 + wid * 2) * Ph;                              // + chunk * 16 * Ph
-  const void* zsrc = (const void*)&wn_zero16;
-  // pieces [k0, k1) of chunk `chunk` -> halo buffer `buf`
-  auto dma_halo = [&](int chunk, int buf, int k0, int k1) {
-    const uint4* cb = tbase + (int64_t)chunk * 16 * Ph;
+  const uint4* zsrc = &wn_zero16;
+  auto halo_load = [&](int chunk, int k) -> uint4 {
+    const int dk = halo_off(k);
+    const uint4* src = dk >= 0 ? tbase + (int64_t)chunk * 16 * Ph + dk : zsrc;
+    if constexpr (ABL & 32)      // timing only: a private 30 KB per workgroup slot and wave that stays in L2
+      src = A.T + (((blockIdx.x & 255) * 4 + wid) * 2 + (chunk & 1)) * 960 + k * 64 + lane;
+    if constexpr (ABL & 64)      // timing only: a private contiguous 15 KB per (workgroup, wave, chunk) (128 ch @ 64^3, B = 8 only)
+      src = A.T + ((((((int64_t)bid * 4 + wid) * nchunk + chunk) * 960) & (((int64_t)1 << 26) - 1)) + k * 64 + lane);
+    if constexpr (ABL & 1) return make_uint4(0, 0, 0, 0);
+    return wn_gload16(src);
+  };
+  auto halo_store = [&](int buf, int k, const uint4& v) {
+    if constexpr (!(ABL & 1)) *(uint4*)(my_smem + buf * WN_HBUF + k * 1024 + lane * 16) = v;
+  };
+  // weights: step s = chunk * 9 + tap; this wave's 8 fragments (row tile 4 x plane 2) of step s are 8 KB contiguous, a
+  // fragment (32 rows x 16 k, one plane) 1 KB = one 16-byte load per lane: they go straight to registers (no other wave
+  // wants them), ring of three sets, requested two steps ahead
+  const uint4* wbase = A.wpk + (((int64_t)rtb * nsteps) * 4 + wid) * 512 + lane;               // + s * 2048 + i * 64
+  auto load_A = [&](int s, bf16x8 (&dst)[8]) {
+    const uint4* wp = wbase + (int64_t)s * 2048;
 #pragma unroll
-    for (int k = 0; k < WN_NDMA; ++k)
-      if (k >= k0 && k < k1 && !(ABL & 1)) {
-        const int dk = SCHED == 3 ? halo_off(k) : doff[SCHED == 3 ? 0 : k];
-        const void* src = dk >= 0 ? (const void*)(cb + dk) : zsrc;
-        if constexpr (ABL & 32) src = (const void*)(A.T + k * 64 + lane + (chunk & 1) * 1024);   // timing only: 30 KB that stay in L2
-        if constexpr (ABL & 64)      // timing only: a private contiguous 15 KB per (workgroup, wave, chunk): HBM stream, full lines
-          src = (const void*)(A.T + ((((((int64_t)bid * 4 + wid) * nchunk + chunk) * 960) & (((int64_t)1 << 26) - 1)) + k * 64 + lane));   // 128 ch @ 64^3, B = 8 only
-        wn_dma16(src, my_lds + (uint32_t)(WN_WSLOT + buf * WN_HBUF + k * 1024));
-      }
+    for (int i = 0; i < 8; ++i) dst[i] = __builtin_bit_cast(bf16x8, wp[i * 64]);
   };
-  // weights: step s = chunk * 9 + tap; this wave's 8 fragments (row tile 4 x plane 2) of step s are 8 KB contiguous
-  const unsigned char* wbase = (const unsigned char*)(A.wpk + (((int64_t)rtb * nsteps) * 4 + wid) * 512);   // + s * 32 KB
-  const uint32_t lane16 = (uint32_t)lane * 16;
-  auto dma_weight_frag = [&](int s, int i) {       // fragment i (row tile i / 2, plane i & 1) of step s -> its place in the slot
-    if constexpr (!(ABL & 2)) wn_dma16_s(wbase + (int64_t)s * 32768 + i * 1024, lane16, my_lds + (uint32_t)(i * 1024));
-  };
-  auto dma_weights = [&](int s) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) dma_weight_frag(s, i);
-  };
-
-  // ---- fragment reads: one VGPR base each, the rest immediates ---------------------------------------------------------
-  const unsigned char* vA = my_smem + lane * 16;                                          // fragment i at + i * 1024
   // halo fragment of column tile ct (= output plane z0 + ct), tap (kd, kh):  entry (ct + kd) * 40 + kh * 4 + j
-  const unsigned char* vB = my_smem + WN_WSLOT + h * 2 * WN_TPOS * 16 + j * 16;
-
-  f32x16 acc[4][4];
-#pragma unroll
-  for (int rt = 0; rt < 4; ++rt)
-#pragma unroll
-    for (int ct = 0; ct < 4; ++ct) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[rt][ct][r] = 0.f;
-      asm volatile("" : "+a"(acc[rt][ct]));          // the 256 accumulator registers are the AccVGPR half of the file
-    }
-
-  bf16x8 Af[2][8];      // SCHED 1: [step parity][rt * 2 + plane]
-  bf16x8 Ar[3][8];      // SCHED 2: [step % 3][rt * 2 + plane]
-  bf16x8 Bf[2][8];      // [step parity][ct * 2 + plane]
-  uint4 hst[2][3];      // SCHED 3: halo pieces on their way from global memory to LDS: [tap parity][piece of the step]
-  auto read_A = [&](bf16x8 (&dst)[8], int i0, int i1, bool force) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-      if (i >= i0 && i < i1 && (force || !(ABL & 8))) dst[i] = *(const bf16x8*)(vA + i * 1024);
-  };
+  const unsigned char* vB = my_smem + h * 2 * WN_TPOS * 16 + j * 16;
   auto read_B = [&](int tap, int buf, bf16x8 (&dst)[8], bool force) {
     const int kd = tap / 3, kh = tap % 3;
     const unsigned char* p = vB + buf * WN_HBUF + (kd * 40 + kh * 4) * 16;
@@ -296,191 +246,98 @@ __global__ __launch_bounds__(WN_THREADS) void md_conv3_wino_kernel(const WnArgs 
         dst[ct * 2 + 1] = *(const bf16x8*)(p + WN_TPOS * 16 + ct * 40 * 16);
       }
   };
-  // ---- prologue ---------------------------------------------------------------------------------------------------
-  dma_halo(0, 0, 0, WN_NDMA);
-  if constexpr (SCHED == 1) {
-    dma_weights(0);
-    wn_wait_vm<0>();                                // a wave reads only what its own DMAs wrote: its vmcnt orders them
-    read_A(Af[0], 0, 8, true);
-    read_B(0, 0, Bf[0], true);
-    wn_wait_lgkm<0>();                              // the weight slot is in registers: refill it
-    dma_weights(nsteps > 1 ? 1 : 0);
-  } else {
+
+  f32x16 acc[4][4];
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const uint4* wp = (const uint4*)(wbase + (int64_t)(q < nsteps ? q : nsteps - 1) * 32768) + lane;
+  for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
-      for (int i = 0; i < 8; ++i) Ar[q][i] = __builtin_bit_cast(bf16x8, wp[i * 64]);
+    for (int ct = 0; ct < 4; ++ct) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[rt][ct][r] = 0.f;
+      asm volatile("" : "+a"(acc[rt][ct]));          // the 256 accumulator registers are the AccVGPR half of the file
     }
-    wn_wait_vm<0>();
-    read_B(0, 0, Bf[0], true);
+  bf16x8 Ar[3][8];      // weights  [step % 3][rt * 2 + plane]
+  bf16x8 Bf[2][8];      // halo     [step parity][ct * 2 + plane]
+  uint4 hst[2][3];      // halo pieces on their way from global memory to LDS: [tap parity][piece of the step]
+
+  // ---- prologue: chunk 0 of the halo (15 pieces, all requested before the first is stored), weights of steps 0 and 1 ----
+  {
+    uint4 h0[WN_NDMA];
+#pragma unroll
+    for (int k = 0; k < WN_NDMA; ++k) h0[k] = halo_load(0, k);
+    load_A(0, Ar[0]);
+    load_A(nsteps > 1 ? 1 : 0, Ar[1]);
+#pragma unroll
+    for (int k = 0; k < WN_NDMA; ++k) halo_store(0, k, h0[k]);
   }
+  read_B(0, 0, Bf[0], true);
 
   // ---- main loop: two chunks (18 steps) per iteration so that every register-set index is a compile-time constant ----
-  // All global traffic of the loop is LDS-DMA issued from inline asm; the compiler sees ds_reads and MFMAs only, so every
-  // vmcnt is placed here.  VMEM retires in order.
+  // No LDS-DMA: an LDS-DMA instruction costs the issuing wave 150-230 cycles (measured; with one wave per SIMD nobody else
+  // feeds the matrix pipe meanwhile), a plain load + ds_write_b128 a fraction of that, and hipcc counts plain loads exactly.
+  // Step s = 48 MFMAs (three passes a_lo*b_hi, a_hi*b_lo, a_hi*b_hi over the 16 accumulator tiles):
+  //   pass 0   || 8 weight loads of step s+2, 8 ds_reads of the halo fragments of step s+1
+  //   pass 1-2 || taps 0..4: 3 halo pieces of the NEXT chunk requested (after this step's weight loads, so that the wait
+  //               for those weights two steps later does not cover them); taps 2..6: the 3 pieces requested two steps
+  //               earlier stored to the other halo buffer at the END of the step -- ~2.7 steps (2 us) after the request.
+  // The other halo buffer is free from tap 0 on (its last reads, issued at tap 7 of the chunk before, returned at tap 8);
+  // its first reader is the fragment read of tap 8, two steps after the last store (LDS executes a wave's accesses in order).
 #define WN_MFMA(PASS, IDX, a, bq)                                                                                       \
   acc[(IDX) >> 2][(IDX) & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[((IDX) >> 2) * 2 + ((PASS) == 0 ? 1 : 0)],   \
                                                                        bq[((IDX) & 3) * 2 + ((PASS) == 1 ? 1 : 0)],    \
                                                                        acc[(IDX) >> 2][(IDX) & 3], 0, 0, 0)
-  // pass 0: a_lo * b_hi, pass 1: a_hi * b_lo, pass 2: a_hi * b_hi; same accumulator every 16 MFMAs
-#define WN_PAIR_DS(n)                                                       \
-  _Pragma("unroll") for (int i_ = 0; i_ < (n); ++i_) {                      \
-    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                      \
-    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                      \
-  }
   for (int c0 = 0; c0 < nchunk; c0 += 2) {
 #pragma unroll
     for (int u = 0; u < 18; ++u) {
       const int tap = u % 9, cpar = u / 9;             // chunk c0 + cpar lives in halo buffer cpar
       const int s = c0 * 9 + u;
-      const int sw = s + 2 < nsteps ? s + 2 : nsteps - 1;                     // clamped: the redundant tail requests are never read
-      const int cn = c0 + cpar + 1 < nchunk ? c0 + cpar + 1 : nchunk - 1;     // clamped likewise (keeps the vmcnt counts uniform)
-      bf16x8 (&Ac)[8] = Af[u & 1], (&Bc)[8] = Bf[u & 1], (&An)[8] = Af[(u + 1) & 1], (&Bn)[8] = Bf[(u + 1) & 1];
-      (void)Ac; (void)An;
-      if constexpr (SCHED == 1) {
-        // Step s = 48 MFMA slots.  The weight slot is recycled fragment by fragment:
-        //   slots  0-3    wait: fragments 0-3 of step s+1 landed        | read them          (requested at slots 16-25 of step s-1)
-        //   slots  4-11                                                  | read the 8 halo fragments of step s+1
-        //   slots 12-15   wait: fragments 4-7 landed                     | read them          (requested at slots 28-37)
-        //   slots 16-27   lgkmcnt(12): fragments 0-3 are in registers    | DMA fragment i of step s+2 before slots 16, 19, 22, 25
-        //   slots 28-39   lgkmcnt(0)                                     | DMA fragments 4-7 before slots 28, 31, 34, 37
-        //   slots 40-47   taps 0..4: one halo piece of the NEXT chunk before slots 40, 43, 46
-        // so a DMA is never issued back to back with another one and a fragment has >= 26 slots (830 cycles) to land.
-        // hp = halo pieces issued by the previous step (they are the newest requests and may stay in flight); pieces of step
-        // s are forced out by the first wait of step s+2 (they precede the weights requested in step s+1).
-        const bool hp = tap >= 1 && tap <= 5;
-        if constexpr (!(ABL & 4)) { if (hp) wn_wait_vm<7>(); else wn_wait_vm<4>(); }
-        read_A(An, 0, 4, false);
+      const int sw = s + 2 < nsteps ? s + 2 : nsteps - 1;                     // clamped: the redundant tail requests are never used
+      const int cn = c0 + cpar + 1 < nchunk ? c0 + cpar + 1 : nchunk - 1;     // clamped likewise
+      bf16x8 (&Aw)[8] = Ar[u % 3], (&Bc)[8] = Bf[u & 1], (&Bn)[8] = Bf[(u + 1) & 1];
+      load_A(sw, Ar[(u + 2) % 3]);
+      if (tap < 8) read_B(tap + 1, cpar, Bn, false);
+      else read_B(0, cpar ^ 1, Bn, false);
 #pragma unroll
-        for (int m = 0; m < 4; ++m) WN_MFMA(0, m, Ac, Bc);
-        WN_PAIR_DS(4)
-        __builtin_amdgcn_sched_barrier(0);
-        if (tap < 8) read_B(tap + 1, cpar, Bn, false);
-        else read_B(0, cpar ^ 1, Bn, false);
+      for (int m = 0; m < 16; ++m) WN_MFMA(0, m, Aw, Bc);
 #pragma unroll
-        for (int m = 4; m < 12; ++m) WN_MFMA(0, m, Ac, Bc);
-        WN_PAIR_DS(8)
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (!(ABL & 4)) { if (hp) wn_wait_vm<3>(); else wn_wait_vm<0>(); }
-        read_A(An, 4, 8, false);
-#pragma unroll
-        for (int m = 12; m < 16; ++m) WN_MFMA(0, m, Ac, Bc);
-        WN_PAIR_DS(4)
-        __builtin_amdgcn_sched_barrier(0);
-        wn_wait_lgkm<12>();
-#pragma unroll
-        for (int g = 0; g < 10; ++g) {                 // 10 groups of 3 MFMAs (slots 16..45), one DMA in front of each but the last two...
-          if (g == 4) wn_wait_lgkm<0>();
-          if (g < 8) dma_weight_frag(sw, g);
-          else if (tap <= 4) dma_halo(cn, cpar ^ 1, tap * 3 + (g - 8), tap * 3 + (g - 8) + 1);
-#pragma unroll
-          for (int m = 3 * g; m < 3 * g + 3; ++m) {
-            if (m < 16) WN_MFMA(1, m, Ac, Bc); else WN_MFMA(2, m - 16, Ac, Bc);
-          }
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        if (tap <= 4) dma_halo(cn, cpar ^ 1, tap * 3 + 2, tap * 3 + 3);
-        WN_MFMA(2, 14, Ac, Bc);
-        WN_MFMA(2, 15, Ac, Bc);
-        __builtin_amdgcn_sched_barrier(0);
+      for (int i_ = 0; i_ < 8; ++i_) {                 // 8 LDS reads and 8 global loads under the 16 MFMAs of the first pass
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
       }
-      if constexpr (SCHED >= 2) {
-        // Weights bypass LDS: fragment = 1 KB contiguous = one global_load_dwordx4 per lane, ring of three register sets,
-        // requested two steps ahead by PLAIN loads (hipcc counts them).  The halo pieces stay hidden LDS-DMAs, issued
-        // AFTER this step's weight loads: hipcc's wait for the weights of step s+2 (before the MFMAs of step s+2) lets
-        // 8 + x younger requests stay in flight by its own count and so forces everything older -- the pieces of step s
-        // included -- to have landed: a piece has ~1.7 steps (a fragment 2), not ~1.1 as with the LDS weight slot.
-        // The halo buffer of the next chunk is free from tap 0 on (its last reads returned at tap 8 of the chunk before).
-        bf16x8 (&Aw)[8] = Ar[u % 3], (&Aw2)[8] = Ar[(u + 2) % 3];
-        {
-          const uint4* wp = (const uint4*)(wbase + (int64_t)sw * 32768) + lane;
+      __builtin_amdgcn_sched_barrier(0);
+      if (tap >= 2 && tap <= 6) {
 #pragma unroll
-          for (int i = 0; i < 8; ++i) Aw2[i] = __builtin_bit_cast(bf16x8, wp[i * 64]);
-        }
-        if (tap < 8) read_B(tap + 1, cpar, Bn, false);
-        else read_B(0, cpar ^ 1, Bn, false);
-#pragma unroll
-        for (int m = 0; m < 16; ++m) WN_MFMA(0, m, Aw, Bc);
-#pragma unroll
-        for (int i_ = 0; i_ < 8; ++i_) {               // 8 LDS reads and 8 global loads under the 16 MFMAs of the first pass
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (SCHED == 2) {
-          // hidden LDS-DMA halo, 3 pieces per step at taps 0..4 (measured: all 15 at tap 0 is no better, 3.11 vs 3.03 ms)
-#pragma unroll
-          for (int g = 0; g < 10; ++g) {
-            if (tap <= 4 && g % 3 == 0 && g < 9) dma_halo(cn, cpar ^ 1, tap * 3 + g / 3, tap * 3 + g / 3 + 1);
-#pragma unroll
-            for (int m = 3 * g; m < 3 * g + 3; ++m) {
-              if (m < 16) WN_MFMA(1, m, Aw, Bc); else WN_MFMA(2, m - 16, Aw, Bc);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-          }
-          WN_MFMA(2, 14, Aw, Bc);
-          WN_MFMA(2, 15, Aw, Bc);
-          __builtin_amdgcn_sched_barrier(0);
-        } else {
-          // SCHED 3: the halo goes through registers too (an LDS-DMA costs the wave 150-230 cycles of issue, measured; a plain
-          // load + ds_write_b128 a fraction of that) and every request is visible to hipcc's wait counting: 3 pieces are
-          // requested per step at taps 0..4 AFTER this step's weight loads and stored to the other halo buffer two steps
-          // later (taps 2..6) at the END of the step, i.e. ~2.7 steps after the request and behind nothing they do not need.
-          if (tap >= 2 && tap <= 6) {
-#pragma unroll
-            for (int q = 0; q < 3; ++q) {
-              const int k = (tap - 2) * 3 + q;
-              if constexpr (ABL & 128) {      // timing only: loads kept alive, no LDS store
-                asm volatile("" ::"v"(hst[tap & 1][q].x), "v"(hst[tap & 1][q].y), "v"(hst[tap & 1][q].z), "v"(hst[tap & 1][q].w));
-              } else if constexpr (!(ABL & 1)) {
-                *(uint4*)(my_smem + WN_WSLOT + (cpar ^ 1) * WN_HBUF + k * 1024 + lane * 16) = hst[tap & 1][q];
-              }
-            }
-          }
-          if (tap <= 4) {
-            const uint4* cb = tbase + (int64_t)cn * 16 * Ph;
-#pragma unroll
-            for (int q = 0; q < 3; ++q) {
-              const int dk = halo_off(tap * 3 + q);
-              const uint4* src = dk >= 0 ? cb + dk : (const uint4*)zsrc;
-              if constexpr (ABL & 32)      // timing only: a private 30 KB per workgroup slot and wave that stays in L2 (no hot spot)
-                src = A.T + (((blockIdx.x & 255) * 4 + wid) * 2 + (cn & 1)) * 960 + (tap * 3 + q) * 64 + lane;
-              if constexpr (ABL & 64)      // timing only: a private contiguous 15 KB per (workgroup, wave, chunk): HBM, whole lines
-                src = A.T + ((((((int64_t)bid * 4 + wid) * nchunk + cn) * 960) & (((int64_t)1 << 26) - 1)) + (tap * 3 + q) * 64 + lane);
-              if constexpr (ABL & 256) hst[tap & 1][q] = make_uint4(lane, tap, q, 0);      // timing only: LDS stores without loads
-              else if constexpr (!(ABL & 1)) hst[tap & 1][q] = wn_gload16(src);
-            }
-          }
-#pragma unroll
-          for (int m = 0; m < 32; ++m) {
-            if (m < 16) WN_MFMA(1, m, Aw, Bc); else WN_MFMA(2, m - 16, Aw, Bc);
-          }
-          // order inside the region: loads early (after the first MFMAs), stores late
-          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x008, 20, 0);
-          __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-          __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-          __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-          __builtin_amdgcn_sched_barrier(0);
-        }
+        for (int q = 0; q < 3; ++q) halo_store(cpar ^ 1, (tap - 2) * 3 + q, hst[tap & 1][q]);
       }
+      if (tap <= 4) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) hst[tap & 1][q] = halo_load(cn, tap * 3 + q);
+      }
+#pragma unroll
+      for (int m = 0; m < 32; ++m) {
+        if (m < 16) WN_MFMA(1, m, Aw, Bc); else WN_MFMA(2, m - 16, Aw, Bc);
+      }
+      // inside the region: the 3 loads early (one per 2 MFMAs), the 3 stores behind the last MFMAs
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 20, 0);
+      __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
 #undef WN_MFMA
-#undef WN_PAIR_DS
 
   // ---- epilogue: the four frequencies of an output pair meet through LDS, one 32-row tile per round ----------------------
-  wn_wait_vm<0>();                                       // the clamped tail requests: nothing may land in LDS after this point
   if constexpr (ABL & 16) {                              // timing only: keep the accumulators alive, write nothing
     float keep = 0.f;
 #pragma unroll
@@ -647,25 +504,16 @@ extern "C" int md_conv3_wino(const void* t_in, const void* wpk, float* out, cons
   const int tiles = (D / WN_TZ) * (H / WN_TY) * (W / WN_TX);
   MD_HIP_CLEAR_ERROR();
   const dim3 grid((unsigned)(tiles * batch), (unsigned)(cout / 128));
-#define WN_LAUNCH(S_, A_) hipLaunchKernelGGL((md_conv3_wino_kernel<S_, A_>), grid, dim3(WN_THREADS), 0, (hipStream_t)stream, a)
+#define WN_LAUNCH(A_) hipLaunchKernelGGL((md_conv3_wino_kernel<A_>), grid, dim3(WN_THREADS), 0, (hipStream_t)stream, a)
   switch (variant) {
-    case 0: WN_LAUNCH(1, 0); break;
-    case 200: WN_LAUNCH(2, 0); break;
-    case 300: WN_LAUNCH(3, 0); break;
+    case 0: WN_LAUNCH(0); break;
 #ifdef MD_BUILD_ABLATIONS      // timing-only variants for tools/bench_wino.py
-    case 1: WN_LAUNCH(1, 1); break;
-    case 16: WN_LAUNCH(1, 16); break;
-    case 201: WN_LAUNCH(2, 1); break;
-    case 216: WN_LAUNCH(2, 16); break;
-    case 232: WN_LAUNCH(2, 32); break;
-    case 264: WN_LAUNCH(2, 64); break;
-    case 301: WN_LAUNCH(3, 1); break;
-    case 316: WN_LAUNCH(3, 16); break;
-    case 332: WN_LAUNCH(3, 32); break;
-    case 428: WN_LAUNCH(3, 128); break;
-    case 556: WN_LAUNCH(3, 256); break;
-    case 364: WN_LAUNCH(3, 64); break;
-    case 32: WN_LAUNCH(1, 32); break;
+    case 1: WN_LAUNCH(1); break;
+    case 9: WN_LAUNCH(9); break;
+    case 16: WN_LAUNCH(16); break;
+    case 25: WN_LAUNCH(25); break;
+    case 32: WN_LAUNCH(32); break;
+    case 64: WN_LAUNCH(64); break;
 #endif
     default: return MD_ERR_UNSUPPORTED;
   }

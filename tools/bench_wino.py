@@ -13,15 +13,15 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from meshdiffusion_amd import hip_ops as ops  # noqa: E402
 
-VARIANTS = {0: "production (interleaved DMAs)", 100: "first schedule (DMAs back to back)", 1: "abl: no halo DMA",
-            6: "abl: no weight DMA, no vmcnt waits", 7: "abl: no DMA at all, no waits", 15: "abl: + no LDS reads (MFMA only)",
-            16: "abl: no epilogue", 31: "abl: MFMA loop only, no epilogue", 107: "first schedule, abl: no DMA, no waits"}
+VARIANTS = {0: "production", 1: "abl: no halo traffic (constant operands: clocks higher)", 9: "abl: no halo, no LDS reads",
+            16: "abl: no epilogue", 25: "abl: MFMA loop + weight loads only, no epilogue",
+            32: "abl: halo from a private L2-resident 30 KB", 64: "abl: halo as a private contiguous HBM stream"}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=7)
-    ap.add_argument("--variants", default="0,100,1,6,7,15,16,31,107")
+    ap.add_argument("--variants", default="0,1,9,16,25,32,64")
     ap.add_argument("--shapes", default="128:128:64:8,256:128:64:8,256:256:32:8,512:256:16:8")
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
