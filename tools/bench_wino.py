@@ -24,6 +24,8 @@ def main():
     ap.add_argument("--variants", default="0,1,9,16,25,32,64")
     ap.add_argument("--shapes", default="128:128:64:8,256:128:64:8,256:256:32:8,512:256:16:8")
     ap.add_argument("--out", default=None)
+    ap.add_argument("--no-stats", action="store_true", help="launch without the GroupNorm-sum epilogue")
+    ap.add_argument("--no-res", action="store_true", help="launch without the residual operand")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     rows = []
@@ -54,8 +56,9 @@ def main():
         print(json.dumps(rows[-1]), flush=True)
         for v in [int(k) for k in a.variants.split(",")]:
             try:
-                ms = timed(lambda: ops.conv3_wino(ww, t, B, S, bias=bias, bias_bstride=cout, residual=res, res_bstride=cout * S ** 3,
-                                                  stats=stats, out=out, variant=v))
+                ms = timed(lambda: ops.conv3_wino(ww, t, B, S, bias=bias, bias_bstride=cout, residual=None if a.no_res else res,
+                                                  res_bstride=0 if a.no_res else cout * S ** 3,
+                                                  stats=None if a.no_stats else stats, out=out, variant=v))
             except Exception as e:  # variant not built
                 print(f"variant {v}: {e}", flush=True)
                 continue

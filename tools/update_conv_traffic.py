@@ -3,7 +3,7 @@
     python tools/update_conv_traffic.py profiles/rNN_pmc_fetch.summary.txt profiles/rNN_pmc_write.summary.txt [--batch 8]
 
 Reads the per-launch means of FETCH_SIZE / WRITE_SIZE (KiB; tools/prof_summary.py output of two separate rocprofv3 --pmc
-passes of `python bench.py ...`) for md_conv3_main_kernel<0, 0>, applies the gfx950 correction of MI355X_MICROARCH.md
+passes of `python bench.py ...`) for the dominant kernel (md_conv3_wino_kernel; --kernel to override), applies the gfx950 correction of MI355X_MICROARCH.md
 (FETCH_SIZE reports half of a wide streaming read: doubled), and stores bytes per launch in profiles/conv_traffic.json
 under the sha of the kernel's source files -- bench.py only reports the figure while that sha still matches.
 """
@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
-KERNEL = "md_conv3_main_kernel<0, 0"
+KERNEL = "md_conv3_wino_kernel"
 
 
 def counter(path, name):
@@ -28,11 +28,15 @@ def counter(path, name):
 
 
 def main():
+    global KERNEL
     ap = argparse.ArgumentParser()
     ap.add_argument("fetch")
     ap.add_argument("write")
     ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--kernel", default=KERNEL, help="substring of the kernel name in the summaries")
+    ap.add_argument("--source", default="conv3_wino.hip", help="source file whose sha keys the entry")
     a = ap.parse_args()
+    KERNEL = a.kernel
     fetch_kib, write_kib = counter(a.fetch, "FETCH_SIZE"), counter(a.write, "WRITE_SIZE")
     nbytes = (2.0 * fetch_kib + write_kib) * 1024.0
     try:
@@ -40,8 +44,8 @@ def main():
             tr = json.load(fh)
     except OSError:
         tr = {}
-    key = bench.conv_source_key()
-    tr[key] = {"kernel": "md_conv3_main_kernel<0,0,0,1> (the build bench.py runs by default)", "hbm_bytes_per_launch": round(nbytes), "batch": a.batch,
+    key = bench.conv_source_key(a.source)
+    tr[key] = {"kernel": f"{KERNEL} (the build bench.py runs by default)", "hbm_bytes_per_launch": round(nbytes), "batch": a.batch,
                "fetch_size_kib": fetch_kib, "write_size_kib": write_kib,
                "formula": "(2*FETCH_SIZE + WRITE_SIZE) KiB, mean over the launches of `python bench.py`",
                "source": f"{os.path.relpath(a.fetch, ROOT)} + {os.path.relpath(a.write, ROOT)}"}
