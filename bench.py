@@ -12,7 +12,9 @@ data.  Sampling shards over GPUs as independent sample batches: no data-path col
 
 Prints ONE JSON line (rank 0).  `value` = N * B * K / wall  (sample-steps per second, whole job); the timed
 region carries no instrumentation.  Extra objects, all measured AFTER the timed region:
-  roofline      dominant kernel (3x3x3 implicit-GEMM conv): HIP events around every launch of a second, untimed pass
+  roofline      dominant kernel (md_conv3_wino: the 3x3x3 convs as Winograd F(2,3) along w): HIP events around every launch of
+                a second, untimed pass; its operand pass md_wino_prep priced beside it (`operand_prep`), and the direct 27-tap
+                kernel on the same convs in the same process (`direct_build`)
   train_step    BASELINE configs[2] per GPU (res64 training step, batch 8, dropout 0.1) through the trainer's step
                 function; with N > 1 the gradients are exchanged by parallel.GradReducer over RCCL (the path's one
                 real collective: 1.456 GB of fp32 gradients per step)
@@ -159,11 +161,9 @@ def main():
                 hip_ops.WINO = False
                 x2, _ = run.step(model_fn, x, it)                     # packs the direct kernel's weight tiles (untimed)
                 hip_ops.PROFILE = []
-                t1 = time.perf_counter()
                 for _ in range(2):
                     x2, _ = run.step(model_fn, x2, it)
                 torch.cuda.synchronize()
-                wall_unfused = (time.perf_counter() - t1) / 2
                 events_unfused, hip_ops.PROFILE = hip_ops.PROFILE, None
                 hip_ops.WINO = True
 
@@ -214,8 +214,9 @@ def main():
                                               "in the halo loader): every 3x3x3 conv of the step with MD_WINO=0",
                                     "achieved": round(au, 2), "frac": round(au / PEAK_BF16_TFLOPS, 4),
                                     "avg_launch_ms": round(sum(t for _, t in mu) / len(mu) * 1e3, 4),
-                                    "ms_per_step_instrumented": round(wall_unfused * 1e3, 2),
-                                    "ms_per_step_instrumented_winograd": round(wall_prof * 1e3, 2)}
+                                    "conv_ms_per_step": round(sum(t for _, t in mu) / 2 * 1e3, 2),
+                                    "note": "2 instrumented steps right after switching paths (allocator churn: their wall time is not "
+                                            "a step time); whole-step A/B of the two paths: profiles/r02_wino_first_bench_{on,off}.json"}
         step_flops = B * FLOPS_PER_SAMPLE_STEP
         step_bytes = B * ACT_BYTES_PER_SAMPLE_STEP + WEIGHT_BYTES_PER_STEP
         whole = {"mfma_frac_step": round(step_flops / (wall / a.steps) / (PEAK_BF16_TFLOPS * 1e12), 4),

@@ -261,7 +261,9 @@ int md_nin_f32(const float* x1, const float* x2, int32_t c1, int32_t c2, const v
  *   x1, x2 : F32B [B][c1/8][Pin][8], [B][c2/8][Pin][8] (x2 NULL when c2 = 0); Pin = D*H*W, or D*H*W/8 with ups = 1
  *   ac     : [B][C][2] folded GroupNorm affine of md_gn_finalize (y = x*ac[c][0] + ac[c][1]), or NULL: no affine, no SiLU
  *   D, H, W: OUTPUT grid of the convolution (W even); md_wino_operand_bytes gives the size of T
- * md_wino_pack_weights: Conv3d weight [Cout][Cin][3][3][3] fp32 -> transformed, split tiles in fragment order
+ * md_wino_pack_weights: Conv3d weight fp32 -> transformed, split tiles in fragment order; element (row, k, tap t27 = (kd*3+kh)*3+kw)
+ *   is read at w[row*s_row + k*s_k + t27] ([Cout][Cin][3][3][3]: s_row = Cin*27, s_k = 27, flip = 0) or, with flip = 1, at
+ *   w[row*s_row + k*s_k + 26 - t27] (the data-gradient conv of W[Co][Ci][27]: cout = Ci, cin = Co, s_row = 27, s_k = Ci*27)
  *   [Cout/128][Cin/16][kd*3+kh][4][row tile 4][plane 2][k-group 2][row 32][8 bf16]  (md_wino_weight_bytes)
  * md_conv3_wino: out F32B [B][cout/8][P][8] = conv(T, wpk) + bias[b*bias_bstride + co] + residual; stats as in MdGemmConvArgs
  *   Supported: cout % 128 == 0, cin % 32 == 0, D % 4 == 0, H % 8 == 0, W % 8 == 0, D*H*W < 2^28; else MD_ERR_UNSUPPORTED.
@@ -271,7 +273,8 @@ int64_t md_wino_operand_bytes(int32_t batch, int32_t cin, int32_t D, int32_t H, 
 int md_wino_prep(const float* x1, const float* x2, int32_t c1, int32_t c2, const float* ac, int32_t silu, int32_t ups,
                  void* t_out, int32_t batch, int32_t D, int32_t H, int32_t W, void* stream);
 int64_t md_wino_weight_bytes(int32_t cout, int32_t cin);
-int md_wino_pack_weights(const float* w, void* wpk, int32_t cout, int32_t cin, void* stream);
+int md_wino_pack_weights(const float* w, void* wpk, int32_t cout, int32_t cin, int64_t s_row, int64_t s_k, int32_t flip,
+                         void* stream);
 int md_conv3_wino(const void* t_in, const void* wpk, float* out, const float* bias, int64_t bias_bstride,
                   const float* residual, int64_t res_bstride, double* stats, int32_t batch, int32_t cin, int32_t cout,
                   int32_t D, int32_t H, int32_t W, int32_t variant, void* stream);

@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) void md_wino_prep_kernel(const float* __restri
 //   layout [cout/128][cin/16][tap (kd,kh) 9][f 4][row tile 4][plane 2][h 2][row 32][8 bf16]
 // ------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void md_wino_pack_weights_kernel(const float* __restrict__ w, uint4* __restrict__ wpk,
-                                                                   int cout, int cin) {
+                                                                   int cout, int cin, int64_t s_row, int64_t s_k, int flip) {
   const int64_t n = (int64_t)cout * cin * 36 / 4;        // items: cout * cin * 36 values * 2 planes / 8
   const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (id >= n) return;
@@ -144,8 +144,11 @@ __global__ __launch_bounds__(256) void md_wino_pack_weights_kernel(const float* 
 #pragma unroll
     for (int e2 = 0; e2 < 2; ++e2) {
       const int ci = chunk * 16 + h * 8 + 2 * q + e2;
-      const float* g = w + (((int64_t)co * cin + ci) * 9 + tap) * 3;
-      const float g0 = g[0], g1 = g[1], g2 = g[2];
+      // element (row, k, kd, kh, kw) of the convolution being packed = w[row * s_row + k * s_k + t27], t27 = (kd*3+kh)*3+kw,
+      // or 26 - t27 when `flip` (data gradient: W'[ci][co][t] = W[co][ci][26 - t], read in place)
+      const float* g = w + (int64_t)co * s_row + (int64_t)ci * s_k;
+      const int t0 = tap * 3;
+      const float g0 = g[flip ? 26 - t0 : t0], g1 = g[flip ? 25 - t0 : t0 + 1], g2 = g[flip ? 24 - t0 : t0 + 2];
       const float G = f == 0 ? g0 : f == 1 ? (g0 + g1 + g2) * 0.5f : f == 2 ? (g0 - g1 + g2) * 0.5f : g2;
       uint32_t hi, lo;
       md_split(G, hi, lo);
@@ -480,12 +483,13 @@ extern "C" int64_t md_wino_weight_bytes(int32_t cout, int32_t cin) {
   return (int64_t)cout * cin * 36 * 4;
 }
 
-extern "C" int md_wino_pack_weights(const float* w, void* wpk, int32_t cout, int32_t cin, void* stream) {
+extern "C" int md_wino_pack_weights(const float* w, void* wpk, int32_t cout, int32_t cin, int64_t s_row, int64_t s_k,
+                                    int32_t flip, void* stream) {
   if (!w || !wpk || cout <= 0 || cin <= 0 || (cout % 128) || (cin % 32)) return MD_ERR_BAD_ARG;
   const int64_t n = (int64_t)cout * cin * 9;
   MD_HIP_CLEAR_ERROR();
   hipLaunchKernelGGL(md_wino_pack_weights_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w,
-                     (uint4*)wpk, cout, cin);
+                     (uint4*)wpk, cout, cin, s_row, s_k, flip);
   MD_HIP_CHECK_LAUNCH();
   return MD_OK;
 }

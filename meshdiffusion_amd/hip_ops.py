@@ -214,19 +214,28 @@ WINO = os.environ.get("MD_WINO", "1") == "1"   # A/B switch: md_wino_prep + md_c
 
 
 class WinoWeight:
-    """Conv3d weight [Co][Ci][3][3][3] -> G-transformed split-bf16 fragment tiles (md_wino_pack_weights)."""
+    """Conv3d weight [Co][Ci][3][3][3] -> G-transformed split-bf16 fragment tiles (md_wino_pack_weights).
+    kind "conv": the forward convolution; "conv_dgrad": its data gradient W'[ci][co][t] = W[co][ci][26 - t], read in place."""
 
-    def __init__(self, w, device):
+    def __init__(self, w, device, kind="conv"):
         lib = _lib.load()
         w = w.detach().to(device=device, dtype=torch.float32).contiguous()
         _require_cuda(w, "weight")
         assert w.dim() == 5 and tuple(w.shape[2:]) == (3, 3, 3)
-        self.rows, self.kdim = w.shape[0], w.shape[1]
+        if kind == "conv":
+            self.rows, self.kdim = w.shape[0], w.shape[1]
+            s_row, s_k, flip = self.kdim * 27, 27, 0
+        elif kind == "conv_dgrad":
+            self.rows, self.kdim = w.shape[1], w.shape[0]
+            s_row, s_k, flip = 27, self.rows * 27, 1
+        else:
+            raise ValueError(kind)
         nbytes = lib.md_wino_weight_bytes(self.rows, self.kdim)
         if nbytes <= 0:
             raise _lib.MeshDiffusionHipError("md_wino_weight_bytes: unsupported weight shape")
         self.data = torch.empty(nbytes // 2, dtype=torch.bfloat16, device=device)
-        check(lib.md_wino_pack_weights(_ptr(w), _ptr(self.data), self.rows, self.kdim, _stream()), "md_wino_pack_weights")
+        check(lib.md_wino_pack_weights(_ptr(w), _ptr(self.data), self.rows, self.kdim, s_row, s_k, flip, _stream()),
+              "md_wino_pack_weights")
 
 
 def wino_ok(rows, kdim, S, B):

@@ -167,6 +167,12 @@ def dgrad_weight(layer, name, conv, cfg):
     return layer._cached(f"{name}/dgrad{cfg}", [conv.weight], build)
 
 
+def dgrad_wino_weight(layer, name, conv):
+    """Winograd tiles of the data-gradient conv (hip_ops.WinoWeight, kind "conv_dgrad")."""
+    return layer._cached(f"{name}/dgrad_wino", [conv.weight],
+                         lambda: ops.WinoWeight(conv.weight, conv.weight.device, kind="conv_dgrad"))
+
+
 def conv3_backward(layer, name, conv, dy, act_s16, B, S_out, ups=0, stride=1, need_dx=True, act_channels=None,
                    bias_sums=None, shared=None):
     """Backward of y = conv k^3 (act) (+bias), k = 3 (any layer) or 5 (stem / head of ddpm_res128, stride 1).
@@ -207,6 +213,14 @@ def conv3_backward(layer, name, conv, dy, act_s16, B, S_out, ups=0, stride=1, ne
         cfg = ops.conv_cfg_for(S_fine)
         pw = dgrad_weight(layer, name, conv, cfg)
         return layers.run_conv3(pw, split_f32b(dyz, B, co_t, S_fine ** 3), B, S_fine)
+    if ksz == 3 and co == co_t and ops.wino_ok(ci, co, S_out, B):
+        # Winograd path (2/3 of the MFMA work): the operand pass reads dy as it is (fp32, no affine) in place of the bf16 split
+        t = ops.wino_prep([(dy, co)], None, False, False, B, S_out)
+        dx = ops.conv3_wino(dgrad_wino_weight(layer, name, conv), t, B, S_out)
+        del t
+        if ups:
+            dx = resample(dx, B, ci, S_out // 2, 0)
+        return dx
     cfg = ops.conv_cfg_for(S_out)
     k16 = ops.CFG_C3_128_K16 if ksz == 3 else ops.CFG_C5_128_K16
     if ksz == 5:

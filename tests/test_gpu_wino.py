@@ -127,6 +127,22 @@ def test_conv3_wino_full_tiles_bitwise_repeatable_and_vs_direct(ops):
     assert e < 2e-5
 
 
+def test_conv3_wino_data_gradient_weights(ops):
+    """kind "conv_dgrad": the tiles of W'[ci][co][t] = W[co][ci][26 - t] packed in place from W -- the Winograd conv of dy with
+    them is the input gradient of F.conv3d (training backward, lib/diffusion/models/backward.py conv3_backward)."""
+    B, S, ci, co = 2, 16, 128, 160
+    w = _rand((co, ci, 3, 3, 3), 70, 0.05)
+    dy = _rand((B, co, S, S, S), 71)
+    ww = ops.WinoWeight(w.cuda(), "cuda", kind="conv_dgrad")
+    assert (ww.rows, ww.kdim) == (ci, co)
+    t = ops.wino_prep([(ops.ncdhw_to_f32b(dy.cuda()), co)], None, False, False, B, S)
+    dx = ops.f32b_to_ncdhw(ops.conv3_wino(ww, t, B, S), (S, S, S)).cpu()
+    ref = torch.nn.grad.conv3d_input((B, ci, S, S, S), w, dy, padding=1)
+    e = rel_l2(dx, ref)
+    print(f"wino data gradient: vs torch {e:.2e}")
+    assert e < TOL_MFMA
+
+
 def test_conv3_wino_rejects_unsupported_shapes(ops):
     from meshdiffusion_amd import _lib
     lib = _lib.load()
