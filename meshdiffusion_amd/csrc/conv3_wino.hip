@@ -173,7 +173,8 @@ struct WnArgs {
   int batch, cin, cout, D, H, W;
 };
 
-// ABL (timing only, results invalid; -DMD_BUILD_ABLATIONS, tools/bench_wino.py): bit 0 no halo traffic, bit 3 no LDS fragment
+// ABL (timing only, results invalid; -DMD_BUILD_ABLATIONS, tools/bench_wino.py): bit 0 no halo traffic, bit 1 halo traffic in the
+//   prologue only (real data stays in LDS), bit 2 weight loads in the prologue only (three real sets reused), bit 3 no LDS fragment
 //   reads, bit 4 no epilogue, bit 5 halo read from a private L2-resident 30 KB, bit 6 halo read as a private contiguous
 //   HBM stream.  NOTE: with bit 0 / 3 the MFMAs run on constant operands and the chip clocks higher (data-dependent power):
 //   such runs bound the MFMA time from below, they do not price the removed traffic.
@@ -270,8 +271,13 @@ __global__ __launch_bounds__(WN_THREADS) void md_conv3_wino_kernel(const WnArgs 
     for (int k = 0; k < WN_NDMA; ++k) h0[k] = halo_load(0, k);
     load_A(0, Ar[0]);
     load_A(nsteps > 1 ? 1 : 0, Ar[1]);
+    if constexpr (ABL & 4) load_A(nsteps > 2 ? 2 : 0, Ar[2]);      // timing only: three real weight sets, reused for every step
 #pragma unroll
     for (int k = 0; k < WN_NDMA; ++k) halo_store(0, k, h0[k]);
+    if constexpr (ABL & 2) {      // timing only: real data in both buffers, no halo traffic after this
+#pragma unroll
+      for (int k = 0; k < WN_NDMA; ++k) halo_store(1, k, h0[k]);
+    }
   }
   read_B(0, 0, Bf[0], true);
 
@@ -297,7 +303,7 @@ __global__ __launch_bounds__(WN_THREADS) void md_conv3_wino_kernel(const WnArgs 
       const int sw = s + 2 < nsteps ? s + 2 : nsteps - 1;                     // clamped: the redundant tail requests are never used
       const int cn = c0 + cpar + 1 < nchunk ? c0 + cpar + 1 : nchunk - 1;     // clamped likewise
       bf16x8 (&Aw)[8] = Ar[u % 3], (&Bc)[8] = Bf[u & 1], (&Bn)[8] = Bf[(u + 1) & 1];
-      load_A(sw, Ar[(u + 2) % 3]);
+      if constexpr (!(ABL & 4)) load_A(sw, Ar[(u + 2) % 3]);
       if (tap < 8) read_B(tap + 1, cpar, Bn, false);
       else read_B(0, cpar ^ 1, Bn, false);
 #pragma unroll
@@ -310,11 +316,11 @@ __global__ __launch_bounds__(WN_THREADS) void md_conv3_wino_kernel(const WnArgs 
         __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
-      if (tap >= 2 && tap <= 6) {
+      if (tap >= 2 && tap <= 6 && !(ABL & 2)) {
 #pragma unroll
         for (int q = 0; q < 3; ++q) halo_store(cpar ^ 1, (tap - 2) * 3 + q, hst[tap & 1][q]);
       }
-      if (tap <= 4) {
+      if (tap <= 4 && !(ABL & 2)) {
 #pragma unroll
         for (int q = 0; q < 3; ++q) hst[tap & 1][q] = halo_load(cn, tap * 3 + q);
       }
@@ -513,6 +519,10 @@ extern "C" int md_conv3_wino(const void* t_in, const void* wpk, float* out, cons
     case 0: WN_LAUNCH(0); break;
 #ifdef MD_BUILD_ABLATIONS      // timing-only variants for tools/bench_wino.py
     case 1: WN_LAUNCH(1); break;
+    case 2: WN_LAUNCH(2); break;
+    case 4: WN_LAUNCH(4); break;
+    case 6: WN_LAUNCH(6); break;
+    case 22: WN_LAUNCH(22); break;
     case 9: WN_LAUNCH(9); break;
     case 16: WN_LAUNCH(16); break;
     case 25: WN_LAUNCH(25); break;

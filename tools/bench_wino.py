@@ -13,7 +13,8 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from meshdiffusion_amd import hip_ops as ops  # noqa: E402
 
-VARIANTS = {0: "production", 1: "abl: no halo traffic (constant operands: clocks higher)", 9: "abl: no halo, no LDS reads",
+VARIANTS = {0: "production", 2: "abl: halo traffic in the prologue only (real data)", 4: "abl: weight loads in the prologue only (real data)",
+            6: "abl: halo + weights in the prologue only (real data)", 22: "abl: 6 + no epilogue", 1: "abl: no halo traffic (constant operands: clocks higher)", 9: "abl: no halo, no LDS reads",
             16: "abl: no epilogue", 25: "abl: MFMA loop + weight loads only, no epilogue",
             32: "abl: halo from a private L2-resident 30 KB", 64: "abl: halo as a private contiguous HBM stream"}
 
