@@ -43,3 +43,26 @@ y = torch.stack([m[0] + m[1] + m[2], m[1] - m[2] - m[3]], -1).reshape(B, Co, S, 
 print("wino-w fp32 rel", float((y.double() - ref).norm() / ref.norm()))
 d32 = F.conv3d(x, w, padding=1)
 print("direct fp32 rel", float((d32.double() - ref).norm() / ref.norm()))
+
+# ---- F(4,3) along w (6 products per 4 outputs): the same measurement, for the next-round note in DESIGN.md section 8 ----
+BT = torch.tensor([[4, 0, -5, 0, 1, 0], [0, -4, -4, 1, 1, 0], [0, 4, -4, -1, 1, 0],
+                   [0, -2, -1, 2, 1, 0], [0, 2, -1, -2, 1, 0], [0, 4, 0, -5, 0, 1]], dtype=torch.float32)
+Gm = torch.tensor([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6],
+                   [1 / 24, 1 / 12, 1 / 6], [1 / 24, -1 / 12, 1 / 6], [0, 0, 1]], dtype=torch.float32)
+AT = torch.tensor([[1, 1, 1, 1, 1, 0], [0, 1, -1, 2, -2, 0], [0, 1, 1, 4, 4, 0], [0, 1, -1, 8, -8, 1]], dtype=torch.float32)
+nq = S // 4
+dq = torch.stack([xp[..., k:k + 4 * (nq - 1) + 1:4] for k in range(6)], -1)          # [B,C,S+2,S+2,S/4,6]: inputs 4i-1 .. 4i+4
+T6 = torch.einsum("fk,...k->...f", BT, dq)                                            # transformed inputs
+G6 = torch.einsum("fk,oihwk->oihwf", Gm, w)                                           # transformed weights [Co,Ci,3,3,6]
+for name, sp in (("bf16x3", True), ("fp32", False)):
+    ms = []
+    for f in range(6):
+        t, g = T6[..., f], G6[..., f][..., None]
+        if sp:
+            th, tl = split(t); gh, gl = split(g)
+            ms.append(F.conv3d(th, gh) + F.conv3d(th, gl) + F.conv3d(tl, gh))
+        else:
+            ms.append(F.conv3d(t, g))
+    M = torch.stack(ms, -1)                                                            # [B,Co,S,S,S/4,6]
+    y4 = torch.einsum("jf,...f->...j", AT, M).reshape(B, Co, S, S, S)
+    print(f"wino-w F(4,3) {name} rel", float((y4.double() - ref).norm() / ref.norm()))
