@@ -261,6 +261,8 @@ int md_nin_f32(const float* x1, const float* x2, int32_t c1, int32_t c2, const v
  *   x1, x2 : F32B [B][c1/8][Pin][8], [B][c2/8][Pin][8] (x2 NULL when c2 = 0); Pin = D*H*W, or D*H*W/8 with ups = 1
  *   ac     : [B][C][2] folded GroupNorm affine of md_gn_finalize (y = x*ac[c][0] + ac[c][1]), or NULL: no affine, no SiLU
  *   D, H, W: OUTPUT grid of the convolution (W even); md_wino_operand_bytes gives the size of T
+ *   drop_p > 0 (training, one part, no upsampling): nn.Dropout after SiLU with the mask of md_gn_apply for the same
+ *            (drop_p, drop_seed) -- the forward conv and the taped activation see the same zeros
  * md_wino_pack_weights: Conv3d weight fp32 -> transformed, split tiles in fragment order; element (row, k, tap t27 = (kd*3+kh)*3+kw)
  *   is read at w[row*s_row + k*s_k + t27] ([Cout][Cin][3][3][3]: s_row = Cin*27, s_k = 27, flip = 0) or, with flip = 1, at
  *   w[row*s_row + k*s_k + 26 - t27] (the data-gradient conv of W[Co][Ci][27]: cout = Ci, cin = Co, s_row = 27, s_k = Ci*27)
@@ -271,7 +273,7 @@ int md_nin_f32(const float* x1, const float* x2, int32_t c1, int32_t c2, const v
  */
 int64_t md_wino_operand_bytes(int32_t batch, int32_t cin, int32_t D, int32_t H, int32_t W);
 int md_wino_prep(const float* x1, const float* x2, int32_t c1, int32_t c2, const float* ac, int32_t silu, int32_t ups,
-                 void* t_out, int32_t batch, int32_t D, int32_t H, int32_t W, void* stream);
+                 void* t_out, int32_t batch, int32_t D, int32_t H, int32_t W, float drop_p, uint64_t drop_seed, void* stream);
 int64_t md_wino_weight_bytes(int32_t cout, int32_t cin);
 int md_wino_pack_weights(const float* w, void* wpk, int32_t cout, int32_t cin, int64_t s_row, int64_t s_k, int32_t flip,
                          void* stream);

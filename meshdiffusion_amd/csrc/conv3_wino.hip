@@ -54,7 +54,8 @@ __device__ __forceinline__ uint4 wn_gload16(const void* p) {
 // ------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void md_wino_prep_kernel(const float* __restrict__ x1, const float* __restrict__ x2,
                                                            int c1, int c2, const float* __restrict__ ac, int silu, int ups,
-                                                           uint4* __restrict__ T, int batch, int D, int H, int W) {
+                                                           uint4* __restrict__ T, int batch, int D, int H, int W,
+                                                           uint32_t thr16, float drop_scale, uint64_t seed) {
   const int Wp = W >> 1;
   const int64_t Ph = (int64_t)D * H * Wp;
   const int CG = (c1 + c2) >> 3;
@@ -87,10 +88,17 @@ __global__ __launch_bounds__(256) void md_wino_prep_kernel(const float* __restri
     const int xw = 2 * pr - 1 + q;
     const bool live = xw >= 0 && xw < W;             // the conv pads the ACTIVATED tensor with zeros
     f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
+    const int xs = ups ? (xw >> 1) : xw;
+    const int64_t spos = ((int64_t)zs * Hi + ys) * Wi + xs;
     if (live) {
-      const int xs = ups ? (xw >> 1) : xw;
-      const f32x4* p = (const f32x4*)(src + (((int64_t)zs * Hi + ys) * Wi + xs) * 8);
+      const f32x4* p = (const f32x4*)(src + spos * 8);
       v0 = p[0]; v1 = p[1];
+    }
+    uint64_t bits[2] = {0, 0};
+    if (thr16) {      // training: the dropout mask of md_gn_apply (same counter-based hash of (seed, sample, channel quad, position))
+      const uint64_t quad0 = (uint64_t)(((int64_t)b * (c1 + c2) + cg * 8) >> 2) * (uint64_t)Pin;
+      bits[0] = md_drop_bits(seed, quad0 + (uint64_t)spos);
+      bits[1] = md_drop_bits(seed, quad0 + (uint64_t)Pin + (uint64_t)spos);
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -99,6 +107,7 @@ __global__ __launch_bounds__(256) void md_wino_prep_kernel(const float* __restri
         yv = yv * a[e] + c[e];
         if (silu) yv = yv * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(yv * -1.4426950408889634f));
       }
+      if (thr16) yv = md_drop_keep(bits[e >> 2], e & 3, thr16) ? yv * drop_scale : 0.f;   // nn.Dropout (layers.py:682)
       d[q][e] = live ? yv : 0.f;
     }
   }
@@ -471,15 +480,17 @@ extern "C" int64_t md_wino_operand_bytes(int32_t batch, int32_t cin, int32_t D, 
 }
 
 extern "C" int md_wino_prep(const float* x1, const float* x2, int32_t c1, int32_t c2, const float* ac, int32_t silu,
-                            int32_t ups, void* t_out, int32_t batch, int32_t D, int32_t H, int32_t W, void* stream) {
+                            int32_t ups, void* t_out, int32_t batch, int32_t D, int32_t H, int32_t W, float drop_p,
+                            uint64_t drop_seed, void* stream) {
   if (!x1 || !t_out || batch <= 0 || c1 <= 0 || c2 < 0 || (c1 & 7) || (c2 & 7) || (c2 > 0 && !x2)) return MD_ERR_BAD_ARG;
+  if (!(drop_p >= 0.f && drop_p < 1.f) || (drop_p > 0.f && (ups || c2 > 0))) return MD_ERR_BAD_ARG;
   if (D <= 0 || H <= 0 || W <= 0 || (W & 1) || (ups && ((D | H | W) & 1))) return MD_ERR_BAD_ARG;
   const int64_t n = (int64_t)batch * ((c1 + c2) / 8) * D * H * (W / 2);
   const int64_t blocks = (n + 255) / 256;
   if (blocks > 0x7fffffff) return MD_ERR_UNSUPPORTED;
   MD_HIP_CLEAR_ERROR();
   hipLaunchKernelGGL(md_wino_prep_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x1, x2, c1, c2, ac, silu,
-                     ups, (uint4*)t_out, batch, D, H, W);
+                     ups, (uint4*)t_out, batch, D, H, W, md_drop_thr16(drop_p), 1.0f / (1.0f - drop_p), drop_seed);
   MD_HIP_CHECK_LAUNCH();
   return MD_OK;
 }

@@ -211,6 +211,7 @@ def gemm_conv(*, cfg, a, b, out, batch, rows, rows_alloc, kdim, dims, bias=None,
 # Winograd F(2,3)-along-w path of the 3x3x3 convolution (inference)
 # ---------------------------------------------------------------------------------------------
 WINO = os.environ.get("MD_WINO", "1") == "1"   # A/B switch: md_wino_prep + md_conv3_wino instead of the fused direct kernel
+WINO_TRAIN_FWD = os.environ.get("MD_WINO_TRAIN_FWD", "1") == "1"   # A/B switch: the same for the forward convs of a training step
 
 
 class WinoWeight:
@@ -244,19 +245,36 @@ def wino_ok(rows, kdim, S, B):
             and B * (S ** 3 // 256) * (rows // 128) >= 256)
 
 
-def wino_prep(parts, ac, silu, ups, B, S):
-    """fp32 F32B parts (+ folded GroupNorm affine, SiLU, nearest-x2 upsampling) -> transformed split operand T."""
+_WINO_SCRATCH = {}
+
+
+def _wino_scratch(n_bf16, device):
+    """T is written by md_wino_prep and read by the md_conv3_wino launched right after it on the same stream, so every
+    (prep, conv) pair of a process can share ONE buffer, grown to the largest operand seen: no multi-GB allocation per conv
+    (the caching allocator otherwise splits / re-merges 2-4 GB blocks among the training tape's tensors)."""
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
+    buf = _WINO_SCRATCH.get(key)
+    if buf is None or buf.numel() < n_bf16:
+        _WINO_SCRATCH.pop(key, None)
+        buf = None
+        buf = _WINO_SCRATCH[key] = torch.empty(n_bf16, dtype=torch.bfloat16, device=device)
+    return buf[:n_bf16]
+
+
+def wino_prep(parts, ac, silu, ups, B, S, drop=None):
+    """fp32 F32B parts (+ folded GroupNorm affine, SiLU, nearest-x2 upsampling) -> transformed split operand T.
+    drop = (p, seed): training dropout after SiLU, the mask gn_apply(drop=...) produces for the same pair."""
     lib = _lib.load()
     cin = sum(c for _, c in parts)
     assert 1 <= len(parts) <= 2
     nbytes = lib.md_wino_operand_bytes(B, cin, S, S, S)
     if nbytes <= 0:
         raise _lib.MeshDiffusionHipError("md_wino_operand_bytes: unsupported operand shape")
-    t = torch.empty(nbytes // 2, dtype=torch.bfloat16, device=parts[0][0].device)
+    t = _wino_scratch(nbytes // 2, parts[0][0].device)
     x2, c2 = (parts[1][0], parts[1][1]) if len(parts) == 2 else (None, 0)
     ev = _prof_begin()
     check(lib.md_wino_prep(_ptr(parts[0][0]), _ptr(x2), parts[0][1], c2, _ptr(ac), 1 if silu else 0, 1 if ups else 0,
-                           _ptr(t), B, S, S, S, _stream()), "md_wino_prep")
+                           _ptr(t), B, S, S, S, drop[0] if drop else 0.0, drop[1] if drop else 0, _stream()), "md_wino_prep")
     _prof_end(ev, "wino_prep", 0.0, 4.0 * B * cin * (S ** 3 // (8 if ups else 1)) + 8.0 * B * cin * S ** 3,   # fp32 in, 2 x bf16 x 2 out
               f"{cin}@{S}x{S}x{S}" + ("/ups" if ups else ""))
     return t

@@ -126,7 +126,9 @@ def run_conv3(pw, act_s16, B, S_out, *, bias=None, bias_bstride=0, residual=None
     """3x3x3 conv of an S16B activation tensor with packed weights `pw` on an S_out^3 output grid.
     want_stats: the output feeds a GroupNorm -- when the launch allows it (dedicated kernel, no split-K) its
     epilogue also accumulates the per-(sample, channel) sums, attached to the result as `_md_sums`.
-    b_f32 (see hip_ops.gemm_conv): fp32 parts + folded GroupNorm affine instead of `act_s16` (fused_operand_ok).
+    b_f32 (see hip_ops.gemm_conv): fp32 parts + folded GroupNorm affine instead of `act_s16` (fused_operand_ok); with
+    `wino_only` (training: `drop` = (p, seed) allowed) it only describes the operand of the Winograd path and the direct
+    kernel keeps reading `act_s16`.
     wino (with b_f32): builder of the layer's WinoWeight (conv3_wino_packed); where hip_ops.wino_ok says so the conv runs as
     md_wino_prep + md_conv3_wino (Winograd F(2,3) along w: 2/3 of the matrix-core work) instead of the direct kernel."""
     P = S_out ** 3
@@ -139,7 +141,7 @@ def run_conv3(pw, act_s16, B, S_out, *, bias=None, bias_bstride=0, residual=None
     if (b_f32 is not None and wino is not None and out_mode == ops.OUT_F32B and rows_alloc == pw.rows
             and pw.prec == ops.PREC_BF16X3 and ops.wino_ok(pw.rows, pw.kdim, S_out, B)):
         stats = torch.zeros((B, rows_alloc, 2), dtype=torch.float64, device=dev) if want_stats and ops.FUSE_GN_STATS else None
-        t = ops.wino_prep(b_f32["parts"], b_f32.get("ac"), b_f32.get("silu"), ups, B, S_out)
+        t = ops.wino_prep(b_f32["parts"], b_f32.get("ac"), b_f32.get("silu"), ups, B, S_out, drop=b_f32.get("drop"))
         ops.conv3_wino(wino(), t, B, S_out, bias=bias, bias_bstride=bias_bstride, residual=residual,
                        res_bstride=res_bstride or 0, stats=stats, out=out)
         if stats is not None:
@@ -147,6 +149,8 @@ def run_conv3(pw, act_s16, B, S_out, *, bias=None, bias_bstride=0, residual=None
         elif hasattr(out, "_md_sums"):
             del out._md_sums
         return out
+    if b_f32 is not None and b_f32.get("wino_only"):
+        b_f32 = None                     # training: the direct kernel takes the taped S16B activation (`act_s16`)
     ksplit = ops.ksplit_for(pw.cfg, B, pw.rows, pw.kdim, S_out) if out_mode == ops.OUT_F32B else 1
     stats = None
     if (want_stats and ops.FUSE_GN_STATS and pw.cfg == ops.CFG_C3_128_FAST and ksplit == 1
@@ -292,10 +296,14 @@ class Upsample(HipLayer):
             return run_conv3(pw, None, B, s_out, bias=self.Conv_0.bias, ups=1, want_stats=True,
                              b_f32=dict(parts=[(x, Cc)], ac=None, silu=False), wino=conv3_wino_packed(self, "w", self.Conv_0))
         act = ops.gn_apply([(x, Cc)], None, B, P, norm=False, silu=False, fp16=pw.prec == ops.PREC_FP16X2)
+        fw = None
         if tape is not None:
             assert pw.prec == ops.PREC_BF16X3
             tape.append(dict(layer=self, act=act, B=B, S_out=s_out))
-        return run_conv3(pw, act, B, s_out, bias=self.Conv_0.bias, ups=1, want_stats=True)
+            if ops.WINO_TRAIN_FWD:
+                fw = dict(parts=[(x, Cc)], ac=None, silu=False, wino_only=True)
+        return run_conv3(pw, act, B, s_out, bias=self.Conv_0.bias, ups=1, want_stats=True, b_f32=fw,
+                         wino=conv3_wino_packed(self, "w", self.Conv_0) if fw is not None else None)
 
     def backward_blocked(self, sv, dy):
         from . import backward as bw
@@ -399,7 +407,12 @@ class ResnetBlockDDPM(HipLayer):
             _, ac1 = ops.gn_params([(h, self.out_ch)], g1.weight, g1.bias, B, P, eps=g1.eps, groups=g1.num_groups, want_ac=True)
             return run_conv3(pw1, None, B, S, bias=self.Conv_1.bias, residual=res, want_stats=True,
                              b_f32=dict(parts=[(h, self.out_ch)], ac=ac1, silu=True), wino=conv3_wino_packed(self, "w1", self.Conv_1))
-        prm = ops.gn_params(parts, g0.weight, g0.bias, B, P, eps=g0.eps, groups=g0.num_groups)
+        # training (tape): the convs go through the Winograd path where it applies (its operand pass repeats GroupNorm + SiLU
+        # + dropout from the fp32 tensors); the S16B activations are still written: the weight gradients read them
+        wino_fwd = tape is not None and not f16 and ops.WINO_TRAIN_FWD
+        prm, ac0 = ops.gn_params(parts, g0.weight, g0.bias, B, P, eps=g0.eps, groups=g0.num_groups, want_ac=True)
+        f0 = dict(parts=parts, ac=ac0, silu=True, wino_only=True) if wino_fwd else None
+        w0 = conv3_wino_packed(self, "w0", self.Conv_0) if f0 is not None else None
         a0 = ops.gn_apply(parts, prm, B, P, norm=True, silu=True, fp16=f16, want_raw=need_nin)
         xs = None
         res = None
@@ -415,14 +428,16 @@ class ResnetBlockDDPM(HipLayer):
                 res.record_stream(main)
                 xs.record_stream(side)
         if bias0 is not None:
-            h = run_conv3(pw0, a0, B, S, bias=bias0, bias_bstride=bias0_stride, want_stats=True)
+            h = run_conv3(pw0, a0, B, S, bias=bias0, bias_bstride=bias0_stride, want_stats=True, b_f32=f0, wino=w0)
         elif temb is not None:   # per-(sample, channel) additive bias = Conv_0.b + Dense_0(SiLU(temb))
             bias0 = ops.linear(temb, self.Dense_0.weight, self._bias0(), silu_in=True)
-            h = run_conv3(pw0, a0, B, S, bias=bias0, bias_bstride=self.out_ch, want_stats=True)
+            h = run_conv3(pw0, a0, B, S, bias=bias0, bias_bstride=self.out_ch, want_stats=True, b_f32=f0, wino=w0)
         else:
-            h = run_conv3(pw0, a0, B, S, bias=self.Conv_0.bias, want_stats=True)
-        prm1 = ops.gn_params([(h, self.out_ch)], g1.weight, g1.bias, B, P, eps=g1.eps, groups=g1.num_groups)
+            h = run_conv3(pw0, a0, B, S, bias=self.Conv_0.bias, want_stats=True, b_f32=f0, wino=w0)
+        prm1, ac1 = ops.gn_params([(h, self.out_ch)], g1.weight, g1.bias, B, P, eps=g1.eps, groups=g1.num_groups, want_ac=True)
         a1 = ops.gn_apply([(h, self.out_ch)], prm1, B, P, norm=True, silu=True, fp16=f16, drop=drop)
+        f1 = dict(parts=[(h, self.out_ch)], ac=ac1, silu=True, drop=drop, wino_only=True) if wino_fwd else None
+        w1 = conv3_wino_packed(self, "w1", self.Conv_1) if f1 is not None else None
         if need_nin:
             if res is None:
                 res = self.NIN_0.forward_s16(xs, B, P)
@@ -435,7 +450,7 @@ class ResnetBlockDDPM(HipLayer):
             assert not f16, "the backward pass uses the bf16x3 operand format"
             tape.append(dict(layer=self, parts=parts, prm0=prm, a0=a0, h=h, prm1=prm1, a1=a1, xs=xs, B=B, P=P, S=S,
                              temb=temb, drop=drop))
-        return run_conv3(pw1, a1, B, S, bias=self.Conv_1.bias, residual=res, want_stats=True)
+        return run_conv3(pw1, a1, B, S, bias=self.Conv_1.bias, residual=res, want_stats=True, b_f32=f1, wino=w1)
 
     def backward_blocked(self, sv, dy):
         """dy: F32B [B][out_ch][P].  Returns ([grad per input part], dbias0 [B, out_ch]); accumulates .grad of
