@@ -88,10 +88,11 @@ def s16b_empty(B, Cc, P, device):
 # weights
 # ---------------------------------------------------------------------------------------------
 class PackedWeight:
-    """Split-bf16 WPK tiles of one conv / NIN weight (built on the device by md_pack_weights)."""
+    """Split-bf16 WPK tiles of one conv / NIN weight (built on the device by md_pack_weights).  The tiles are packed on the
+    first access of `.data`: a layer whose convolution runs through the Winograd path never packs its direct tiles (in
+    training every weight version would otherwise be packed twice per step)."""
 
     def __init__(self, w, kind, cfg, device, prec=PREC_BF16X3):
-        lib = _lib.load()
         self.prec = prec
         nt, kc = CFG_NT_KC[cfg]
         w = w.detach().to(device=device, dtype=torch.float32).contiguous()
@@ -116,13 +117,23 @@ class PackedWeight:
             raise ValueError(kind)
         self.rows, self.taps, self.cfg = rows, taps, cfg
         self.kdim = ((kdim + kc - 1) // kc) * kc  # K padded to the chunk size (zero filled)
-        nbytes = lib.md_packed_weight_bytes(rows, kdim, taps, nt, kc)
-        if nbytes <= 0:
-            raise _lib.MeshDiffusionHipError("md_packed_weight_bytes failed")
-        self.data = torch.empty(nbytes // 2, dtype=torch.bfloat16, device=device)
-        wp = C.c_void_p(w.data_ptr() + 4 * base_off)
-        check(lib.md_pack_weights(wp, _ptr(self.data), rows, kdim, taps, s_row, s_k, s_tap, nt, kc,
-                                  prec, _stream()), "md_pack_weights")
+        self._src = (w, rows, kdim, taps, s_row, s_k, s_tap, nt, kc, base_off)   # `w` is this weight version (cache key)
+        self._data = None
+
+    @property
+    def data(self):
+        if self._data is None:
+            lib = _lib.load()
+            w, rows, kdim, taps, s_row, s_k, s_tap, nt, kc, base_off = self._src
+            nbytes = lib.md_packed_weight_bytes(rows, kdim, taps, nt, kc)
+            if nbytes <= 0:
+                raise _lib.MeshDiffusionHipError("md_packed_weight_bytes failed")
+            self._data = torch.empty(nbytes // 2, dtype=torch.bfloat16, device=w.device)
+            wp = C.c_void_p(w.data_ptr() + 4 * base_off)
+            check(lib.md_pack_weights(wp, _ptr(self._data), rows, kdim, taps, s_row, s_k, s_tap, nt, kc,
+                                      self.prec, _stream()), "md_pack_weights")
+            self._src = None
+        return self._data
 
 
 def pack_s16b_from_matrix(w_kp, device):
