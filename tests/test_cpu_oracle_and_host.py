@@ -132,6 +132,13 @@ def test_bad_arguments_are_rejected_without_a_gpu(hip_lib):
     assert hip_lib.md_gemm_conv(ctypes.byref(a), None) == -1
     assert hip_lib.md_packed_weight_bytes(128, 128, 27, 128, 32) == 128 * 128 * 27 * 4
     assert hip_lib.md_marching_tets_workspace_bytes(0, 5) < 0
+    # Winograd path: operand T = 8 bytes per input element, weight tiles = 36/27 of the fp32 weight; shapes it does not take
+    assert hip_lib.md_wino_operand_bytes(8, 128, 64, 64, 64) == 8 * 128 * 64 ** 3 * 8
+    assert hip_lib.md_wino_weight_bytes(128, 256) == 128 * 256 * 36 * 4
+    assert hip_lib.md_wino_operand_bytes(1, 12, 8, 8, 8) < 0 and hip_lib.md_wino_operand_bytes(1, 16, 8, 8, 7) < 0
+    assert hip_lib.md_wino_weight_bytes(96, 64) < 0 and hip_lib.md_wino_weight_bytes(128, 48) < 0
+    assert hip_lib.md_wino_prep(None, None, 8, 0, None, 0, 0, None, 1, 8, 8, 8, 0.0, 0, None) == -1
+    assert hip_lib.md_conv3_wino(None, None, None, None, 0, None, 0, None, 1, 32, 128, 8, 8, 8, 0, None) == -1
 
 
 def test_hip_path_refuses_cpu_tensors():

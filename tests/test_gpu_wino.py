@@ -127,6 +127,27 @@ def test_conv3_wino_full_tiles_bitwise_repeatable_and_vs_direct(ops):
     assert e < 2e-5
 
 
+@pytest.mark.parametrize("kind", ["conv", "conv_dgrad"])
+def test_wino_pack_weights_layout(ops, kind):
+    """md_wino_pack_weights: tiles [rows/128][K/16][kd*3+kh][f 4][row tile 4][plane 2][k-group 2][row 32][8 bf16] of
+    G g = (g0, (g0+g1+g2)/2, (g0-g1+g2)/2, g2) along kw, split into bf16 hi / lo (RNE) -- bit-exact against the same
+    arithmetic in torch, for the forward weights and for the data-gradient weights W'[ci][co][t] = W[co][ci][26 - t]."""
+    co, ci = (128, 64) if kind == "conv" else (96, 256)
+    w = _rand((co, ci, 3, 3, 3), 80, 0.1)
+    ww = ops.WinoWeight(w.cuda(), "cuda", kind=kind)
+    weff = w if kind == "conv" else w.reshape(co, ci, 27).flip(2).transpose(0, 1).reshape(ci, co, 3, 3, 3)
+    rows, K = weff.shape[0], weff.shape[1]
+    assert (ww.rows, ww.kdim) == (rows, K)
+    g0, g1, g2 = weff[..., 0], weff[..., 1], weff[..., 2]
+    G = torch.stack([g0, (g0 + g1 + g2) * 0.5, (g0 - g1 + g2) * 0.5, g2], -1)          # [rows, K, 3, 3, 4] fp32
+    hi, lo = _split_bf16(G)
+    planes = torch.stack([hi, lo], 0)                                                     # [plane, rows, K, kd, kh, f]
+    t = planes.reshape(2, rows // 128, 4, 32, K // 16, 2, 8, 9, 4)                        # plane, ct, rt, row, chunk, h, e, tap, f
+    want = t.permute(1, 4, 7, 8, 2, 0, 5, 3, 6).contiguous()                             # ct, chunk, tap, f, rt, plane, h, row, e
+    got = ww.data.cpu().view(rows // 128, K // 16, 9, 4, 4, 2, 2, 32, 8)
+    assert torch.equal(got.view(torch.int16), want.view(torch.int16))
+
+
 def test_conv3_wino_data_gradient_weights(ops):
     """kind "conv_dgrad": the tiles of W'[ci][co][t] = W[co][ci][26 - t] packed in place from W -- the Winograd conv of dy with
     them is the input gradient of F.conv3d (training backward, lib/diffusion/models/backward.py conv3_backward)."""
