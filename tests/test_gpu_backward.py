@@ -113,6 +113,67 @@ def test_resnet_block_dropout_forward_backward(hip_lib):
     assert rel_l2(ops.f32b_to_ncdhw(y_eval, (S, S, S)).cpu(), uo.resnet_block(sd, x, temb)) < 1e-4
 
 
+def test_resnet_block_training_through_winograd_path(hip_lib):
+    """A block big enough for the Winograd path (hip_ops.wino_ok: 256 workgroups) in TRAINING mode: two-part input
+    (torch.cat of a skip connection), FiLM, dropout 0.1 -- forward convs (md_wino_prep with the dropout mask of md_gn_apply +
+    md_conv3_wino) and data-gradient convs (conv_dgrad tiles) against torch autograd through the oracle with the same
+    explicit mask; the launches are checked to be the Winograd kernels, and the direct path must give the same numbers."""
+    from meshdiffusion_amd import hip_ops as ops
+    from meshdiffusion_amd.lib.diffusion.models import layers
+    from oracle import unet_oracle as uo
+    B, cin_parts, cout, S, p = 16, (128, 128), 128, 16, 0.1
+    cin, P = sum(cin_parts), S ** 3
+    assert ops.wino_ok(cout, cin, S, B) and ops.WINO and ops.WINO_TRAIN_FWD
+    blk = layers.ResnetBlockDDPM(act=torch.nn.SiLU(), in_ch=cin, out_ch=cout, temb_dim=128, dropout=p)
+    sd = _load(blk, 5)
+    blk = blk.cuda().train()
+    xs = [_randn((B, c, S, S, S), 20 + i) for i, c in enumerate(cin_parts)]
+    temb, dy = _randn((B, 128), 22), _randn((B, cout, S, S, S), 23)
+    parts = [(_f32b(ops, x), c) for x, c in zip(xs, cin_parts)]
+
+    def run():
+        for q in blk.parameters():
+            q.grad = None
+        tape = []
+        torch.manual_seed(99)
+        ops.PROFILE = []
+        try:
+            with torch.no_grad():
+                y = blk.forward_blocked(parts, B, P, temb.cuda(), tape=tape)
+                dparts, _ = blk.backward_blocked(tape[0], _f32b(ops, dy))
+            tags = [e[0] for e in ops.PROFILE]
+        finally:
+            ops.PROFILE = None
+        grads = {n: q.grad.clone() for n, q in blk.named_parameters() if q.grad is not None}
+        return y, dparts, grads, tape[0]["drop"], tags
+
+    y, dparts, grads, (pd, seed), tags = run()
+    assert tags.count("wino") == 4 and tags.count("wino_prep") == 4        # Conv_0, Conv_1 forward + their two data gradients
+    scale = ops.f32b_to_ncdhw(ops.dropout_scale(B, cout, P, p, seed, torch.device("cuda", 0)), (S, S, S)).cpu()
+    sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    xr = [x.clone().requires_grad_(True) for x in xs]
+    tr = temb.clone().requires_grad_(True)
+    y_ref = uo.resnet_block(sdr, torch.cat(xr, 1), tr, drop=scale)
+    y_ref.backward(dy)
+    assert rel_l2(ops.f32b_to_ncdhw(y, (S, S, S)).cpu(), y_ref.detach()) < 1e-4
+    for g, x in zip(dparts, xr):
+        assert rel_l2(ops.f32b_to_ncdhw(g, (S, S, S)).cpu(), x.grad) < TOL
+    for n in ["Conv_0.weight", "Conv_1.weight", "GroupNorm_0.weight", "GroupNorm_1.weight", "GroupNorm_1.bias", "NIN_0.W"]:
+        assert rel_l2(grads[n].cpu(), sdr[n].grad) < TOL, n
+    # the direct kernels on the same inputs and mask
+    ops.WINO = False
+    try:
+        y2, dparts2, grads2, drop2, tags2 = run()
+    finally:
+        ops.WINO = True
+    assert "wino" not in tags2 and drop2 == (pd, seed)
+    assert rel_l2(y.cpu(), y2.cpu()) < 2e-5
+    for g, g2 in zip(dparts, dparts2):
+        assert rel_l2(g.cpu(), g2.cpu()) < 5e-5
+    for n in grads:
+        assert rel_l2(grads[n].cpu(), grads2[n].cpu()) < 5e-5, n
+
+
 def test_up_down_nin_backward(hip_lib):
     from meshdiffusion_amd import hip_ops as ops
     from meshdiffusion_amd.lib.diffusion.models import backward as bw, layers
