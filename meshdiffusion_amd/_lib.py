@@ -72,6 +72,11 @@ SIGNATURES = {
     "md_wino_weight_bytes": (_I64, [_I32, _I32]),
     "md_wino_pack_weights": (C.c_int, [_P, _P, _I32, _I32, _I64, _I64, _I32, _P]),
     "md_conv3_wino": (C.c_int, [_P, _P, _P, _P, _I64, _P, _I64, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P]),
+    "md_wino43_operand_bytes": (_I64, [_I32, _I32, _I32, _I32, _I32]),
+    "md_wino43_prep": (C.c_int, [_P, _P, _I32, _I32, _P, _I32, _I32, _P, _I32, _I32, _I32, _I32, _P]),
+    "md_wino43_weight_bytes": (_I64, [_I32, _I32]),
+    "md_wino43_pack_weights": (C.c_int, [_P, _P, _I32, _I32, _I64, _I64, _I32, _P]),
+    "md_conv3_wino43": (C.c_int, [_P, _P, _P, _P, _I64, _P, _I64, _P, _I32, _I32, _I32, _I32, _I32, _I32, _P]),
     "md_attn_fwd": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _F, _P]),
     "md_softmax_keys": (C.c_int, [_P, _P, _I32, _I32, _I32, _P]),
     "md_ancestral_step": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I64, _P]),

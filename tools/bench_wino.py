@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--variants", default="0,1,9,16,25,32,64")
     ap.add_argument("--shapes", default="128:128:64:8,256:128:64:8,256:256:32:8,512:256:16:8")
     ap.add_argument("--out", default=None)
+    ap.add_argument("--f43", action="store_true", help="also time the experimental F(4,3) kernels (md_wino43_*)")
     ap.add_argument("--no-stats", action="store_true", help="launch without the GroupNorm-sum epilogue")
     ap.add_argument("--no-res", action="store_true", help="launch without the residual operand")
     a = ap.parse_args()
@@ -55,6 +56,20 @@ def main():
         ms_prep = timed(lambda: ops.wino_prep([(x, cin)], ac, True, False, B, S))
         rows.append(dict(shape=sh, kernel="md_wino_prep", ms=round(ms_prep, 4), gbs=round(12.0 * B * cin * S ** 3 / ms_prep / 1e6, 1)))
         print(json.dumps(rows[-1]), flush=True)
+        if a.f43:
+            ww43 = ops.WinoWeight43(w, dev)
+            t43 = ops.wino43_prep([(x, cin)], ac, True, False, B, S)
+            ms = timed(lambda: ops.wino43_prep([(x, cin)], ac, True, False, B, S))
+            rows.append(dict(shape=sh, kernel="md_wino43_prep", ms=round(ms, 4), gbs=round(10.0 * B * cin * S ** 3 / ms / 1e6, 1)))
+            print(json.dumps(rows[-1]), flush=True)
+            for rep in range(2):
+                ms = timed(lambda: ops.conv3_wino43(ww43, t43, B, S, bias=bias, bias_bstride=cout, residual=None if a.no_res else res,
+                                                    res_bstride=0 if a.no_res else cout * S ** 3,
+                                                    stats=None if a.no_stats else stats, out=out))
+                rows.append(dict(shape=sh, kernel="md_conv3_wino43", ms=round(ms, 4), tflops_alg=round(flops / ms / 1e9, 1),
+                                 issued_frac_of_peak=round(flops * 0.5 * 3 / ms / 1e9 / 2500.0, 4)))
+                print(json.dumps(rows[-1]), flush=True)
+            t = ops.wino_prep([(x, cin)], ac, True, False, B, S)      # the two paths share one scratch buffer: restore T
         for v in [int(k) for k in a.variants.split(",")]:
             try:
                 ms = timed(lambda: ops.conv3_wino(ww, t, B, S, bias=bias, bias_bstride=cout, residual=None if a.no_res else res,
