@@ -281,6 +281,11 @@ int md_conv3_wino(const void* t_in, const void* wpk, float* out, const float* bi
                   const float* residual, int64_t res_bstride, double* stats, int32_t batch, int32_t cin, int32_t cout,
                   int32_t D, int32_t H, int32_t W, int32_t variant, void* stream);
 
+/* md_wino_prep in two phases through LDS (csrc/wino_prep2.hip), bit-identical output, 13 % faster (the host package's default);
+ * additionally needs W | 256 and D*H*W % 256 == 0 (whole rows per workgroup), else MD_ERR_UNSUPPORTED. */
+int md_wino_prep_v2(const float* x1, const float* x2, int32_t c1, int32_t c2, const float* ac, int32_t silu, int32_t ups,
+                    void* t_out, int32_t batch, int32_t D, int32_t H, int32_t W, float drop_p, uint64_t drop_seed, void* stream);
+
 /*
  * EXPERIMENTAL (not used by default; MD_WINO43=1 in the host package): the same convolution through Winograd F(4,3) along w
  * (csrc/conv3_wino43.hip): 6 products per 4 outputs = 1/2 of the direct MFMA work, T = 1.5x the input

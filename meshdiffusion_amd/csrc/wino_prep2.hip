@@ -1,0 +1,129 @@
+// md_wino_prep in two phases through LDS (the host package's default where W divides 256; MD_WINO_PREP_V2=0: one thread per pair).  Same result, bit for bit, as
+// md_wino_prep_kernel (conv3_wino.hip: GroupNorm affine + SiLU (+ dropout) of lib/diffusion/models/layers.py:676-682, zero
+// pad, F(2,3) input transform along w, bf16 hi / lo split -> T[B][C/8][4][2][D][H][W/2][8]).
+//
+// md_wino_prep_kernel lets one thread own one output pair: it loads 4 positions (2 of them its neighbours'), so every
+// activation is computed twice and a 16-byte load touches 32 different cache lines per wave.  Here a workgroup takes 256
+// consecutive positions (whole rows: W divides 256) of one (sample, 8-channel group):
+//   phase 1  one POSITION per thread: 32 contiguous bytes (a wave reads 2 KB in a row), activation once, -> LDS (fp32)
+//   phase 2  one (pair, frequency half) per thread: waves 0-1 write d0-d2 and d1+d2, waves 2-3 d2-d1 and d1-d3 of the 128
+//            pairs, 3 positions each out of LDS; every store instruction writes 1 KB contiguous
+#include "md_common.h"
+
+namespace {
+constexpr int P2_POS = 256;               // positions per workgroup
+constexpr int P2_STRIDE = 12;             // floats per position in LDS (8 + pad: 48 B keeps 16-byte alignment, 2-way bank conflicts)
+}  // namespace
+
+__global__ __launch_bounds__(256) void md_wino_prep2_kernel(const float* __restrict__ x1, const float* __restrict__ x2,
+                                                            int c1, int c2, const float* __restrict__ ac, int silu, int ups,
+                                                            uint4* __restrict__ T, int batch, int D, int H, int W,
+                                                            uint32_t thr16, float drop_scale, uint64_t seed) {
+  __shared__ __attribute__((aligned(16))) float act[P2_POS * P2_STRIDE];
+  const int tid = threadIdx.x;
+  const int Wp = W >> 1;
+  const int64_t P = (int64_t)D * H * W, Ph = P >> 1;
+  const int CG = (c1 + c2) >> 3;
+  const int nblk = (int)(P / P2_POS);
+  const int blk = blockIdx.x % nblk;
+  const int cg = (blockIdx.x / nblk) % CG;
+  const int b = blockIdx.x / (nblk * CG);
+  int Di = D, Hi = H, Wi = W;
+  if (ups) { Di >>= 1; Hi >>= 1; Wi >>= 1; }
+  const int64_t Pin = (int64_t)Di * Hi * Wi;
+  const float* src = (cg * 8 < c1) ? x1 + ((int64_t)b * (c1 >> 3) + cg) * Pin * 8
+                                   : x2 + ((int64_t)b * (c2 >> 3) + (cg - (c1 >> 3))) * Pin * 8;
+  // ---- phase 1 ----------------------------------------------------------------------------------------------------
+  {
+    const int64_t p = (int64_t)blk * P2_POS + tid;                  // position of the OUTPUT grid
+    const int x = (int)(p % W), y = (int)((p / W) % H), z = (int)(p / ((int64_t)W * H));
+    const int64_t spos = ups ? ((int64_t)(z >> 1) * Hi + (y >> 1)) * Wi + (x >> 1) : p;
+    const f32x4* sp = (const f32x4*)(src + spos * 8);
+    const f32x4 v0 = sp[0], v1 = sp[1];
+    float a[8], c[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { a[e] = 1.f; c[e] = 0.f; }
+    if (ac != nullptr) {
+      const f32x4* ap = (const f32x4*)(ac + ((int64_t)b * (c1 + c2) + cg * 8) * 2);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 v = ap[q];
+        a[2 * q] = v[0]; c[2 * q] = v[1]; a[2 * q + 1] = v[2]; c[2 * q + 1] = v[3];
+      }
+    }
+    uint64_t bits[2] = {0, 0};
+    if (thr16) {
+      const uint64_t quad0 = (uint64_t)(((int64_t)b * (c1 + c2) + cg * 8) >> 2) * (uint64_t)Pin;
+      bits[0] = md_drop_bits(seed, quad0 + (uint64_t)spos);
+      bits[1] = md_drop_bits(seed, quad0 + (uint64_t)Pin + (uint64_t)spos);
+    }
+    float yv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float t = e < 4 ? v0[e] : v1[e - 4];
+      if (ac != nullptr) {
+        t = t * a[e] + c[e];
+        if (silu) t = t * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t * -1.4426950408889634f));
+      }
+      if (thr16) t = md_drop_keep(bits[e >> 2], e & 3, thr16) ? t * drop_scale : 0.f;
+      yv[e] = t;
+    }
+    float* dst = act + tid * P2_STRIDE;
+    *(f32x4*)dst = f32x4{yv[0], yv[1], yv[2], yv[3]};
+    *(f32x4*)(dst + 4) = f32x4{yv[4], yv[5], yv[6], yv[7]};
+  }
+  __syncthreads();
+  // ---- phase 2 ----------------------------------------------------------------------------------------------------
+  {
+    const int pi = tid & 127, fh = tid >> 7;                         // pair of the workgroup, frequency half (wave-uniform)
+    const int lp = 2 * pi;                                           // local position of the pair's first output
+    const int x = lp % W;                                            // x of that position (rows are whole)
+    // d_k = activated input at x - 1 + k; outside the row: zero (the conv pads the ACTIVATED tensor)
+    float d[4][8];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const bool need = fh == 0 ? k < 3 : k > 0;                     // half 0 uses d0 d1 d2, half 1 uses d1 d2 d3
+      const int xx = x - 1 + k;
+      const bool live = need && xx >= 0 && xx < W;
+      f32x4 u0 = {0.f, 0.f, 0.f, 0.f}, u1 = u0;
+      if (live) {
+        const float* s = act + (lp - 1 + k) * P2_STRIDE;
+        u0 = *(const f32x4*)s; u1 = *(const f32x4*)(s + 4);
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) d[k][e] = e < 4 ? u0[e] : u1[e - 4];
+    }
+    const int64_t pos2 = ((int64_t)blk * P2_POS >> 1) + pi;
+    uint4* out = T + ((int64_t)b * CG + cg) * 8 * Ph + pos2;          // [f][plane][Ph] items of 16 B
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      const int f = 2 * fh + g;
+      float t[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        t[e] = f == 0 ? d[0][e] - d[2][e] : f == 1 ? d[1][e] + d[2][e] : f == 2 ? d[2][e] - d[1][e] : d[1][e] - d[3][e];
+      uint32_t hw[4], lw[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) md_split2(t[2 * q], t[2 * q + 1], hw[q], lw[q]);
+      out[(int64_t)(f * 2) * Ph] = make_uint4(hw[0], hw[1], hw[2], hw[3]);
+      out[(int64_t)(f * 2 + 1) * Ph] = make_uint4(lw[0], lw[1], lw[2], lw[3]);
+    }
+  }
+}
+
+extern "C" int md_wino_prep_v2(const float* x1, const float* x2, int32_t c1, int32_t c2, const float* ac, int32_t silu,
+                               int32_t ups, void* t_out, int32_t batch, int32_t D, int32_t H, int32_t W, float drop_p,
+                               uint64_t drop_seed, void* stream) {
+  if (!x1 || !t_out || batch <= 0 || c1 <= 0 || c2 < 0 || (c1 & 7) || (c2 & 7) || (c2 > 0 && !x2)) return MD_ERR_BAD_ARG;
+  if (D <= 0 || H <= 0 || W <= 0 || (W & 1) || (ups && ((D | H | W) & 1))) return MD_ERR_BAD_ARG;
+  if (!(drop_p >= 0.f && drop_p < 1.f) || (drop_p > 0.f && (ups || c2 > 0))) return MD_ERR_BAD_ARG;
+  const int64_t P = (int64_t)D * H * W;
+  if ((P2_POS % W) || (P % P2_POS)) return MD_ERR_UNSUPPORTED;      // whole rows per workgroup
+  const int64_t blocks = (int64_t)batch * ((c1 + c2) / 8) * (P / P2_POS);
+  if (blocks > 0x7fffffff) return MD_ERR_UNSUPPORTED;
+  MD_HIP_CLEAR_ERROR();
+  hipLaunchKernelGGL(md_wino_prep2_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x1, x2, c1, c2, ac, silu,
+                     ups, (uint4*)t_out, batch, D, H, W, md_drop_thr16(drop_p), 1.0f / (1.0f - drop_p), drop_seed);
+  MD_HIP_CHECK_LAUNCH();
+  return MD_OK;
+}

@@ -164,6 +164,36 @@ def test_conv3_wino_data_gradient_weights(ops):
     assert e < TOL_MFMA
 
 
+@pytest.mark.parametrize("case", ["raw_two_parts", "gn_silu", "ups", "gn_silu_dropout"])
+def test_wino_prep_v2_is_bit_identical(ops, case):
+    """The two-phase operand pass (md_wino_prep_v2, csrc/wino_prep2.hip: the default where W divides 256) writes the same T,
+    bit for bit, as the one-thread-per-pair md_wino_prep."""
+    B, S = 2, 16
+    cs = [16, 8] if case == "raw_two_parts" else [32]
+    cin = sum(cs)
+    ups = case == "ups"
+    Sin = S // 2 if ups else S
+    xs = [_rand((B, c, Sin, Sin, Sin), 90 + i) for i, c in enumerate(cs)]
+    parts = [(ops.ncdhw_to_f32b(t.cuda()), c) for t, c in zip(xs, cs)]
+    ac, silu, drop = None, False, None
+    if case.startswith("gn_silu"):
+        gamma, beta = 1.0 + 0.2 * _rand((cin,), 92), 0.5 * _rand((cin,), 93)
+        _, ac = ops.gn_params(parts, gamma.cuda(), beta.cuda(), B, Sin ** 3, want_ac=True)
+        silu = True
+    if case == "gn_silu_dropout":
+        drop = (0.1, 12345)
+    keep = ops.WINO_PREP_V2
+    try:
+        ops.WINO_PREP_V2 = False
+        t1 = ops.wino_prep(parts, ac, silu, ups, B, S, drop=drop).clone()
+        ops.WINO_PREP_V2 = True
+        t2 = ops.wino_prep(parts, ac, silu, ups, B, S, drop=drop).clone()
+    finally:
+        ops.WINO_PREP_V2 = keep
+    assert torch.equal(t1.view(torch.int16), t2.view(torch.int16))
+    assert float(t1.float().abs().sum()) > 0
+
+
 @pytest.mark.parametrize("case", ["plain_128", "two_parts_gn_silu_res_stats", "ups_256rows", "gn_no_silu_k64"])
 def test_conv3_wino43_experimental_vs_torch(ops, case):
     """EXPERIMENTAL F(4,3) path (md_wino43_prep + md_wino43_pack_weights + md_conv3_wino43; not used by default): the same

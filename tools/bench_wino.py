@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--variants", default="0,1,9,16,25,32,64")
     ap.add_argument("--shapes", default="128:128:64:8,256:128:64:8,256:256:32:8,512:256:16:8")
     ap.add_argument("--out", default=None)
+    ap.add_argument("--prep-v2", action="store_true", help="also time the experimental two-phase operand pass")
     ap.add_argument("--f43", action="store_true", help="also time the experimental F(4,3) kernels (md_wino43_*)")
     ap.add_argument("--no-stats", action="store_true", help="launch without the GroupNorm-sum epilogue")
     ap.add_argument("--no-res", action="store_true", help="launch without the residual operand")
@@ -52,10 +53,17 @@ def main():
                 ts.append(e0.elapsed_time(e1))
             return sorted(ts)[len(ts) // 2]
 
+        ops.WINO_PREP_V2 = False
         t = ops.wino_prep([(x, cin)], ac, True, False, B, S)
         ms_prep = timed(lambda: ops.wino_prep([(x, cin)], ac, True, False, B, S))
         rows.append(dict(shape=sh, kernel="md_wino_prep", ms=round(ms_prep, 4), gbs=round(12.0 * B * cin * S ** 3 / ms_prep / 1e6, 1)))
         print(json.dumps(rows[-1]), flush=True)
+        if a.prep_v2 and 256 % S == 0:
+            ops.WINO_PREP_V2 = True
+            ms2 = timed(lambda: ops.wino_prep([(x, cin)], ac, True, False, B, S))
+            ops.WINO_PREP_V2 = False
+            rows.append(dict(shape=sh, kernel="md_wino_prep_v2", ms=round(ms2, 4), gbs=round(12.0 * B * cin * S ** 3 / ms2 / 1e6, 1)))
+            print(json.dumps(rows[-1]), flush=True)
         if a.f43:
             ww43 = ops.WinoWeight43(w, dev)
             t43 = ops.wino43_prep([(x, cin)], ac, True, False, B, S)
