@@ -287,22 +287,6 @@ int md_wino_prep_v2(const float* x1, const float* x2, int32_t c1, int32_t c2, co
                     void* t_out, int32_t batch, int32_t D, int32_t H, int32_t W, float drop_p, uint64_t drop_seed, void* stream);
 
 /*
- * EXPERIMENTAL (not used by default; MD_WINO43=1 in the host package): the same convolution through Winograd F(4,3) along w
- * (csrc/conv3_wino43.hip): 6 products per 4 outputs = 1/2 of the direct MFMA work, T = 1.5x the input
- * (T[B][C/8][6][2][D][H][W/4][8 bf16]), weight tiles [Cout/128][Cin/16][kd*3+kh][6][row tile 4][plane 2][k-group 2][row 32][8].
- * Arguments as md_wino_* (no dropout, W % 8 == 0 for the conv); error of one conv ~1.3e-5 (F(2,3): 5.5e-6).
- */
-int64_t md_wino43_operand_bytes(int32_t batch, int32_t cin, int32_t D, int32_t H, int32_t W);
-int md_wino43_prep(const float* x1, const float* x2, int32_t c1, int32_t c2, const float* ac, int32_t silu, int32_t ups,
-                   void* t_out, int32_t batch, int32_t D, int32_t H, int32_t W, void* stream);
-int64_t md_wino43_weight_bytes(int32_t cout, int32_t cin);
-int md_wino43_pack_weights(const float* w, void* wpk, int32_t cout, int32_t cin, int64_t s_row, int64_t s_k, int32_t flip,
-                           void* stream);
-int md_conv3_wino43(const void* t_in, const void* wpk, float* out, const float* bias, int64_t bias_bstride,
-                    const float* residual, int64_t res_bstride, double* stats, int32_t batch, int32_t cin, int32_t cout,
-                    int32_t D, int32_t H, int32_t W, void* stream);
-
-/*
  * md_attn_fwd: fused single-head self-attention (AttnBlock.forward, layers.py:595-608: the two einsums :602,:606 and the
  * softmax :604) -- QK^T, online softmax over the keys and PV in one kernel, bf16x3 MFMA for both contractions; the
  * [B][N][N] score matrix is never materialised.

@@ -73,11 +73,6 @@ SIGNATURES = {
     "md_wino_pack_weights": (C.c_int, [_P, _P, _I32, _I32, _I64, _I64, _I32, _P]),
     "md_conv3_wino": (C.c_int, [_P, _P, _P, _P, _I64, _P, _I64, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P]),
     "md_wino_prep_v2": (C.c_int, [_P, _P, _I32, _I32, _P, _I32, _I32, _P, _I32, _I32, _I32, _I32, _F, _U64, _P]),
-    "md_wino43_operand_bytes": (_I64, [_I32, _I32, _I32, _I32, _I32]),
-    "md_wino43_prep": (C.c_int, [_P, _P, _I32, _I32, _P, _I32, _I32, _P, _I32, _I32, _I32, _I32, _P]),
-    "md_wino43_weight_bytes": (_I64, [_I32, _I32]),
-    "md_wino43_pack_weights": (C.c_int, [_P, _P, _I32, _I32, _I64, _I64, _I32, _P]),
-    "md_conv3_wino43": (C.c_int, [_P, _P, _P, _P, _I64, _P, _I64, _P, _I32, _I32, _I32, _I32, _I32, _I32, _P]),
     "md_attn_fwd": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _F, _P]),
     "md_softmax_keys": (C.c_int, [_P, _P, _I32, _I32, _I32, _P]),
     "md_ancestral_step": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I64, _P]),
@@ -107,6 +102,15 @@ SIGNATURES = {
     "md_marching_tets": (C.c_int, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _I64, _P]),
 }
 
+# include/meshdiffusion_hip_experimental.h: present only in a MD_BUILD_EXPERIMENTAL=1 build; bound when the library has them
+EXPERIMENTAL_SIGNATURES = {
+    "md_wino43_operand_bytes": (_I64, [_I32, _I32, _I32, _I32, _I32]),
+    "md_wino43_prep": (C.c_int, [_P, _P, _I32, _I32, _P, _I32, _I32, _P, _I32, _I32, _I32, _I32, _P]),
+    "md_wino43_weight_bytes": (_I64, [_I32, _I32]),
+    "md_wino43_pack_weights": (C.c_int, [_P, _P, _I32, _I32, _I64, _I64, _I32, _P]),
+    "md_conv3_wino43": (C.c_int, [_P, _P, _P, _P, _I64, _P, _I64, _P, _I32, _I32, _I32, _I32, _I32, _I32, _P]),
+}
+
 _lib = None
 
 
@@ -134,6 +138,11 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
+    for name, (res, args) in EXPERIMENTAL_SIGNATURES.items():
+        fn = getattr(lib, name, None)
+        if fn is not None:
+            fn.restype = res
+            fn.argtypes = args
     if lib.md_abi_version() != ABI_VERSION:
         raise MeshDiffusionHipError(f"ABI version mismatch: library {lib.md_abi_version()}, host code {ABI_VERSION}")
     for cfg, (nt, kc) in CFG_NT_KC.items():
@@ -146,6 +155,11 @@ def load():
                                     f"({lib.md_device_count()} vs {torch.cuda.device_count()} devices)")
     _lib = lib
     return lib
+
+
+def has_experimental():
+    """True when the loaded library was built with MD_BUILD_EXPERIMENTAL=1."""
+    return all(hasattr(load(), n) for n in EXPERIMENTAL_SIGNATURES)
 
 
 def check(rc, what):

@@ -14,7 +14,9 @@ INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 OBJDIR = os.path.join(CSRC, "build")
 LIB_PATH = os.path.join(HERE, "libmeshdiffusion_hip.so")
 ARCH = "gfx950"
-SOURCES = ["capi.hip", "gemm_conv.hip", "conv3_main.hip", "conv3_wino.hip", "conv3_wino43.hip", "wino_prep2.hip", "norm.hip", "elementwise.hip", "attention.hip", "nin_stream.hip", "train.hip", "backward.hip", "wgrad.hip", "dmtet.hip"]
+SOURCES = ["capi.hip", "gemm_conv.hip", "conv3_main.hip", "conv3_wino.hip", "wino_prep2.hip", "norm.hip", "elementwise.hip", "attention.hip", "nin_stream.hip", "train.hip", "backward.hip", "wgrad.hip", "dmtet.hip"]
+# default-off experiments (MD_BUILD_EXPERIMENTAL=1): declared in include/meshdiffusion_hip_experimental.h, bound lazily by _lib.py
+EXPERIMENTAL_SOURCES = ["experimental/conv3_wino43.hip"]
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", f"-I{INCLUDE}", f"-I{CSRC}",
          "-munsafe-fp-atomics", "-Wno-unused-result"]
 
@@ -35,22 +37,25 @@ def _newer(target, deps):
 
 def build(verbose=False, force=False):
     """Compile every HIP source for gfx950 (in parallel) and link the shared library. Returns its path.
-    MD_BUILD_ABLATIONS=1 in the environment also builds the timing-only kernel variants of tools/bench_conv.py
-    (adds ~4 minutes: seven more instantiations of the unrolled 27-tap conv kernel)."""
+    MD_BUILD_ABLATIONS=1 in the environment also builds the timing-only kernel variants of tools/bench_conv.py /
+    tools/bench_wino.py (adds ~4 minutes: seven more instantiations of the unrolled 27-tap conv kernel);
+    MD_BUILD_EXPERIMENTAL=1 adds the default-off experimental kernels (csrc/experimental/: the F(4,3) Winograd prototype)."""
     from concurrent.futures import ThreadPoolExecutor
     hipcc = _hipcc()
     os.makedirs(OBJDIR, exist_ok=True)
     headers = [os.path.join(CSRC, "md_common.h"), os.path.join(INCLUDE, "meshdiffusion_hip.h")]
     flags = FLAGS + (["-DMD_BUILD_ABLATIONS"] if os.environ.get("MD_BUILD_ABLATIONS") == "1" else [])
+    experimental = os.environ.get("MD_BUILD_EXPERIMENTAL") == "1"
+    flags = flags + (["-DMD_BUILD_EXPERIMENTAL"] if experimental else [])
     stamp = os.path.join(OBJDIR, "flags.txt")
     if not os.path.exists(stamp) or open(stamp).read() != " ".join(flags):
         force = True
     objs, jobs = [], []
-    for src in SOURCES:
+    for src in SOURCES + (EXPERIMENTAL_SOURCES if experimental else []):
         sp = os.path.join(CSRC, src)
         if not os.path.exists(sp):
             raise RuntimeError(f"missing source {sp}")
-        obj = os.path.join(OBJDIR, src.replace(".hip", ".o"))
+        obj = os.path.join(OBJDIR, os.path.basename(src).replace(".hip", ".o"))
         if force or _newer(obj, [sp] + headers):
             jobs.append([hipcc] + flags + ["-c", sp, "-o", obj])
         objs.append(obj)

@@ -483,6 +483,7 @@ extern "C" int md_wino_prep(const float* x1, const float* x2, int32_t c1, int32_
                             int32_t ups, void* t_out, int32_t batch, int32_t D, int32_t H, int32_t W, float drop_p,
                             uint64_t drop_seed, void* stream) {
   if (!x1 || !t_out || batch <= 0 || c1 <= 0 || c2 < 0 || (c1 & 7) || (c2 & 7) || (c2 > 0 && !x2)) return MD_ERR_BAD_ARG;
+  if (silu && !ac) return MD_ERR_BAD_ARG;      // SiLU is applied together with the folded GroupNorm affine only
   if (!(drop_p >= 0.f && drop_p < 1.f) || (drop_p > 0.f && (ups || c2 > 0))) return MD_ERR_BAD_ARG;
   if (D <= 0 || H <= 0 || W <= 0 || (W & 1) || (ups && ((D | H | W) & 1))) return MD_ERR_BAD_ARG;
   const int64_t n = (int64_t)batch * ((c1 + c2) / 8) * D * H * (W / 2);

@@ -16,6 +16,7 @@
 // 36 MFMAs per step.  Its halo image holds two frequency slices (2 x 480 entries = the same 15 pieces of 1 KB per chunk);
 // the slices of frequencies 4 and 5 are fetched by two waves each.  Workgroup tile = 128 Cout x (4 x 8 x 8) positions.
 #include "md_common.h"
+#include "meshdiffusion_hip_experimental.h"
 
 namespace {
 constexpr int W4_THREADS = 256;
@@ -448,6 +449,7 @@ extern "C" int64_t md_wino43_operand_bytes(int32_t batch, int32_t cin, int32_t D
 extern "C" int md_wino43_prep(const float* x1, const float* x2, int32_t c1, int32_t c2, const float* ac, int32_t silu,
                               int32_t ups, void* t_out, int32_t batch, int32_t D, int32_t H, int32_t W, void* stream) {
   if (!x1 || !t_out || batch <= 0 || c1 <= 0 || c2 < 0 || (c1 & 7) || (c2 & 7) || (c2 > 0 && !x2)) return MD_ERR_BAD_ARG;
+  if (silu && !ac) return MD_ERR_BAD_ARG;
   if (D <= 0 || H <= 0 || W <= 0 || (W & 3) || (ups && ((D | H | W) & 1))) return MD_ERR_BAD_ARG;
   const int64_t n = (int64_t)batch * ((c1 + c2) / 8) * D * H * (W / 4);
   const int64_t blocks = (n + 255) / 256;

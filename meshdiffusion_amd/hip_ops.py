@@ -273,12 +273,19 @@ def _wino_scratch(n_bf16, device):
     return buf[:n_bf16]
 
 
+def release_scratch():
+    """Drop the per-stream Winograd operand buffers (several GB after a training / sampling run at 64^3): the next
+    wino_prep allocates again."""
+    _WINO_SCRATCH.clear()
+
+
 def wino_prep(parts, ac, silu, ups, B, S, drop=None):
     """fp32 F32B parts (+ folded GroupNorm affine, SiLU, nearest-x2 upsampling) -> transformed split operand T.
     drop = (p, seed): training dropout after SiLU, the mask gn_apply(drop=...) produces for the same pair."""
     lib = _lib.load()
     cin = sum(c for _, c in parts)
     assert 1 <= len(parts) <= 2
+    assert ac is not None or not silu, "SiLU is applied together with the folded GroupNorm affine (pass `ac`)"
     nbytes = lib.md_wino_operand_bytes(B, cin, S, S, S)
     if nbytes <= 0:
         raise _lib.MeshDiffusionHipError("md_wino_operand_bytes: unsupported operand shape")
@@ -311,12 +318,16 @@ def conv3_wino(ww, t, B, S, *, bias=None, bias_bstride=0, residual=None, res_bst
     return out
 
 
-# ---- EXPERIMENTAL: Winograd F(4,3) along w (csrc/conv3_wino43.hip); tools/bench_wino.py --f43, tests/test_gpu_wino.py ----
-WINO43 = os.environ.get("MD_WINO43", "0") == "1"
+# ---- EXPERIMENTAL: Winograd F(4,3) along w (csrc/experimental/conv3_wino43.hip, MD_BUILD_EXPERIMENTAL=1 builds only);
+# ---- tools/bench_wino.py --f43, tests/test_gpu_wino.py.  Nothing on the product path uses it.
+def _need_experimental():
+    if not _lib.has_experimental():
+        raise _lib.MeshDiffusionHipError("the F(4,3) prototype is not in this build (MD_BUILD_EXPERIMENTAL=1 python -m meshdiffusion_amd.build)")
 
 
 class WinoWeight43:
     def __init__(self, w, device, kind="conv"):
+        _need_experimental()
         lib = _lib.load()
         w = w.detach().to(device=device, dtype=torch.float32).contiguous()
         _require_cuda(w, "weight")
@@ -336,6 +347,7 @@ class WinoWeight43:
 
 
 def wino43_prep(parts, ac, silu, ups, B, S):
+    _need_experimental()
     lib = _lib.load()
     cin = sum(c for _, c in parts)
     nbytes = lib.md_wino43_operand_bytes(B, cin, S, S, S)

@@ -61,7 +61,9 @@ class _FlatOptState:
         self.v = torch.zeros_like(fg.flat)
         self.e = torch.empty_like(fg.flat)
         self.sq = torch.zeros(1, dtype=torch.float64, device=dev)
-        self.step_t = torch.zeros((), dtype=torch.float32)          # shared by every parameter's Adam state entry
+        # one 0-dim `step` tensor PER parameter (torch.optim.Adam advances each entry's step in place: a tensor shared by
+        # all entries would be advanced once per parameter after a resume through the torch optimizer)
+        self.step_ts = [torch.zeros((), dtype=torch.float32) for _ in fg.params]
         self.ema_index = None
         for p in fg.params:                                          # parameters -> views of the flat buffer
             _, o, n = fg.slices[id(p)]
@@ -78,15 +80,16 @@ class _FlatOptState:
         """Adopt whatever state the torch objects currently hold (fresh, or just loaded from a checkpoint)."""
         mv, vv = self._views(self.m), self._views(self.v)
         self.opt_steps = 0
-        for p, m_, v_ in zip(self.fg.params, mv, vv):
+        for p, m_, v_, s_ in zip(self.fg.params, mv, vv, self.step_ts):
             st = optimizer.state.get(p)
             if st and "exp_avg" in st:
                 m_.copy_(st["exp_avg"]); v_.copy_(st["exp_avg_sq"])
                 self.opt_steps = int(float(st["step"]))
             else:
                 m_.zero_(); v_.zero_()
-            optimizer.state[p] = dict(step=self.step_t, exp_avg=m_, exp_avg_sq=v_)
-        self.step_t.fill_(float(self.opt_steps))
+            optimizer.state[p] = dict(step=s_, exp_avg=m_, exp_avg_sq=v_)
+        for s_ in self.step_ts:
+            s_.fill_(float(self.opt_steps))
         live = [p for g in optimizer.param_groups for p in g["params"] if p.requires_grad]
         idx = {id(p): i for i, p in enumerate(live)}
         ev = self._views(self.e)
@@ -95,8 +98,20 @@ class _FlatOptState:
             e_.copy_(ema.shadow_params[i])
             ema.shadow_params[i] = e_
         self.m0, self.e0, self.ema_i0 = mv[0], ev[0], idx[id(self.fg.params[0])]
+        self.live_key = (id(optimizer), id(ema), len(live), len(ema.shadow_params))
+
+    def params_alias_flat(self):
+        """The first and the last parameter still are views of the flat buffer (model.to() / float() / a manual
+        `p.data = ...` / load_state_dict(assign=True) replace the storage: md_adam_ema_step would then update an orphan)."""
+        for p in (self.fg.params[0], self.fg.params[-1]):
+            _, o, n = self.fg.slices[id(p)]
+            if p.data_ptr() != self.p.data_ptr() + 4 * o or p.numel() != n:
+                return False
+        return True
 
     def usable(self, optimizer, ema):
+        if not self.params_alias_flat():
+            return False                          # the caller rebuilds the flat state from the live parameters
         p0 = self.fg.params[0]
         st = optimizer.state.get(p0)
         if not st or st.get("exp_avg") is None or st["exp_avg"].data_ptr() != self.m0.data_ptr() \
@@ -110,7 +125,7 @@ class _FlatOptState:
         lr = float(lr0 * np.minimum(sched_step / warmup, 1.0)) if warmup > 0 else float(g["lr"])
         g["lr"] = lr
         self.opt_steps += 1
-        self.step_t.fill_(float(self.opt_steps))
+        torch._foreach_add_(self.step_ts, 1.0)
         d = ema._effective_decay()
         sq = None
         if grad_clip >= 0:
@@ -138,15 +153,19 @@ def _fused_opt_for(net, fg, optimizer, ema, optimize_fn):
     if g.get("amsgrad") or g.get("maximize") or g.get("capturable") or g.get("differentiable"):
         return None
     live = [p for p in g["params"] if p.requires_grad]
-    if len(ema.shadow_params) != len(live) or any(id(p) not in {id(q) for q in live} for p in fg.params):
-        return None
+    fs = net.__dict__.get("_md_flat_opt")
+    key = (id(optimizer), id(ema), len(live), len(ema.shadow_params))
+    if fs is None or fs.fg is not fg or fs.live_key != key:      # eligibility is re-derived only when an object changed
+        live_ids = {id(q) for q in live}
+        if len(ema.shadow_params) != len(live) or any(id(p) not in live_ids for p in fg.params):
+            return None
+        fs = None
     if any(p.grad is not None for p in live if id(p) not in fg.slices):
         return None                                  # a parameter outside the flat buffer received a gradient
-    fs = net.__dict__.get("_md_flat_opt")
-    if fs is None or fs.fg is not fg:
+    if fs is None or not fs.usable(optimizer, ema):
         fs = _FlatOptState(fg, optimizer, ema)
         net.__dict__["_md_flat_opt"] = fs
-    fs.usable(optimizer, ema)
+        fs.usable(optimizer, ema)
     return fs
 
 

@@ -304,7 +304,7 @@ def get_ddim_sampler(sde, shape, predictor, inverse_scaler, n_steps=1, denoise=F
     return statement reads an undefined name (`encode`, sampling.py:569), so it raises NameError whenever
     `config.sampling.noise_removal` is true; here `encode` is taken as False, i.e. noise_removal=True returns the last
     x0 prediction and noise_removal=False returns the last state (the path the unmodified reference can run, pinned by
-    tests/golden/ddim_small.npz).  The state is float64 from the first update on, as in the reference."""
+    tests/golden/ddim.npz).  The state is float64 from the first update on, as in the reference."""
     if predictor is not DDIMPredictor:
         raise NotImplementedError("the DDIM sampler runs with the 'ddim' predictor")
     B = shape[0]

@@ -273,3 +273,53 @@ def test_fused_optimizer_under_reference_objects_matches_torch_path(hip_lib, tmp
     errs = [rel(x, y) for x, y in zip(c, a)]
     print("restored-from-checkpoint continuation vs uninterrupted:", errs)
     assert max(errs) < 2e-6
+    # the same fused-written checkpoint resumed through the TORCH optimizer (MD_FUSED_OPT off = the reference's
+    # torch.optim.Adam): every parameter's Adam `step` must advance by exactly 1 per optimizer.step() (a `step` tensor shared
+    # by all entries would advance once per parameter) and the result must equal the uninterrupted torch-path run
+    st_q, fn_q, _ = fresh()
+    st_q = restore_checkpoint(ck, st_q, torch.device("cuda"))
+    steps0 = {float(e["step"]) for e in st_q["optimizer"].state_dict()["state"].values()}
+    assert steps0 == {2.0}
+    ptrs = {e["step"].data_ptr() for e in st_q["optimizer"].state.values()}
+    assert len(ptrs) == len(st_q["optimizer"].state), "Adam step tensors alias each other after the restore"
+    st_q, _, _ = run(False, 1, st_q, fn_q, batch, first=2)
+    steps1 = {float(e["step"]) for e in st_q["optimizer"].state_dict()["state"].values()}
+    assert steps1 == {3.0}, steps1
+    errs = [rel(x, y) for x, y in zip(snapshot(st_q), b)]
+    print("fused-written checkpoint continued by torch.optim.Adam vs the all-torch run:", errs)
+    assert max(errs) < 2e-5
+
+
+def test_flat_optimizer_state_follows_replaced_parameter_storage(hip_lib):
+    """parameters whose storage is replaced after the first fused step (p.data = ..., model.float(), ...) no
+    longer alias the flat buffer: the flat state must be rebuilt from the live parameters instead of updating an orphan."""
+    from meshdiffusion_amd import synth
+    from meshdiffusion_amd.lib.diffusion import losses, sde_lib
+    from meshdiffusion_amd.lib.diffusion.models import ddpm_res64, utils as mutils  # noqa: F401
+    from meshdiffusion_amd.lib.diffusion.models.ema import ExponentialMovingAverage
+    cfg = synth.small_config(); cfg.device = torch.device("cuda")
+    cfg.optim.warmup, cfg.optim.lr, cfg.optim.grad_clip = 0, 1e-3, 1.0
+    model = mutils.create_model(cfg)
+    R = cfg.data.image_size
+    sd = synth.sensitised_state_dict(model.module.state_dict(), seed=1234, grid_mask=synth.synthetic_grid_mask(R))
+    model.module.load_state_dict(sd, strict=True)
+    ema = ExponentialMovingAverage(model.parameters(), decay=0.999)
+    opt = losses.get_optimizer(cfg, model.parameters())
+    sde = sde_lib.VPSDE(0.1, 20.0, 1000, device="cuda")
+    mask = synth.synthetic_grid_mask(R).view(1, 1, R, R, R).cuda()
+    step_fn = losses.get_step_fn(sde, train=True, optimize_fn=losses.optimization_manager(cfg), mask=mask)
+    batch = (synth.synthetic_inputs(2, 4, R, seed=8) * mask.cpu()).cuda()
+    state = dict(model=model, ema=ema, optimizer=opt, step=1)
+    torch.manual_seed(1); step_fn(state, batch)
+    fs0 = model.module.__dict__.get("_md_flat_opt")
+    assert fs0 is not None and fs0.params_alias_flat()
+    for p in model.parameters():                       # what model.float() / a manual reassignment does
+        p.data = p.data.clone()
+    assert not fs0.params_alias_flat()
+    before = [p.detach().clone() for p in model.parameters() if p.requires_grad]
+    torch.manual_seed(2); step_fn(state, batch)
+    fs1 = model.module.__dict__.get("_md_flat_opt")
+    assert fs1 is not fs0 and fs1.params_alias_flat()
+    moved = sum(float((p.detach() - q).abs().sum()) for p, q in zip((p for p in model.parameters() if p.requires_grad), before))
+    assert moved > 0, "the live parameters did not train after their storage was replaced"
+    assert fs1.opt_steps == 2                          # Adam state (incl. the step count) carried over
