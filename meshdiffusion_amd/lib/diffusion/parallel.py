@@ -32,13 +32,22 @@ def init_distributed(backend=None, force=False):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend is None:     # MD_DIST_BACKEND=gloo: several ranks on ONE GPU (tests; RCCL refuses two ranks per device)
+            backend = os.environ.get("MD_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
         kw = dict(device_id=torch.device("cuda", local_rank)) if backend == "nccl" else {}
         dist.init_process_group(backend, rank=rank, world_size=world, **kw)
     return rank, world, local_rank
+
+
+def barrier():
+    """dist.barrier() on this rank's device (no-op outside a multi-rank run)."""
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        if dist.get_backend() == "nccl":
+            dist.barrier(device_ids=[torch.cuda.current_device()])
+        else:
+            dist.barrier()
 
 
 def sharded_sample(sample_fn, total_batch, seed, gather=True):
@@ -59,9 +68,8 @@ def sharded_sample(sample_fn, total_batch, seed, gather=True):
     if ref is not None:
         shape_t[0] = ref.dim()
         shape_t[1:1 + ref.dim()] = torch.tensor(ref.shape)
-    dev = ref.device if ref is not None else torch.device("cpu")
-    if dist.get_backend() == "nccl":
-        dev = torch.device("cuda", torch.cuda.current_device())
+    # RCCL moves device buffers; gloo gathers through host memory (also when the shards live on a GPU)
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
     shape_t = shape_t.to(dev)
     dist.all_reduce(shape_t, op=dist.ReduceOp.MAX)
     nd = int(shape_t[0])

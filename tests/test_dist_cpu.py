@@ -220,3 +220,91 @@ def test_bench_multi_process_control_flow_dry_run():
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and abs(d["max_wall"] - 0.2) < 1e-9 and d["value"] == 2 * 8 * 3 / 0.2
+
+
+def _evaler_worker(rank, world, port, tmp, total):
+    """One rank of `main_diffusion.py --mode=uncond_gen` / cond_gen under torchrun; the sampler is a stub (the HIP path
+    needs a GPU; tests/test_gpu_dist.py runs the same flow through the real kernels)."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), MD_DIST_BACKEND="gloo")
+    os.chdir(tmp)
+    import numpy as np
+    import main_diffusion
+    from meshdiffusion_amd.lib.diffusion import sampling
+
+    def fake_get_sampling_fn(config, sde, shape, inverse_scaler, eps, grid_mask=None, return_traj=False):
+        def fn(model, partial=None, partial_mask=None, partial_channel=0, freeze_iters=None):
+            # rows carry (rank's global seed, the local batch the sampler was built for, conditioning flag)
+            x = torch.zeros(shape)
+            x[:, 0] = float(torch.initial_seed())
+            x[:, 1] = float(shape[0])
+            x[:, 2] = 0.0 if partial is None else float(partial.abs().sum())
+            return x, 0
+        return fn
+
+    sampling.get_sampling_fn = fake_get_sampling_fn
+    common = ["--config", os.path.join(tmp, "small.py"), f"--config.eval.eval_dir={tmp}/out",
+              f"--config.eval.ckpt_path={tmp}/ckpt.pth", f"--config.eval.batch_size={total}", "--config.seed=7"]
+    main_diffusion.main(common + ["--mode=uncond_gen"])
+    if rank == 0:
+        x = np.load(os.path.join(tmp, "out", "0.npy"))
+        np.save(os.path.join(tmp, "uncond.npy"), x)
+    main_diffusion.main(common + ["--mode=cond_gen", f"--config.eval.partial_dmtet_path={tmp}/dmtet.pt",
+                                  f"--config.eval.tet_path={tmp}/tets.npz", "--config.eval.freeze_iters=3"])
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("total", [5, 1])
+@retry_rendezvous
+def test_cli_generation_shards_over_two_ranks_and_writes_one_file_gloo(total, tmp_path):
+    """`torchrun --nproc-per-node 2 main_diffusion.py --mode=uncond_gen|cond_gen` -- every rank samples
+    its shard of eval.batch_size with seed config.seed + rank, rank 0 gathers and writes ONE {idx}.npy with the full batch
+    in rank order (reference: evaler.py:14-60 + DataParallel, models/utils.py:88-96).  total = 1: rank 1 has no sample."""
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    from meshdiffusion_amd import synth
+    from meshdiffusion_amd.lib.diffusion import losses, parallel
+    from meshdiffusion_amd.lib.diffusion.models import ddpm_res64, utils as mutils  # noqa: F401
+    from meshdiffusion_amd.lib.diffusion.models.ema import ExponentialMovingAverage
+    from meshdiffusion_amd.lib.diffusion.utils import save_checkpoint
+    tmp = str(tmp_path)
+    cfg = synth.small_config(); cfg.device = torch.device("cpu")
+    R = cfg.data.image_size
+    model = mutils.create_model(cfg)
+    ema = ExponentialMovingAverage(model.parameters(), decay=cfg.model.ema_rate)
+    save_checkpoint(os.path.join(tmp, "ckpt.pth"),
+                    dict(optimizer=losses.get_optimizer(cfg, model.parameters()), model=model, ema=ema, step=3))
+    os.makedirs(os.path.join(tmp, "data"), exist_ok=True)
+    m = synth.synthetic_grid_mask(R)
+    torch.save(m, os.path.join(tmp, "data", f"grid_mask_{R}.pt"))
+    with open(os.path.join(tmp, "small.py"), "w") as f:
+        f.write("import torch\nfrom meshdiffusion_amd import synth\n\ndef get_config():\n    c = synth.small_config()\n"
+                "    c.device = torch.device('cpu')\n    return c\n")
+    idx = np.argwhere(m.numpy() > 0).astype(np.float32)
+    np.savez(os.path.join(tmp, "tets.npz"), vertices=(idx / (R - 1) - 0.5).astype(np.float32), indices=np.zeros((1, 4), np.int32))
+    g = torch.Generator().manual_seed(1)
+    part = {"sdf": torch.sign(torch.randn(len(idx), generator=g)), "vis": torch.rand(len(idx), generator=g) < 0.5}
+    torch.save(part, os.path.join(tmp, "dmtet.pt"))
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    procs = [ctx.Process(target=_evaler_worker, args=(r, 2, port, tmp, total)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=240)
+    codes = [p.exitcode for p in procs]
+    _reap(procs)
+    assert codes == [0, 0], codes
+    sizes = parallel.shard_sizes(total, 2)
+    files = sorted(os.listdir(os.path.join(tmp, "out")))
+    assert files == ["0.npy"], files                                      # ONE file, written by rank 0
+    for name, cond in (("uncond.npy", False), (os.path.join("out", "0.npy"), True)):
+        x = np.load(os.path.join(tmp, name))
+        assert x.shape == (total, 4, R, R, R) and x.dtype == np.float32
+        row = 0
+        for r, n in enumerate(sizes):
+            for _ in range(n):
+                assert x[row, 0].flat[0] == 7 + r and x[row, 1].flat[0] == n    # seed + rank, built for the local batch
+                assert (x[row, 2].flat[0] != 0) == cond
+                row += 1
