@@ -222,6 +222,15 @@ def main():
         whole = {"mfma_frac_step": round(step_flops / (wall / a.steps) / (PEAK_BF16_TFLOPS * 1e12), 4),
                  "hbm_frac_step": round(step_bytes / (wall / a.steps) / (PEAK_HBM_GBS * 1e9), 4),
                  "ms_per_unet_eval_per_sample": round(ms_per_step / B, 3)}
+        if roof:     # flat copies: the driver's `parsed` record keeps scalar members of `roofline` only
+            roof["whole_step_mfma_frac"], roof["whole_step_hbm_frac"] = whole["mfma_frac_step"], whole["hbm_frac_step"]
+            if roof.get("operand_prep"):
+                op = roof["operand_prep"]
+                roof["operand_prep_ms_per_step"], roof["operand_prep_gbs"] = op["ms_per_step"], op["achieved"]
+                roof["operand_prep_hbm_frac"], roof["conv_plus_prep_frac"] = op["frac"], op["conv_plus_prep_frac"]
+            if train:
+                roof["train_step_ms"] = train.get("ms_per_step")
+                roof["train_step_mfma_frac"] = train.get("mfma_frac_step")
         hbm_kernels = hbm_bound_kernels(dev, B) if world == 1 else None
         other = None
         if world == 1 and not a.no_res128:
@@ -482,32 +491,50 @@ def cpu_baseline(sd_cpu, cfg, synth):
     denoise steps at B=1 (one res64 U-Net evaluation + ancestral update each = 1/8 of one unit batch of the GPU
     workload), one warm-up step then >= 3 timed ones, median."""
     from oracle import unet_oracle as uo
-    # oneDNN convs of this size get slower beyond a few dozen threads (256 threads: 98 s/step measured)
-    threads = min(os.cpu_count() or 1, 32)
-    torch.set_num_threads(threads)
     ocfg = synth.oracle_cfg(cfg)
     R = cfg.data.image_size
-    x = synth.synthetic_inputs(1, 4, R, seed=42)
+    state = {"x": synth.synthetic_inputs(1, 4, R, seed=42), "i": 0}
     z = synth.synthetic_inputs(1, 4, R, seed=43)
     mask = synth.synthetic_grid_mask(R).view(1, R, R, R)
-    times = []
+
+    def one_step():
+        t0 = time.perf_counter()
+        t = torch.tensor(1.0 - state["i"] * 1e-3)
+        e = uo.unet_res64_forward(sd_cpu, ocfg, state["x"], torch.ones(1) * t * 999)
+        state["x"], _ = uo.ancestral_step(state["x"], e, z, t, mask)
+        state["i"] += 1
+        return time.perf_counter() - t0
+
+    # Thread sweep (VERDICT r02 item 5): oneDNN convs of this size do not scale to the whole host (r02: 256 threads 98 s per
+    # step against 3.5 s at 32), so the baseline is the BEST thread count of a bounded sweep, reported with the sweep.  One
+    # warm-up + one timed step per count; the sweep stops once a count is 1.5x slower than the best so far (past the optimum),
+    # which also keeps the whole-host count out of the default run when it is hopeless.
+    ncpu = os.cpu_count() or 1
+    cands = [t for t in (16, 32, 64, 128, 256) if t <= ncpu] or [ncpu]
+    if ncpu > cands[-1]:
+        cands.append(ncpu)
+    sweep, best = {}, None
     with torch.no_grad():
-        for i in range(4):
-            t0 = time.perf_counter()
-            t = torch.tensor(1.0 - i * 1e-3)
-            e = uo.unet_res64_forward(sd_cpu, ocfg, x, torch.ones(1) * t * 999)
-            x, _ = uo.ancestral_step(x, e, z, t, mask)
-            times.append(time.perf_counter() - t0)
-            if i == 0 and times[0] > 40.0:       # a very slow host: keep the default bench run within minutes
+        for t in cands:
+            torch.set_num_threads(t)
+            warm = one_step()
+            s = one_step() if warm < 40.0 else warm      # a very slow count: its warm-up step is its measurement
+            sweep[str(t)] = round(s, 2)
+            if best is None or s < best[1]:
+                best = (t, s)
+            elif s > 1.5 * best[1]:
                 break
-    timed = times[1:] if len(times) > 1 else times
+        torch.set_num_threads(best[0])
+        timed = [one_step() for _ in range(3)] if best[1] < 20.0 else [best[1]]
     med = statistics.median(timed)
-    return {"value": round(1.0 / med, 4), "unit": "sample-steps/s", "cores": threads, "kind": "port",
-            "host_cpu_count": os.cpu_count(), "host_cpu_model": cpu_model_name(), "torch_threads": torch.get_num_threads(),
+    return {"value": round(1.0 / med, 4), "unit": "sample-steps/s", "cores": best[0], "kind": "port",
+            "host_cpu_count": ncpu, "host_cpu_model": cpu_model_name(), "torch_threads": torch.get_num_threads(),
             "s_per_sample_step": round(med, 2), "timed_steps_s": [round(v, 2) for v in timed],
-            "sample": f"{len(timed)} timed denoise steps (res64 U-Net eval + ancestral update) at batch=1 on the host CPU after "
-                      "one warm-up step, median; PyTorch fp32 oracle restatement (oracle/unet_oracle.py); a full 999-step "
-                      "run would take ~999x this"}
+            "thread_sweep_s_per_step": sweep,
+            "sample": f"{len(timed)} timed denoise steps (res64 U-Net eval + ancestral update) at batch=1 on the host CPU at the best "
+                      "thread count of the sweep in thread_sweep_s_per_step (one warm-up + one timed step per count), median; PyTorch "
+                      "fp32 oracle restatement (oracle/unet_oracle.py, pinned to the imported reference by oracle/gen_golden.py; the "
+                      "reference itself is absent on the GPU box); a full 999-step run would take ~999x this"}
 
 
 if __name__ == "__main__":

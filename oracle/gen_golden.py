@@ -14,6 +14,7 @@ outputs are stored):
   sampler_cond_res64_b32.npz  BASELINE config #5: cond_gen res64, B=32, first 5 iterations of the inpainting sampler
   sampler_res128_b2.npz       BASELINE config #4: res128, B=2, first 2 ancestral steps
   train_grads.npz    reference loss function (train mode): loss + per-parameter gradient norms / samples
+  train_grads_b2.npz the same for the real res64 network at B = 2 (--only train_b2)
   dataset.npz        reference ShapeNetDMTetDataset items (augmentation on/off) for seeded on-disk grids
   dmtet.npz          reference DMTet.__call__ on the shipped 64-grid: counts, hashes, samples
   64_tets_cropped.npz  the tet-grid DATA asset (vertices/indices), copied verbatim
@@ -487,7 +488,7 @@ class fixed_draws:
         torch.randint, torch.randn_like = self.ri, self.rl
 
 
-def gen_train(full):
+def gen_train(full, b2_only=False):
     """Loss and parameter gradients of the UNMODIFIED reference loss function (lib/diffusion/losses.py:54-85, train
     mode, dropout 0) for the small res64/res128 configs and -- `full` -- the real res64 network at B=1.
     Stored per parameter: gradient norm and a strided sample of <= 256 entries."""
@@ -497,6 +498,12 @@ def gen_train(full):
     if full:
         from meshdiffusion_amd.config import get_config_res64
         cases.append(("res64", get_config_res64(), 1, 1234))
+    if b2_only:
+        # train_grads_b2.npz: the real res64 network at B = 2 -- at that batch the 32^3 levels of the HIP path run through the
+        # Winograd kernels too (hip_ops.wino_ok), so forward + data-gradient Winograd convs at 64^3 AND 32^3 are pinned to
+        # the reference's autograd, not to one block
+        from meshdiffusion_amd.config import get_config_res64
+        cases = [("res64_b2", get_config_res64(), 2, 1234)]
     out = {}
     for name, cfg, B, sd_seed in cases:
         cfg.device = torch.device("cpu")
@@ -524,7 +531,7 @@ def gen_train(full):
             out[f"{name}/{n}/sample"] = g[::stride][:256].numpy().copy()
             gsq += float(g.double().square().sum())
         out[f"{name}_gnorm"] = np.float64(gsq ** 0.5)
-    np.savez_compressed(os.path.join(GOLD, "train_grads.npz"), **out)
+    np.savez_compressed(os.path.join(GOLD, "train_grads_b2.npz" if b2_only else "train_grads.npz"), **out)
 
 
 def dataset_inputs(tmp, R=8):
@@ -568,7 +575,7 @@ def gen_dataset():
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-res64", action="store_true")
-    ap.add_argument("--only", choices=["unet", "dmtet", "dataset", "train", "graded", "ddim"], default=None)
+    ap.add_argument("--only", choices=["unet", "dmtet", "dataset", "train", "train_b2", "graded", "ddim"], default=None)
     ap.add_argument("--graded", default="config1,cond32,res128", help="which graded-size sampler fixtures to (re)generate")
     a = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
@@ -579,6 +586,8 @@ if __name__ == "__main__":
         gen_dataset()
     if a.only in (None, "train"):
         gen_train(full=not a.skip_res64)
+    if a.only in (None, "train_b2"):
+        gen_train(full=False, b2_only=True)
     if a.only in (None, "unet"):
         gen_unet_and_sampler(a.skip_res64)
     if a.only in (None, "ddim"):

@@ -308,3 +308,60 @@ def test_cli_generation_shards_over_two_ranks_and_writes_one_file_gloo(total, tm
                 assert x[row, 0].flat[0] == 7 + r and x[row, 1].flat[0] == n    # seed + rank, built for the local batch
                 assert (x[row, 2].flat[0] != 0) == cond
                 row += 1
+
+
+def _accum_worker(rank, world, port, q):
+    """Gradient accumulation (trainer.py:94-116, training.iter_size = 2) through the in-place flat reducer, the way
+    losses.get_step_fn drives it: micro-step 1 only accumulates (no reducer exists); micro-step 2 accumulates layer by layer
+    and announces each finished layer, so bucket all-reduces of the finished prefix are in flight while later layers of the
+    SAME flat buffer are still being written."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from meshdiffusion_amd.lib.diffusion import parallel
+    parallel.init_distributed(backend="gloo")
+    shapes = [(40, 30), (30,), (64, 16), (16,), (7, 5, 3), (200,)]
+    params = [torch.nn.Parameter(torch.zeros(s)) for s in shapes]
+    fg = parallel.FlatGrads(params)                     # completion order = list order
+    g = torch.Generator().manual_seed(50 + rank)
+    micro = [[torch.randn(s, generator=g) for s in shapes] for _ in range(2)]
+    fg.zero_(); fg.attach()                             # clear_grad on the first micro-step
+    for p, gr in zip(params, micro[0]):                 # micro-step 1: update_param=False -> no GradReducer
+        p.grad.add_(gr)
+    red = parallel.GradReducer(cap_bytes=1024, flat=fg)  # micro-step 2 (update_param=True)
+    fg.attach()
+    assert red.active
+    launched = []
+    for p, gr in zip(params, micro[1]):
+        p.grad.add_(gr)                                 # this layer's gradient becomes final ...
+        red.ready([p])                                  # ... and is announced; earlier buckets may already be on the wire
+        launched.append(len(red.pending))
+    red.finish(params)
+    assert launched[0] >= 1 and red.stats["buckets"] >= 3 and red.stats["bytes"] == 4 * fg.n
+    q.put((rank, [m for m in micro], fg.flat.clone()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@retry_rendezvous
+def test_gradient_accumulation_two_micro_steps_flat_reducer_gloo():
+    """iter_size = 2 with the in-place prefix all-reduces -- the exchanged buffer must hold the
+    rank-mean of the SUM of both micro-steps' gradients (the reference accumulates without dividing, trainer.py:94-116)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_accum_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(2):
+        rank, micro, flat = q.get(timeout=120)
+        res[rank] = (micro, flat)
+    for p in procs:
+        p.join(timeout=60)
+    codes = [p.exitcode for p in procs]
+    _reap(procs)
+    assert codes == [0, 0], codes
+    expect = torch.cat([(0.5 * (res[0][0][0][k] + res[0][0][1][k] + res[1][0][0][k] + res[1][0][1][k])).reshape(-1)
+                        for k in range(6)])
+    assert torch.allclose(res[0][1], expect, atol=1e-6) and torch.equal(res[0][1], res[1][1])

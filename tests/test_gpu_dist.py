@@ -27,8 +27,9 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _one_step(rank, world, shard):
-    """Build the small U-Net (per-rank init seed), broadcast, run one training step on `shard` of the common batch."""
+def _one_step(rank, world, shard, micro=1):
+    """Build the small U-Net (per-rank init seed), broadcast, run one training step on `shard` of the common batch
+    (`micro` > 1: the shard in that many accumulated micro-steps, trainer.py:94-116 with training.iter_size = micro)."""
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle.gen_golden import fixed_draws, train_step_inputs
@@ -50,20 +51,32 @@ def _one_step(rank, world, shard):
     sde = sde_lib.VPSDE(cfg.model.beta_min, cfg.model.beta_max, cfg.model.num_scales, device="cuda")
     step_fn = losses.get_step_fn(sde, train=True, optimize_fn=losses.optimization_manager(cfg), mask=mask.cuda())
     state = dict(model=model, ema=ema, optimizer=opt, step=1)
-    with fixed_draws(labels[shard].cuda(), noise[shard].cuda()):
-        loss = step_fn(state, batch[shard].cuda())["loss"]
+    idx = list(range(B_TOTAL))[shard] if isinstance(shard, slice) else list(shard)
+    per = len(idx) // micro
+    loss = 0.0
+    for m in range(micro):
+        sel = idx[m * per:(m + 1) * per]
+        with fixed_draws(labels[sel].cuda(), noise[sel].cuda()):
+            loss = loss + step_fn(state, batch[sel].cuda(), clear_grad=(m == 0), update_param=(m == micro - 1))["loss"] / micro
     return (float(loss.detach()), [p.detach().cpu().clone() for p in model.parameters()],
             [p.grad.detach().cpu().clone() for p in model.parameters() if p.grad is not None])
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, micro=1):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
     from meshdiffusion_amd.lib.diffusion import parallel
     parallel.init_distributed(backend="gloo")
     per = B_TOTAL // world
-    loss, params, grads = _one_step(rank, world, slice(rank * per, (rank + 1) * per))
+    # micro > 1: rank r's micro-step m takes samples [m*B/micro + r*per/micro, ...): the union over ranks of micro-step m is
+    # the m-th contiguous block of the batch, i.e. what a single process accumulating `micro` steps of B/micro would see
+    if micro > 1:
+        pm = per // micro
+        sel = [m * (B_TOTAL // micro) + rank * pm + k for m in range(micro) for k in range(pm)]
+        loss, params, grads = _one_step(rank, world, sel, micro=micro)
+    else:
+        loss, params, grads = _one_step(rank, world, slice(rank * per, (rank + 1) * per))
     q.put((rank, loss, [t.numpy() for t in params], [t.numpy() for t in grads]))       # by value: the child exits before the parent reads
     dist.barrier()
     dist.destroy_process_group()
@@ -99,6 +112,38 @@ def test_two_replicas_one_step_equals_full_batch_step(hip_lib):
 
     assert len(res[0][2]) == len(grads_full) and rel(res[0][2], grads_full) < 1e-5
     # ... and so is the update, up to Adam's first step turning 1e-7 differences of near-zero gradients into +-lr
+    assert rel(res[0][1], params_full) < 1e-4
+
+
+def test_two_replicas_gradient_accumulation_equals_single_process_accumulation(hip_lib):
+    """VERDICT r02 item 3(iv) on the HIP path: training.iter_size = 2 on two replicas (micro-step 1 accumulates locally, the
+    in-place bucket all-reduces ride under micro-step 2's backward) == one process accumulating the same two micro-batches."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, 2)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    try:
+        for _ in range(2):
+            rank, loss, params, grads = q.get(timeout=300)
+            res[rank] = (loss, [torch.from_numpy(a) for a in params], [torch.from_numpy(a) for a in grads])
+        for p in procs:
+            p.join(timeout=120)
+            assert p.exitcode == 0
+    finally:
+        _reap(procs)
+    for a, b in zip(res[0][1], res[1][1]):
+        assert torch.equal(a, b)
+    loss_full, params_full, grads_full = _one_step(0, 1, slice(0, B_TOTAL), micro=2)
+
+    def rel(xs, ys):
+        num = sum(float((a.double() - b.double()).pow(2).sum()) for a, b in zip(xs, ys))
+        return (num / sum(float(b.double().pow(2).sum()) for b in ys)) ** 0.5
+
+    assert abs(0.5 * (res[0][0] + res[1][0]) - loss_full) < 1e-5 * abs(loss_full)
+    assert len(res[0][2]) == len(grads_full) and rel(res[0][2], grads_full) < 1e-5
     assert rel(res[0][1], params_full) < 1e-4
 
 

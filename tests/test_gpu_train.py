@@ -150,11 +150,13 @@ def test_whole_unet_backward_and_train_step_vs_oracle_autograd(hip_lib, arch, B)
     assert len(moved) == len(grads) and state["step"] == 2 and ema.num_updates == 1
 
 
-@pytest.mark.parametrize("case", ["small_res64", "small_res128", "res64"])
+@pytest.mark.parametrize("case", ["small_res64", "small_res128", "res64", "res64_b2"])
 def test_loss_and_gradients_vs_reference_golden(hip_lib, case):
     """The UNMODIFIED reference loss function run on the CPU by oracle/gen_golden.py (train mode, dropout 0, fixed
     labels/noise) pins loss and every parameter gradient of the HIP path -- `res64` is the real 364 M-parameter
-    network at B = 1 (the autograd reference takes 40 s on the build host; here only its recorded norms/samples)."""
+    network at B = 1 (the autograd reference takes 40 s on the build host; here only its recorded norms/samples);
+    `res64_b2` (train_grads_b2.npz) the same at B = 2, where the 32^3 levels run through the Winograd forward /
+    data-gradient kernels as well (hip_ops.wino_ok), so those are pinned to the reference's autograd at two grid sizes."""
     import os
     from conftest import GOLD
     from oracle.gen_golden import fixed_draws, train_step_inputs
@@ -162,8 +164,9 @@ def test_loss_and_gradients_vs_reference_golden(hip_lib, case):
     from meshdiffusion_amd.config import get_config_res64
     from meshdiffusion_amd.lib.diffusion import losses, sde_lib
     from meshdiffusion_amd.lib.diffusion.models import ddpm_res64, ddpm_res128, utils as mutils  # noqa: F401
-    gold = np.load(os.path.join(GOLD, "train_grads.npz"))
-    cfg = {"small_res64": synth.small_config, "small_res128": synth.small_config_res128, "res64": get_config_res64}[case]()
+    gold = np.load(os.path.join(GOLD, "train_grads_b2.npz" if case == "res64_b2" else "train_grads.npz"))
+    cfg = {"small_res64": synth.small_config, "small_res128": synth.small_config_res128, "res64": get_config_res64,
+           "res64_b2": get_config_res64}[case]()
     cfg.device = torch.device("cuda")
     cfg.model.dropout = 0.0
     R, B = cfg.data.image_size, int(gold[f"{case}_B"])
@@ -175,9 +178,18 @@ def test_loss_and_gradients_vs_reference_golden(hip_lib, case):
     batch, labels, noise, mask = train_step_inputs(B, R, seed=2024)
     sde = sde_lib.VPSDE(cfg.model.beta_min, cfg.model.beta_max, cfg.model.num_scales, device="cuda")
     loss_fn = losses.get_ddpm_loss_fn(sde, train=True, mask=mask.cuda())
-    with fixed_draws(labels.cuda(), noise.cuda()):
-        loss = loss_fn(model, batch.cuda())
-    loss.backward()
+    from meshdiffusion_amd import hip_ops
+    wino_launches = []
+    real_wino = hip_ops.conv3_wino
+    hip_ops.conv3_wino = lambda ww, t, B_, S_, **kw: (wino_launches.append(S_), real_wino(ww, t, B_, S_, **kw))[1]
+    try:
+        with fixed_draws(labels.cuda(), noise.cuda()):
+            loss = loss_fn(model, batch.cuda())
+        loss.backward()
+    finally:
+        hip_ops.conv3_wino = real_wino
+    if case == "res64_b2":      # the point of this case: Winograd launches (forward and data gradient) at both grid sizes
+        assert hip_ops.WINO and wino_launches.count(64) >= 20 and wino_launches.count(32) >= 20, sorted(set(wino_launches))
     ref_loss = float(gold[f"{case}_loss"])
     assert abs(float(loss.detach()) - ref_loss) / ref_loss < 2e-5
     gnorm = float(gold[f"{case}_gnorm"])
@@ -323,3 +335,63 @@ def test_flat_optimizer_state_follows_replaced_parameter_storage(hip_lib):
     moved = sum(float((p.detach() - q).abs().sum()) for p, q in zip((p for p in model.parameters() if p.requires_grad), before))
     assert moved > 0, "the live parameters did not train after their storage was replaced"
     assert fs1.opt_steps == 2                          # Adam state (incl. the step count) carried over
+
+
+def test_res64_batch8_training_gradients_winograd_vs_direct_kernels(hip_lib):
+    """the whole res64 loss + backward at the bench / training batch (B = 8), once with the Winograd
+    forward and data-gradient convs (64^3, 32^3 AND 16^3 levels at this batch) and once with the direct kernels
+    (MD_WINO=0, the build pinned to the reference's autograd by `res64` / `res64_b2` above): loss and all 494 parameter
+    gradients must agree to 5e-5."""
+    from oracle.gen_golden import fixed_draws, train_step_inputs
+    from meshdiffusion_amd import hip_ops, synth
+    from meshdiffusion_amd.config import get_config_res64
+    from meshdiffusion_amd.lib.diffusion import losses, sde_lib
+    from meshdiffusion_amd.lib.diffusion.models import ddpm_res64, utils as mutils  # noqa: F401
+    cfg = get_config_res64(); cfg.device = torch.device("cuda")
+    cfg.model.dropout = 0.0
+    R, B = 64, 8
+    model = mutils.create_model(cfg)
+    sd = synth.sensitised_state_dict(model.module.state_dict(), seed=1234, grid_mask=synth.synthetic_grid_mask(R))
+    model.module.load_state_dict(sd, strict=True)
+    del sd
+    batch, labels, noise, mask = train_step_inputs(B, R, seed=2024)
+    sde = sde_lib.VPSDE(cfg.model.beta_min, cfg.model.beta_max, cfg.model.num_scales, device="cuda")
+    loss_fn = losses.get_ddpm_loss_fn(sde, train=True, mask=mask.cuda())
+    runs = {}
+    keep = hip_ops.WINO
+    try:
+        for wino in (True, False):
+            hip_ops.WINO = wino
+            seen = []
+            real = hip_ops.conv3_wino
+            hip_ops.conv3_wino = lambda ww, t, B_, S_, **kw: (seen.append(S_), real(ww, t, B_, S_, **kw))[1]
+            try:
+                for p in model.parameters():
+                    p.grad = None
+                with fixed_draws(labels.cuda(), noise.cuda()):
+                    loss = loss_fn(model, batch.cuda())
+                loss.backward()
+            finally:
+                hip_ops.conv3_wino = real
+            runs[wino] = (float(loss.detach()), {n: p.grad.detach().cpu().clone() for n, p in model.module.named_parameters()
+                                                 if p.grad is not None}, sorted(set(seen)))
+    finally:
+        hip_ops.WINO = keep
+    (l1, g1, s1), (l0, g0, s0) = runs[True], runs[False]
+    assert s1 == [16, 32, 64] and s0 == [], (s1, s0)
+    assert abs(l1 - l0) <= 2e-6 * abs(l0), (l1, l0)
+    assert g1.keys() == g0.keys() and len(g0) == 494
+    gsq = sum(float(g.double().square().sum()) for g in g0.values())
+    ntot = sum(g.numel() for g in g0.values())
+    num, worst = 0.0, ("", 0.0)
+    for n in g0:
+        d = float((g1[n].double() - g0[n].double()).square().sum())
+        num += d
+        # per tensor: relative to its own norm, floored at the norm an average-sized entry would give this tensor
+        floor = (gsq / ntot * g0[n].numel()) ** 0.5 * 1e-2
+        e = d ** 0.5 / max(float(g0[n].double().norm()), floor)
+        if e > worst[1]:
+            worst = (n, e)
+    print(f"res64 B=8 training gradients, Winograd vs direct kernels: loss {l1:.6f} / {l0:.6f}, all gradients rel-L2 "
+          f"{(num / gsq) ** 0.5:.3e}, worst tensor {worst}")
+    assert (num / gsq) ** 0.5 < 5e-5 and worst[1] < 5e-5
