@@ -251,10 +251,13 @@ class WinoWeight:
               "md_wino_pack_weights")
 
 
+WINO_MIN_WGS = int(os.environ.get("MD_WINO_MIN_WGS", "256"))   # fewest workgroups the Winograd kernel is launched with
+
+
 def wino_ok(rows, kdim, S, B):
     """Shapes md_conv3_wino takes AND fills the chip with (one workgroup per CU, 128 rows x 4x8x8 positions each)."""
     return (WINO and PRECISION == "bf16x3" and rows % 128 == 0 and kdim % 32 == 0 and S % 8 == 0
-            and B * (S ** 3 // 256) * (rows // 128) >= 256)
+            and B * (S ** 3 // 256) * (rows // 128) >= WINO_MIN_WGS)
 
 
 _WINO_SCRATCH = {}
