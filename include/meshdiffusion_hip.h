@@ -42,7 +42,7 @@ extern "C" {
 #define MD_ERR_UNSUPPORTED (-2)
 #define MD_ERR_NO_DEVICE (-3)
 
-#define MD_ABI_VERSION 8
+#define MD_ABI_VERSION 9
 
 /* ---- tile configurations of md_gemm_conv (compile-time instantiations) ---- */
 enum {
@@ -286,6 +286,14 @@ int md_conv3_wino(const void* t_in, const void* wpk, float* out, const float* bi
 int md_wino_prep_v2(const float* x1, const float* x2, int32_t c1, int32_t c2, const float* ac, int32_t silu, int32_t ups,
                     void* t_out, int32_t batch, int32_t D, int32_t H, int32_t W, float drop_p, uint64_t drop_seed, void* stream);
 
+/* md_wino_prep_v2 with a second output u_out in the layout of T: per output pair (x = 2i, 2i+1) of the (activated) tensor
+ * v the four values (v[2i], v[2i] + v[2i+1], v[2i] - v[2i+1], v[2i+1]), hi / lo bf16 planes -- the dY operand of
+ * md_wgrad_wino when the tensor is an output gradient (training backward: one pass over dY feeds both the Winograd data
+ * gradient conv, T, and the Winograd weight gradient, U).  Same shape restrictions as md_wino_prep_v2. */
+int md_wino_prep_dual(const float* x1, const float* x2, int32_t c1, int32_t c2, const float* ac, int32_t silu, int32_t ups,
+                      void* t_out, void* u_out, int32_t batch, int32_t D, int32_t H, int32_t W, float drop_p,
+                      uint64_t drop_seed, void* stream);
+
 /*
  * md_attn_fwd: fused single-head self-attention (AttnBlock.forward, layers.py:595-608: the two einsums :602,:606 and the
  * softmax :604) -- QK^T, online softmax over the keys and PV in one kernel, bf16x3 MFMA for both contractions; the
@@ -399,6 +407,22 @@ int64_t md_wgrad_workspace_bytes(int32_t rows, int32_t cols, int32_t taps, int32
 int md_wgrad(const void* dy_pb, const void* act_pb, float* dw, void* workspace, int64_t workspace_bytes, int32_t batch,
              int32_t a_ch, int32_t b_ch, int32_t rows, int32_t cols, int32_t D, int32_t H, int32_t W, int32_t guard,
              int32_t taps, int32_t ksplit, int64_t s_row, int64_t s_k, int64_t s_tap, void* stream);
+
+/*
+ * md_wgrad_wino: weight gradient of a 3x3x3 stride-1 convolution in the Winograd F(2,3)-along-w domain (csrc/wgrad_wino.hip;
+ * autograd of nn.Conv3d, layers.py:118-124, for the layers whose forward runs through md_conv3_wino):
+ *   dw[co*s_row + ci*s_k + ((kd*3+kh)*3+kw)*s_tap] += sum_{sample, position} dY[co][pos] * A[ci][pos + (kd-1, kh-1, kw-1)]
+ * from  u_dy  = md_wino_prep_dual's second output for dY            [B][co/8][4][2][D][H][W/2][8 bf16]
+ *       t_act = the operand T of the forward convolution (md_wino_prep / _v2 of the activated input, kept from the forward)
+ * 4 products per output pair and (kd, kh) instead of 6 (2/3 of md_wgrad's matrix-core work), no PB16 re-layout; bf16x3 MFMA,
+ * fp32 accumulate.  co, ci multiples of 128; W in {32, 64} (rows of 16 / 32 pairs), D, H >= 2.  The contraction is split
+ * into `ksplit` ranges of (sample, z) planes (1 <= ksplit <= batch * (D - 1)); partial sums live in `workspace`
+ * (md_wgrad_wino_workspace_bytes) and are reduced in a fixed order: results are run-to-run identical.
+ */
+int64_t md_wgrad_wino_workspace_bytes(int32_t co, int32_t ci, int32_t ksplit);
+int md_wgrad_wino(const void* u_dy, const void* t_act, float* dw, void* workspace, int64_t workspace_bytes, int32_t batch,
+                  int32_t co, int32_t ci, int32_t D, int32_t H, int32_t W, int32_t ksplit, int64_t s_row, int64_t s_k,
+                  int64_t s_tap, void* stream);
 int md_gn_bwd_stats(const float* x, const float* dy, const float* params, double* sums, int32_t batch, int32_t C,
                     int64_t P, int32_t c_total, int32_t c_off, int32_t dy_ctotal, int32_t silu, float drop_p,
                     uint64_t drop_seed, void* stream);

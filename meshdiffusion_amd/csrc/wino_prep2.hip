@@ -15,10 +15,14 @@ constexpr int P2_POS = 256;               // positions per workgroup
 constexpr int P2_STRIDE = 12;             // floats per position in LDS (8 + pad: 48 B keeps 16-byte alignment, 2-way bank conflicts)
 }  // namespace
 
+// DUAL (md_wino_prep_dual): also writes U, the transposed algorithm's transform of the same activated tensor,
+//   u = (d1, d1 + d2, d1 - d2, d2) per pair (d1, d2 = the pair's own two positions), in the layout of T -- the dY operand of
+//   the Winograd weight gradient (csrc/wgrad_wino.hip) when the tensor is an output gradient.
+template <bool DUAL>
 __global__ __launch_bounds__(256) void md_wino_prep2_kernel(const float* __restrict__ x1, const float* __restrict__ x2,
                                                             int c1, int c2, const float* __restrict__ ac, int silu, int ups,
-                                                            uint4* __restrict__ T, int batch, int D, int H, int W,
-                                                            uint32_t thr16, float drop_scale, uint64_t seed) {
+                                                            uint4* __restrict__ T, uint4* __restrict__ U, int batch, int D, int H,
+                                                            int W, uint32_t thr16, float drop_scale, uint64_t seed) {
   __shared__ __attribute__((aligned(16))) float act[P2_POS * P2_STRIDE];
   const int tid = threadIdx.x;
   const int Wp = W >> 1;
@@ -108,12 +112,28 @@ __global__ __launch_bounds__(256) void md_wino_prep2_kernel(const float* __restr
       out[(int64_t)(f * 2) * Ph] = make_uint4(hw[0], hw[1], hw[2], hw[3]);
       out[(int64_t)(f * 2 + 1) * Ph] = make_uint4(lw[0], lw[1], lw[2], lw[3]);
     }
+    if constexpr (DUAL) {
+      uint4* uo = U + ((int64_t)b * CG + cg) * 8 * Ph + pos2;
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const int f = 2 * fh + g;
+        float t[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          t[e] = f == 0 ? d[1][e] : f == 1 ? d[1][e] + d[2][e] : f == 2 ? d[1][e] - d[2][e] : d[2][e];
+        uint32_t hw[4], lw[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) md_split2(t[2 * q], t[2 * q + 1], hw[q], lw[q]);
+        uo[(int64_t)(f * 2) * Ph] = make_uint4(hw[0], hw[1], hw[2], hw[3]);
+        uo[(int64_t)(f * 2 + 1) * Ph] = make_uint4(lw[0], lw[1], lw[2], lw[3]);
+      }
+    }
   }
 }
 
-extern "C" int md_wino_prep_v2(const float* x1, const float* x2, int32_t c1, int32_t c2, const float* ac, int32_t silu,
-                               int32_t ups, void* t_out, int32_t batch, int32_t D, int32_t H, int32_t W, float drop_p,
-                               uint64_t drop_seed, void* stream) {
+static int md_wino_prep2_launch(const float* x1, const float* x2, int32_t c1, int32_t c2, const float* ac, int32_t silu,
+                                int32_t ups, void* t_out, void* u_out, int32_t batch, int32_t D, int32_t H, int32_t W, float drop_p,
+                                uint64_t drop_seed, void* stream) {
   if (!x1 || !t_out || batch <= 0 || c1 <= 0 || c2 < 0 || (c1 & 7) || (c2 & 7) || (c2 > 0 && !x2)) return MD_ERR_BAD_ARG;
   if (silu && !ac) return MD_ERR_BAD_ARG;      // SiLU is applied together with the folded GroupNorm affine only
   if (D <= 0 || H <= 0 || W <= 0 || (W & 1) || (ups && ((D | H | W) & 1))) return MD_ERR_BAD_ARG;
@@ -123,8 +143,27 @@ extern "C" int md_wino_prep_v2(const float* x1, const float* x2, int32_t c1, int
   const int64_t blocks = (int64_t)batch * ((c1 + c2) / 8) * (P / P2_POS);
   if (blocks > 0x7fffffff) return MD_ERR_UNSUPPORTED;
   MD_HIP_CLEAR_ERROR();
-  hipLaunchKernelGGL(md_wino_prep2_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x1, x2, c1, c2, ac, silu,
-                     ups, (uint4*)t_out, batch, D, H, W, md_drop_thr16(drop_p), 1.0f / (1.0f - drop_p), drop_seed);
+  if (u_out)
+    hipLaunchKernelGGL((md_wino_prep2_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x1, x2, c1, c2, ac,
+                       silu, ups, (uint4*)t_out, (uint4*)u_out, batch, D, H, W, md_drop_thr16(drop_p), 1.0f / (1.0f - drop_p),
+                       drop_seed);
+  else
+    hipLaunchKernelGGL((md_wino_prep2_kernel<false>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x1, x2, c1, c2, ac,
+                       silu, ups, (uint4*)t_out, (uint4*)nullptr, batch, D, H, W, md_drop_thr16(drop_p), 1.0f / (1.0f - drop_p),
+                       drop_seed);
   MD_HIP_CHECK_LAUNCH();
   return MD_OK;
+}
+
+extern "C" int md_wino_prep_v2(const float* x1, const float* x2, int32_t c1, int32_t c2, const float* ac, int32_t silu,
+                               int32_t ups, void* t_out, int32_t batch, int32_t D, int32_t H, int32_t W, float drop_p,
+                               uint64_t drop_seed, void* stream) {
+  return md_wino_prep2_launch(x1, x2, c1, c2, ac, silu, ups, t_out, nullptr, batch, D, H, W, drop_p, drop_seed, stream);
+}
+
+extern "C" int md_wino_prep_dual(const float* x1, const float* x2, int32_t c1, int32_t c2, const float* ac, int32_t silu,
+                                 int32_t ups, void* t_out, void* u_out, int32_t batch, int32_t D, int32_t H, int32_t W,
+                                 float drop_p, uint64_t drop_seed, void* stream) {
+  if (!u_out) return MD_ERR_BAD_ARG;
+  return md_wino_prep2_launch(x1, x2, c1, c2, ac, silu, ups, t_out, u_out, batch, D, H, W, drop_p, drop_seed, stream);
 }

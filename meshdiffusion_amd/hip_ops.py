@@ -263,11 +263,11 @@ def wino_ok(rows, kdim, S, B):
 _WINO_SCRATCH = {}
 
 
-def _wino_scratch(n_bf16, device):
+def _wino_scratch(n_bf16, device, slot="t"):
     """T is written by md_wino_prep and read by the md_conv3_wino launched right after it on the same stream, so every
     (prep, conv) pair of a process can share ONE buffer, grown to the largest operand seen: no multi-GB allocation per conv
     (the caching allocator otherwise splits / re-merges 2-4 GB blocks among the training tape's tensors)."""
-    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream, slot)
     buf = _WINO_SCRATCH.get(key)
     if buf is None or buf.numel() < n_bf16:
         _WINO_SCRATCH.pop(key, None)
@@ -282,9 +282,11 @@ def release_scratch():
     _WINO_SCRATCH.clear()
 
 
-def wino_prep(parts, ac, silu, ups, B, S, drop=None):
+def wino_prep(parts, ac, silu, ups, B, S, drop=None, keep=False, dual=False):
     """fp32 F32B parts (+ folded GroupNorm affine, SiLU, nearest-x2 upsampling) -> transformed split operand T.
-    drop = (p, seed): training dropout after SiLU, the mask gn_apply(drop=...) produces for the same pair."""
+    drop = (p, seed): training dropout after SiLU, the mask gn_apply(drop=...) produces for the same pair.
+    keep: T goes to its own tensor instead of the shared scratch buffer (training forward: the Winograd weight gradient of the
+    backward reads it again).  dual: returns (T, U) -- U = the dY operand of md_wgrad_wino (md_wino_prep_dual)."""
     lib = _lib.load()
     cin = sum(c for _, c in parts)
     assert 1 <= len(parts) <= 2
@@ -292,15 +294,48 @@ def wino_prep(parts, ac, silu, ups, B, S, drop=None):
     nbytes = lib.md_wino_operand_bytes(B, cin, S, S, S)
     if nbytes <= 0:
         raise _lib.MeshDiffusionHipError("md_wino_operand_bytes: unsupported operand shape")
-    t = _wino_scratch(nbytes // 2, parts[0][0].device)
+    dev = parts[0][0].device
+    t = torch.empty(nbytes // 2, dtype=torch.bfloat16, device=dev) if keep else _wino_scratch(nbytes // 2, dev)
     x2, c2 = (parts[1][0], parts[1][1]) if len(parts) == 2 else (None, 0)
     ev = _prof_begin()
-    fn = lib.md_wino_prep_v2 if (WINO_PREP_V2 and 256 % S == 0) else lib.md_wino_prep
-    check(fn(_ptr(parts[0][0]), _ptr(x2), parts[0][1], c2, _ptr(ac), 1 if silu else 0, 1 if ups else 0,
-             _ptr(t), B, S, S, S, drop[0] if drop else 0.0, drop[1] if drop else 0, _stream()), "md_wino_prep")
-    _prof_end(ev, "wino_prep", 0.0, 4.0 * B * cin * (S ** 3 // (8 if ups else 1)) + 8.0 * B * cin * S ** 3,   # fp32 in, 2 x bf16 x 2 out
-              f"{cin}@{S}x{S}x{S}" + ("/ups" if ups else ""))
-    return t
+    args = (_ptr(parts[0][0]), _ptr(x2), parts[0][1], c2, _ptr(ac), 1 if silu else 0, 1 if ups else 0)
+    tail = (B, S, S, S, drop[0] if drop else 0.0, drop[1] if drop else 0, _stream())
+    if dual:
+        if 256 % S:
+            raise _lib.MeshDiffusionHipError("md_wino_prep_dual needs W | 256")
+        u = _wino_scratch(nbytes // 2, dev, slot="u")
+        check(lib.md_wino_prep_dual(*args, _ptr(t), _ptr(u), *tail), "md_wino_prep_dual")
+    else:
+        fn = lib.md_wino_prep_v2 if (WINO_PREP_V2 and 256 % S == 0) else lib.md_wino_prep
+        check(fn(*args, _ptr(t), *tail), "md_wino_prep")
+    _prof_end(ev, "wino_prep", 0.0, 4.0 * B * cin * (S ** 3 // (8 if ups else 1)) + (16.0 if dual else 8.0) * B * cin * S ** 3,   # fp32 in, 2 x bf16 x 2 out
+              f"{cin}@{S}x{S}x{S}" + ("/ups" if ups else "") + ("/dual" if dual else ""))
+    return (t, u) if dual else t
+
+
+# Winograd weight gradient (csrc/wgrad_wino.hip): the training backward of the layers on the Winograd path contracts the
+# forward's operand T (kept on the tape) with the transformed output gradient -- no S16B activations, no PB16 re-layout
+WGRAD_WINO = os.environ.get("MD_WGRAD_WINO", "1") == "1"
+
+
+def wgrad_wino_ok(co, ci, S, B):
+    """Layers whose weight gradient md_wgrad_wino takes: on the Winograd forward path, whole 128-channel tiles, rows of 16 / 32 pairs."""
+    return WGRAD_WINO and WINO_TRAIN_FWD and S in (32, 64) and co % 128 == 0 and ci % 128 == 0 and wino_ok(co, ci, S, B)
+
+
+def wgrad_wino(u_dy, t_act, B, co, ci, S, dw):
+    """dw[co][ci][27] += weight gradient from U (md_wino_prep_dual of dY) and the forward's T -- md_wgrad_wino."""
+    lib = _lib.load()
+    units = (co // 128) * (ci // 128) * 12
+    ksplit = max(1, min(256 // units, B * (S - 1)))
+    nbytes = lib.md_wgrad_wino_workspace_bytes(co, ci, ksplit)
+    if nbytes <= 0:
+        raise _lib.MeshDiffusionHipError("md_wgrad_wino_workspace_bytes: unsupported shape")
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=u_dy.device)
+    ev = _prof_begin()
+    check(lib.md_wgrad_wino(_ptr(u_dy), _ptr(t_act), _ptr(dw), _ptr(ws), nbytes, B, co, ci, S, S, S, ksplit, ci * 27, 27, 1,
+                            _stream()), "md_wgrad_wino")
+    _prof_end(ev, "wgrad_wino", 2.0 * B * co * ci * 27 * S ** 3, 16.0 * B * (co + ci) * S ** 3 / 2, f"{ci}->{co}@{S}x{S}x{S}")
 
 
 WINO_VARIANT = int(os.environ.get("MD_WINO_VARIANT", "0"))

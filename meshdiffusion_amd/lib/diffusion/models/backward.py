@@ -174,12 +174,15 @@ def dgrad_wino_weight(layer, name, conv):
 
 
 def conv3_backward(layer, name, conv, dy, act_s16, B, S_out, ups=0, stride=1, need_dx=True, act_channels=None,
-                   bias_sums=None, shared=None):
+                   bias_sums=None, shared=None, t_act=None):
     """Backward of y = conv k^3 (act) (+bias), k = 3 (any layer) or 5 (stem / head of ddpm_res128, stride 1).
     dy: F32B [B][co][S_out^3]; act_s16: S16B input operand of the forward (coarse grid when ups, fine grid 2*S_out
     when stride 2).  Returns dx (F32B) or None.
     shared: dict cache of tensors derived from `dy` (its PB16 operand, its S16B split) when another layer consumes the same
-    gradient (the ResnetBlock's Conv_1 and shortcut NIN_0 both start from the block's output gradient)."""
+    gradient (the ResnetBlock's Conv_1 and shortcut NIN_0 both start from the block's output gradient).
+    t_act: the forward conv's Winograd operand T (layers on the Winograd path, hip_ops.wgrad_wino_ok) in place of `act_s16`:
+    ONE pass over dy (md_wino_prep_dual) feeds the Winograd data-gradient conv and the Winograd weight gradient (md_wgrad_wino);
+    no S16B / PB16 tensors at all."""
     from . import layers
     co, ci, ksz = conv.weight.shape[0], conv.weight.shape[1], conv.weight.shape[-1]
     taps, pad = ksz ** 3, ksz // 2
@@ -191,6 +194,16 @@ def conv3_backward(layer, name, conv, dy, act_s16, B, S_out, ups=0, stride=1, ne
     if bias_sums is not False:   # False: the caller owns the bias gradient (ResnetBlock Conv_0: FiLM shares the sums)
         bs = bias_sums if bias_sums is not None else channel_sums(dy, B, co_t, P)
         _grad_of(conv.bias).add_(bs.sum(0)[:co])
+    if t_act is not None:
+        assert ksz == 3 and stride == 1 and co == co_t
+        t_dy, u_dy = ops.wino_prep([(dy, co)], None, False, False, B, S_out, dual=True)
+        ops.wgrad_wino(u_dy, t_act, B, co, ci, S_out, _grad_of(conv.weight))
+        if not need_dx:
+            return None
+        dx = ops.conv3_wino(dgrad_wino_weight(layer, name, conv), t_dy, B, S_out)
+        if ups:
+            dx = resample(dx, B, ci, S_out // 2, 0)
+        return dx
     # weight gradient
     S_fine = S_out * stride
     if stride == 2:

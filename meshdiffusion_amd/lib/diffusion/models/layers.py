@@ -130,7 +130,9 @@ def run_conv3(pw, act_s16, B, S_out, *, bias=None, bias_bstride=0, residual=None
     `wino_only` (training: `drop` = (p, seed) allowed) it only describes the operand of the Winograd path and the direct
     kernel keeps reading `act_s16`.
     wino (with b_f32): builder of the layer's WinoWeight (conv3_wino_packed); where hip_ops.wino_ok says so the conv runs as
-    md_wino_prep + md_conv3_wino (Winograd F(2,3) along w: 2/3 of the matrix-core work) instead of the direct kernel."""
+    md_wino_prep + md_conv3_wino (Winograd F(2,3) along w: 2/3 of the matrix-core work) instead of the direct kernel.
+    b_f32["keep"] (training, layers with hip_ops.wgrad_wino_ok): the operand T is allocated on its own and handed back as
+    b_f32["t_out"]; `act_s16` may then be None (nothing else reads the S16B activation of such a layer)."""
     P = S_out ** 3
     dev = act_s16.device if act_s16 is not None else b_f32["parts"][0][0].device
     rows_alloc = rows_alloc if rows_alloc is not None else ((pw.rows + 7) // 8) * 8
@@ -141,7 +143,10 @@ def run_conv3(pw, act_s16, B, S_out, *, bias=None, bias_bstride=0, residual=None
     if (b_f32 is not None and wino is not None and out_mode == ops.OUT_F32B and rows_alloc == pw.rows
             and pw.prec == ops.PREC_BF16X3 and ops.wino_ok(pw.rows, pw.kdim, S_out, B)):
         stats = torch.zeros((B, rows_alloc, 2), dtype=torch.float64, device=dev) if want_stats and ops.FUSE_GN_STATS else None
-        t = ops.wino_prep(b_f32["parts"], b_f32.get("ac"), b_f32.get("silu"), ups, B, S_out, drop=b_f32.get("drop"))
+        t = ops.wino_prep(b_f32["parts"], b_f32.get("ac"), b_f32.get("silu"), ups, B, S_out, drop=b_f32.get("drop"),
+                          keep=bool(b_f32.get("keep")))
+        if b_f32.get("keep"):
+            b_f32["t_out"] = t           # training: the Winograd weight gradient reads the operand again (tape)
         ops.conv3_wino(wino(), t, B, S_out, bias=bias, bias_bstride=bias_bstride, residual=residual,
                        res_bstride=res_bstride or 0, stats=stats, out=out)
         if stats is not None:
@@ -295,19 +300,23 @@ class Upsample(HipLayer):
         if tape is None and fused_operand_ok(pw) and pw.kdim == Cc:   # the conv splits the raw fp32 input while loading it
             return run_conv3(pw, None, B, s_out, bias=self.Conv_0.bias, ups=1, want_stats=True,
                              b_f32=dict(parts=[(x, Cc)], ac=None, silu=False), wino=conv3_wino_packed(self, "w", self.Conv_0))
-        act = ops.gn_apply([(x, Cc)], None, B, P, norm=False, silu=False, fp16=pw.prec == ops.PREC_FP16X2)
         fw = None
+        ww = (tape is not None and pw.prec == ops.PREC_BF16X3 and pw.kdim == Cc
+              and ops.wgrad_wino_ok(pw.rows, pw.kdim, s_out, B))      # Winograd weight gradient: T instead of the S16B operand
+        act = None if ww else ops.gn_apply([(x, Cc)], None, B, P, norm=False, silu=False, fp16=pw.prec == ops.PREC_FP16X2)
         if tape is not None:
             assert pw.prec == ops.PREC_BF16X3
-            tape.append(dict(layer=self, act=act, B=B, S_out=s_out))
             if ops.WINO_TRAIN_FWD:
-                fw = dict(parts=[(x, Cc)], ac=None, silu=False, wino_only=True)
-        return run_conv3(pw, act, B, s_out, bias=self.Conv_0.bias, ups=1, want_stats=True, b_f32=fw,
-                         wino=conv3_wino_packed(self, "w", self.Conv_0) if fw is not None else None)
+                fw = dict(parts=[(x, Cc)], ac=None, silu=False, wino_only=True, keep=ww)
+        out = run_conv3(pw, act, B, s_out, bias=self.Conv_0.bias, ups=1, want_stats=True, b_f32=fw,
+                        wino=conv3_wino_packed(self, "w", self.Conv_0) if fw is not None else None)
+        if tape is not None:
+            tape.append(dict(layer=self, act=act, t=fw.get("t_out") if fw else None, B=B, S_out=s_out))
+        return out
 
     def backward_blocked(self, sv, dy):
         from . import backward as bw
-        return bw.conv3_backward(self, "w", self.Conv_0, dy, sv["act"], sv["B"], sv["S_out"], ups=1)
+        return bw.conv3_backward(self, "w", self.Conv_0, dy, sv["act"], sv["B"], sv["S_out"], ups=1, t_act=sv.get("t"))
 
     def forward(self, x):
         parts, B, P, spatial = _parts_of(x)
@@ -410,23 +419,32 @@ class ResnetBlockDDPM(HipLayer):
         # training (tape): the convs go through the Winograd path where it applies (its operand pass repeats GroupNorm + SiLU
         # + dropout from the fp32 tensors); the S16B activations are still written: the weight gradients read them
         wino_fwd = tape is not None and not f16 and ops.WINO_TRAIN_FWD
+        # layers whose weight gradient runs in the Winograd domain (hip_ops.wgrad_wino_ok) keep the operand T of the forward
+        # conv on the tape and write NO S16B activation: nothing else would read it
+        ww0 = wino_fwd and pw0.kdim == cin and ops.wgrad_wino_ok(self.out_ch, cin, S, B)
+        ww1 = wino_fwd and pw1.kdim == self.out_ch and ops.wgrad_wino_ok(self.out_ch, self.out_ch, S, B)
         prm, ac0 = ops.gn_params(parts, g0.weight, g0.bias, B, P, eps=g0.eps, groups=g0.num_groups, want_ac=True)
-        f0 = dict(parts=parts, ac=ac0, silu=True, wino_only=True) if wino_fwd else None
+        f0 = dict(parts=parts, ac=ac0, silu=True, wino_only=True, keep=ww0) if wino_fwd else None
         w0 = conv3_wino_packed(self, "w0", self.Conv_0) if f0 is not None else None
-        a0 = ops.gn_apply(parts, prm, B, P, norm=True, silu=True, fp16=f16, want_raw=need_nin)
         xs = None
         res = None
-        if need_nin:
-            a0, xs = a0
-            if ops.NIN_SIDE_STREAM:
-                # The shortcut GEMM is HBM-bound and independent of Conv_0 (MFMA-bound): launch it on a second HIP
-                # stream so that it shares the GPU with the convolution instead of preceding Conv_1 serially.
-                main, side = torch.cuda.current_stream(), ops.side_stream()
-                side.wait_stream(main)
-                with torch.cuda.stream(side):
-                    res = self.NIN_0.forward_s16(xs, B, P)
-                res.record_stream(main)
-                xs.record_stream(side)
+        if ww0:
+            a0 = None
+            if need_nin:                 # the shortcut NIN (forward GEMM and its weight gradient) still takes the raw bf16 split
+                xs = ops.gn_apply(parts, None, B, P, norm=False, silu=False)
+        else:
+            a0 = ops.gn_apply(parts, prm, B, P, norm=True, silu=True, fp16=f16, want_raw=need_nin)
+            if need_nin:
+                a0, xs = a0
+        if need_nin and ops.NIN_SIDE_STREAM:
+            # The shortcut GEMM is HBM-bound and independent of Conv_0 (MFMA-bound): launch it on a second HIP
+            # stream so that it shares the GPU with the convolution instead of preceding Conv_1 serially.
+            main, side = torch.cuda.current_stream(), ops.side_stream()
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                res = self.NIN_0.forward_s16(xs, B, P)
+            res.record_stream(main)
+            xs.record_stream(side)
         if bias0 is not None:
             h = run_conv3(pw0, a0, B, S, bias=bias0, bias_bstride=bias0_stride, want_stats=True, b_f32=f0, wino=w0)
         elif temb is not None:   # per-(sample, channel) additive bias = Conv_0.b + Dense_0(SiLU(temb))
@@ -435,8 +453,8 @@ class ResnetBlockDDPM(HipLayer):
         else:
             h = run_conv3(pw0, a0, B, S, bias=self.Conv_0.bias, want_stats=True, b_f32=f0, wino=w0)
         prm1, ac1 = ops.gn_params([(h, self.out_ch)], g1.weight, g1.bias, B, P, eps=g1.eps, groups=g1.num_groups, want_ac=True)
-        a1 = ops.gn_apply([(h, self.out_ch)], prm1, B, P, norm=True, silu=True, fp16=f16, drop=drop)
-        f1 = dict(parts=[(h, self.out_ch)], ac=ac1, silu=True, drop=drop, wino_only=True) if wino_fwd else None
+        a1 = None if ww1 else ops.gn_apply([(h, self.out_ch)], prm1, B, P, norm=True, silu=True, fp16=f16, drop=drop)
+        f1 = dict(parts=[(h, self.out_ch)], ac=ac1, silu=True, drop=drop, wino_only=True, keep=ww1) if wino_fwd else None
         w1 = conv3_wino_packed(self, "w1", self.Conv_1) if f1 is not None else None
         if need_nin:
             if res is None:
@@ -446,11 +464,12 @@ class ResnetBlockDDPM(HipLayer):
         else:
             assert len(parts) == 1
             res = parts[0][0]
+        out = run_conv3(pw1, a1, B, S, bias=self.Conv_1.bias, residual=res, want_stats=True, b_f32=f1, wino=w1)
         if tape is not None:
             assert not f16, "the backward pass uses the bf16x3 operand format"
             tape.append(dict(layer=self, parts=parts, prm0=prm, a0=a0, h=h, prm1=prm1, a1=a1, xs=xs, B=B, P=P, S=S,
-                             temb=temb, drop=drop))
-        return run_conv3(pw1, a1, B, S, bias=self.Conv_1.bias, residual=res, want_stats=True, b_f32=f1, wino=w1)
+                             temb=temb, drop=drop, t0=f0.get("t_out") if f0 else None, t1=f1.get("t_out") if f1 else None))
+        return out
 
     def backward_blocked(self, sv, dy):
         """dy: F32B [B][out_ch][P].  Returns ([grad per input part], dbias0 [B, out_ch]); accumulates .grad of
@@ -461,13 +480,13 @@ class ResnetBlockDDPM(HipLayer):
         # operand (both weight gradients) and its bf16 split (both data gradients) are computed once
         shared = {} if self.in_ch != self.out_ch else None
         bsum = bw.channel_sums(dy, B, self.out_ch, P)
-        d_a1 = bw.conv3_backward(self, "w1", self.Conv_1, dy, sv["a1"], B, S, bias_sums=bsum, shared=shared)
+        d_a1 = bw.conv3_backward(self, "w1", self.Conv_1, dy, sv["a1"], B, S, bias_sums=bsum, shared=shared, t_act=sv.get("t1"))
         dbias0 = torch.zeros((B, self.out_ch), dtype=torch.float32, device=dy.device)
         d_h = bw.gn_backward([(sv["h"], self.out_ch)], d_a1, sv["prm1"], self.GroupNorm_1, B, P, silu=True,
                              drop=sv.get("drop"), sums_out=dbias0)[0]     # d(bias0) = channel sums of d_h, same pass
         del d_a1
         # Conv_0.bias gradient = batch sum of dbias0: the FiLM caller adds it once together with Dense_0's
-        d_a0 = bw.conv3_backward(self, "w0", self.Conv_0, d_h, sv["a0"], B, S, bias_sums=False)
+        d_a0 = bw.conv3_backward(self, "w0", self.Conv_0, d_h, sv["a0"], B, S, bias_sums=False, t_act=sv.get("t0"))
         del d_h
         if self.in_ch != self.out_ch:
             d_xcat = bw.nin_backward(self.NIN_0, dy, sv["xs"], B, P, S, bias_sums=bsum, shared=shared)

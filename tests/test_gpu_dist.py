@@ -231,11 +231,11 @@ def test_cli_uncond_gen_two_ranks_per_shard_parity(hip_lib, tmp_path, monkeypatc
     from meshdiffusion_amd.lib.diffusion import parallel
     tmp = str(tmp_path)
     cfg = synth.small_config(); cfg.device = torch.device("cuda")
-    cfg.model.num_scales = 12
+    cfg.model.num_scales = 40                      # (below ~21 levels the discrete betas exceed 1: NaN for any sampler)
     _write_ckpt_and_mask(tmp_path, cfg, synth)
     with open(os.path.join(tmp, "small.py"), "w") as f:
         f.write("from meshdiffusion_amd import synth\n\ndef get_config():\n    c = synth.small_config()\n"
-                "    c.model.num_scales = 12\n    return c\n")
+                "    c.model.num_scales = 40\n    return c\n")
     total, R = 3, cfg.data.image_size
     ctx = mp.get_context("spawn")
     procs = [ctx.Process(target=_cli_sampling_worker, args=(r, 2, _free_port_pair(), tmp, total)) for r in range(2)]

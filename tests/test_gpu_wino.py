@@ -259,3 +259,62 @@ def test_conv3_wino_rejects_unsupported_shapes(ops):
 
 
 _ = np
+
+
+def test_wino_prep_dual_second_output_bit_exact(ops):
+    """md_wino_prep_dual: T as md_wino_prep_v2 writes it, and U[b][c/8][f][plane][z][y][pair][8] = (v0, v0 + v1, v0 - v1, v1) of
+    every output pair (v0 = x[2i], v1 = x[2i+1]) split into bf16 hi / lo -- bit-exact against the same arithmetic in torch."""
+    B, S, cin = 2, 32, 16
+    x = _rand((B, cin, S, S, S), 31)
+    parts = [(ops.ncdhw_to_f32b(x.cuda()), cin)]
+    t_ref = ops.wino_prep(parts, None, False, False, B, S).clone()
+    t, u = ops.wino_prep(parts, None, False, False, B, S, dual=True)
+    assert torch.equal(t.view(torch.int16), t_ref.view(torch.int16))
+    u = u.cpu().view(B, cin // 8, 4, 2, S, S, S // 2, 8)
+    v0, v1 = x[..., 0::2], x[..., 1::2]
+    tr = [v0, v0 + v1, v0 - v1, v1]
+    for f in range(4):
+        hi, lo = _split_bf16(tr[f])
+        for plane, ref in enumerate((hi, lo)):
+            want = ref.view(B, cin // 8, 8, S, S, S // 2).permute(0, 1, 3, 4, 5, 2)
+            assert torch.equal(u[:, :, f, plane].view(torch.int16), want.contiguous().view(torch.int16)), (f, plane)
+
+
+@pytest.mark.parametrize("case", ["k128_32", "k256_64_b1", "k128_r256_32_b3"])
+def test_wgrad_wino_vs_torch(ops, case):
+    """md_wgrad_wino (Winograd-domain weight gradient from the forward's operand T and md_wino_prep_dual's U) against
+    torch.nn.grad.conv3d_weight in float64 on sub-sampled channels and against the PB16 kernel md_wgrad on all of them: rows
+    of 16 pairs (32^3) and 32 pairs (64^3), several K ranges (planes split unevenly), 1-2 tiles per operand, accumulation
+    into a non-zero dW."""
+    from meshdiffusion_amd.lib.diffusion.models import backward as bw
+    cfg = {"k128_32": dict(B=2, ci=128, co=128, S=32), "k256_64_b1": dict(B=1, ci=256, co=128, S=64),
+           "k128_r256_32_b3": dict(B=3, ci=128, co=256, S=32)}[case]
+    B, ci, co, S = cfg["B"], cfg["ci"], cfg["co"], cfg["S"]
+    P = S ** 3
+    a = _rand((B, ci, S, S, S), 70)
+    dy = _rand((B, co, S, S, S), 71, 0.1)
+    a_f, dy_f = ops.ncdhw_to_f32b(a.cuda()), ops.ncdhw_to_f32b(dy.cuda())
+    t_act = ops.wino_prep([(a_f, ci)], None, False, False, B, S, keep=True)
+    t_dy, u_dy = ops.wino_prep([(dy_f, co)], None, False, False, B, S, dual=True)
+    dw0 = _rand((co, ci, 3, 3, 3), 72, 0.01).cuda()
+    dw = dw0.clone()
+    ops.wgrad_wino(u_dy, t_act, B, co, ci, S, dw)
+    got = (dw - dw0).cpu()
+    # (a) the PB16 kernel (direct 27-tap contraction, bf16x3) on the same tensors
+    ref_k = torch.zeros((co, ci, 3, 3, 3), device="cuda")
+    dy_pb = bw.to_pb16(dy_f, B, co, S, 0, zhalo=False)
+    act_pb = bw.to_pb16(bw.split_f32b(a_f, B, ci, P), B, ci, S, 1)
+    bw.wgrad(dy_pb, act_pb, B, co, ci, S, 27, ref_k, ci * 27, 27, 1)
+    e_k = rel_l2(got, ref_k.cpu())
+    # (b) float64 autograd of nn.Conv3d for 4 output x 6 input channels spread over the tiles
+    cos, cis = [0, 37, co // 2 + 5, co - 1], [0, 1, 63, ci // 2, ci - 2, ci - 1]
+    ref = torch.nn.grad.conv3d_weight(a[:, cis].double(), (len(cos), len(cis), 3, 3, 3), dy[:, cos].double(), padding=1)
+    sub = got[cos][:, cis].double()
+    e = rel_l2(sub, ref)
+    per_tap = [(t, rel_l2(sub.reshape(len(cos), len(cis), 27)[..., t], ref.reshape(len(cos), len(cis), 27)[..., t])) for t in range(27)]
+    worst = max(per_tap, key=lambda v: v[1])
+    print(f"wgrad_wino ({case}): vs float64 autograd {e:.2e} (worst tap {worst}), vs md_wgrad {e_k:.2e}")
+    assert e < TOL_MFMA and worst[1] < 2 * TOL_MFMA and e_k < TOL_MFMA
+    dw2 = dw0.clone()
+    ops.wgrad_wino(u_dy, t_act, B, co, ci, S, dw2)
+    assert torch.equal(dw2, dw)                              # fixed reduction order: run-to-run identical
