@@ -14,6 +14,9 @@ from collections import defaultdict
 
 
 def short(name):
+    name = name.replace("(anonymous namespace)::", "")
+    if name.startswith("void "):
+        name = name[5:]
     name = re.sub(r"\(.*$", "", name)
     m = re.search(r"md_gemm_conv_kernel<GCfg<([^>]*)>", name)
     if m:
