@@ -139,6 +139,20 @@ def test_bad_arguments_are_rejected_without_a_gpu(hip_lib):
     assert hip_lib.md_wino_weight_bytes(96, 64) < 0 and hip_lib.md_wino_weight_bytes(128, 48) < 0
     assert hip_lib.md_wino_prep(None, None, 8, 0, None, 0, 0, None, 1, 8, 8, 8, 0.0, 0, None) == -1
     assert hip_lib.md_conv3_wino(None, None, None, None, 0, None, 0, None, 1, 32, 128, 8, 8, 8, 0, None) == -1
+    # SiLU is applied together with the folded GroupNorm affine only: silu = 1 without `ac` is an argument error
+    buf = ctypes.create_string_buffer(64)      # any non-null pointers: the check comes before any launch
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    for fn in (hip_lib.md_wino_prep, hip_lib.md_wino_prep_v2):
+        assert fn(p, None, 8, 0, None, 1, 0, p, 1, 8, 8, 8, 0.0, 0, None) == -1
+    assert hip_lib.md_wino_prep_dual(p, None, 8, 0, None, 0, 0, p, None, 1, 8, 8, 8, 0.0, 0, None) == -1     # no second output
+    # Winograd weight gradient: workspace size, shapes it does not take (channels % 128, W not in {32, 64}), K-range bound
+    assert hip_lib.md_wgrad_wino_workspace_bytes(128, 256, 10) == 10 * 36 * 128 * 256 * 4
+    assert hip_lib.md_wgrad_wino_workspace_bytes(96, 128, 1) < 0
+    big = 10 * 36 * 128 * 256 * 4
+    assert hip_lib.md_wgrad_wino(p, p, p, p, big, 8, 128, 256, 64, 64, 16, 10, 27 * 256, 27, 1, None) == -2    # MD_ERR_UNSUPPORTED
+    assert hip_lib.md_wgrad_wino(p, p, p, p, big, 8, 96, 256, 64, 64, 64, 10, 27 * 256, 27, 1, None) == -2
+    assert hip_lib.md_wgrad_wino(p, p, p, p, 16, 8, 128, 256, 64, 64, 64, 10, 27 * 256, 27, 1, None) == -1     # workspace too small
+    assert hip_lib.md_wgrad_wino(p, p, p, p, big, 1, 128, 256, 64, 64, 64, 64, 27 * 256, 27, 1, None) == -1    # ksplit > B (D - 1)
 
 
 def test_hip_path_refuses_cpu_tensors():

@@ -38,3 +38,27 @@ def test_data_gradient_weights_are_the_flipped_transpose():
     wd = w.reshape(co, ci, 27).flip(2).transpose(0, 1).reshape(ci, co, 3, 3, 3)    # W'[ci][co][t] = W[co][ci][26 - t]
     assert float((F.conv3d(dy, wd, padding=1) - ref).abs().max()) < 1e-12
     assert float((wino_conv_reference(dy, wd) - ref).abs().max()) < 1e-12
+
+
+def test_weight_gradient_in_the_winograd_domain_equals_autograd():
+    """The transposed minimal algorithm md_wgrad_wino specifies: with t = B^T d (the forward operand T) and
+    u = (dy0, dy0 + dy1, dy0 - dy1, dy1) (md_wino_prep_dual's second output), n_f[kd][kh] = sum over samples, rows and pairs of
+    u_f * t_f shifted by (kd - 1, kh - 1) rows, and dg0 = n0 + (n1 + n2)/2, dg1 = (n1 - n2)/2, dg2 = (n1 + n2)/2 - n3
+    (md_wgrad_wino_reduce) -- against autograd of nn.Conv3d in float64."""
+    B, ci, co, D, H, W = 2, 3, 4, 4, 5, 8
+    a, dy = _rand((B, ci, D, H, W), 5), _rand((B, co, D, H, W), 6)
+    ref = torch.nn.grad.conv3d_weight(a, (co, ci, 3, 3, 3), dy, padding=1)
+    ap = F.pad(a, (1, 1, 1, 1, 1, 1))
+    d = [ap[..., k:k + W:2] for k in range(4)]
+    t = [d[0] - d[2], d[1] + d[2], d[2] - d[1], d[1] - d[3]]                 # [B,ci,D+2,H+2,W/2] (rows -1 / D, H are zeros)
+    dy0, dy1 = dy[..., 0::2], dy[..., 1::2]
+    u = [dy0, dy0 + dy1, dy0 - dy1, dy1]
+    n = torch.zeros((4, co, ci, 3, 3), dtype=torch.float64)
+    for f in range(4):
+        for kd in range(3):
+            for kh in range(3):
+                tt = t[f][:, :, kd:kd + D, kh:kh + H]                          # T rows (z + kd - 1, y + kh - 1)
+                n[f, :, :, kd, kh] = torch.einsum("bozyp,bizyp->oi", u[f], tt)
+    h12 = 0.5 * (n[1] + n[2])
+    got = torch.stack([n[0] + h12, 0.5 * (n[1] - n[2]), h12 - n[3]], -1)      # [co,ci,kd,kh,kw]
+    assert float((got - ref).abs().max()) < 1e-11

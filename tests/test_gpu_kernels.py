@@ -345,7 +345,7 @@ def test_conv3_fused_groupnorm_silu_operand(ops, case):
     bias = _rand((B, cout), 23)
     parts = [(ops.ncdhw_to_f32b(t.cuda()), c) for t, c in zip(xs, cs)]
     pw = ops.PackedWeight(w.cuda(), "conv", ops.CFG_C3_128_FAST, "cuda")
-    silu = case != "gn_no_silu"
+    silu = case not in ("gn_no_silu", "ups_split_only")   # (SiLU without the affine is rejected by the library: MD_ERR_BAD_ARG)
     ac = None
     if not ups:
         prm, ac = ops.gn_params(parts, gamma.cuda(), beta.cuda(), B, Pin, want_ac=True)
