@@ -36,6 +36,10 @@ def main():
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--out", default=None)
     ap.add_argument("--seeds", default="42", help="comma-separated seeds: one full trajectory pair per seed")
+    ap.add_argument("--partner", default="oracle", choices=["oracle", "direct"],
+                    help="oracle: the fp32 PyTorch restatement on the same GPU (default); direct: the HIP path with the direct 27-tap "
+                         "kernels (MD_WINO=0) -- the build whose 999-step parity vs the oracle is on record -- so that a B = 8 run "
+                         "of the full schedule costs minutes instead of half an hour of fp32 torch convolutions")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     cfg = get_config_res64() if a.config == "res64" else synth.small_config()
@@ -79,8 +83,16 @@ def one_seed(a, seed, st, model_fn, sd_gpu, ocfg, shape, dev, mask):
             torch.cuda.synchronize(); t0 = time.perf_counter()
             x_h, xm_h = st.step(model_fn, x_h, i, draw=lambda _t: z)
             torch.cuda.synchronize(); t1 = time.perf_counter()
-            e = uo.unet_res64_forward(sd_gpu, ocfg, x_o, st.labels[i])
-            # per-evaluation error of the HIP U-Net on the ORACLE's state (no trajectory feedback)
+            if a.partner == "direct":
+                from meshdiffusion_amd import hip_ops
+                keep, hip_ops.WINO = hip_ops.WINO, False
+                try:
+                    e = model_fn(x_o, st.labels[i])
+                finally:
+                    hip_ops.WINO = keep
+            else:
+                e = torch.cat([uo.unet_res64_forward(sd_gpu, ocfg, x_o[b:b + 1], st.labels[i][b:b + 1]) for b in range(shape[0])])
+            # per-evaluation error of the HIP U-Net on the PARTNER's state (no trajectory feedback)
             if (i + 1) in marks:
                 e_h = model_fn(x_o, st.labels[i])
                 eval_err = rel(e_h, e)
@@ -92,7 +104,8 @@ def one_seed(a, seed, st, model_fn, sd_gpu, ocfg, shape, dev, mask):
                        "unet_eval_rel_l2": eval_err}
                 log.append(rec)
                 print(json.dumps(rec), flush=True)
-    return {"config": a.config, "batch": a.batch, "steps": a.steps, "seed": seed, "final_x_mean_rel_l2": log[-1]["x_mean_rel_l2"],
+    return {"config": a.config, "batch": a.batch, "steps": a.steps, "seed": seed, "partner": a.partner,
+            "final_x_mean_rel_l2": log[-1]["x_mean_rel_l2"],
             "target": 1e-3, "hip_s_per_step": t_h / a.steps, "oracle_gpu_s_per_step": t_o / a.steps, "trace": log}
 
 

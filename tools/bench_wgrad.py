@@ -11,7 +11,7 @@ from meshdiffusion_amd import _lib, hip_ops as ops  # noqa: E402
 from meshdiffusion_amd.lib.diffusion.models import backward as bw  # noqa: E402
 
 SHAPES = [(128, 128, 64, 27), (128, 256, 64, 27), (128, 128, 32, 27), (256, 256, 16, 27), (512, 512, 8, 27), (512, 512, 4, 27),
-          (128, 256, 64, 1), (8, 128, 64, 27), (128, 16, 64, 27)]
+          (128, 256, 64, 1), (8, 128, 64, 27), (128, 16, 64, 27), (512, 1024, 4, 27), (512, 1024, 8, 27), (256, 768, 16, 27)]
 
 
 def main():
