@@ -289,9 +289,11 @@ int md_wino_prep_v2(const float* x1, const float* x2, int32_t c1, int32_t c2, co
 /* md_wino_prep_v2 with a second output u_out in the layout of T: per output pair (x = 2i, 2i+1) of the (activated) tensor
  * v the four values (v[2i], v[2i] + v[2i+1], v[2i] - v[2i+1], v[2i+1]), hi / lo bf16 planes -- the dY operand of
  * md_wgrad_wino when the tensor is an output gradient (training backward: one pass over dY feeds both the Winograd data
- * gradient conv, T, and the Winograd weight gradient, U).  Same shape restrictions as md_wino_prep_v2. */
+ * gradient conv, T, and the Winograd weight gradient, U).  sums (optional, float [B][c1 + c2], accumulated with atomics, not
+ * with ups): += per-(sample, channel) sums of the activated tensor over the grid -- the bias gradient of the same pass.
+ * Same shape restrictions as md_wino_prep_v2. */
 int md_wino_prep_dual(const float* x1, const float* x2, int32_t c1, int32_t c2, const float* ac, int32_t silu, int32_t ups,
-                      void* t_out, void* u_out, int32_t batch, int32_t D, int32_t H, int32_t W, float drop_p,
+                      void* t_out, void* u_out, float* sums, int32_t batch, int32_t D, int32_t H, int32_t W, float drop_p,
                       uint64_t drop_seed, void* stream);
 
 /*
@@ -423,6 +425,17 @@ int64_t md_wgrad_wino_workspace_bytes(int32_t co, int32_t ci, int32_t ksplit);
 int md_wgrad_wino(const void* u_dy, const void* t_act, float* dw, void* workspace, int64_t workspace_bytes, int32_t batch,
                   int32_t co, int32_t ci, int32_t D, int32_t H, int32_t W, int32_t ksplit, int64_t s_row, int64_t s_k,
                   int64_t s_tap, void* stream);
+
+/*
+ * md_wgrad_nin: weight gradient of a 1x1x1 NIN layer (autograd of layers.py:573-582) straight from S16B tensors:
+ *   dw[co*s_row + ci*s_k] += sum_{sample, position} dY[co][pos] * x[ci][pos]
+ * dy_s16 / x_s16: S16B [B][C/8][2][P][8] (md_gn_apply with norm = 0 of dY / of the layer's input) -- no PB16 re-layout
+ * (md_to_pb16 + md_wgrad with taps = 1 remain for the other shapes).  co, ci multiples of 128, P a multiple of 16; the
+ * contraction is split into `ksplit` ranges of 16-position elements (1 <= ksplit <= batch * P / 16), reduced in a fixed order.
+ */
+int64_t md_wgrad_nin_workspace_bytes(int32_t co, int32_t ci, int32_t ksplit);
+int md_wgrad_nin(const void* dy_s16, const void* x_s16, float* dw, void* workspace, int64_t workspace_bytes, int32_t batch,
+                 int32_t co, int32_t ci, int64_t P, int32_t ksplit, int64_t s_row, int64_t s_k, void* stream);
 int md_gn_bwd_stats(const float* x, const float* dy, const float* params, double* sums, int32_t batch, int32_t C,
                     int64_t P, int32_t c_total, int32_t c_off, int32_t dy_ctotal, int32_t silu, float drop_p,
                     uint64_t drop_seed, void* stream);

@@ -73,9 +73,11 @@ SIGNATURES = {
     "md_wino_pack_weights": (C.c_int, [_P, _P, _I32, _I32, _I64, _I64, _I32, _P]),
     "md_conv3_wino": (C.c_int, [_P, _P, _P, _P, _I64, _P, _I64, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P]),
     "md_wino_prep_v2": (C.c_int, [_P, _P, _I32, _I32, _P, _I32, _I32, _P, _I32, _I32, _I32, _I32, _F, _U64, _P]),
-    "md_wino_prep_dual": (C.c_int, [_P, _P, _I32, _I32, _P, _I32, _I32, _P, _P, _I32, _I32, _I32, _I32, _F, _U64, _P]),
+    "md_wino_prep_dual": (C.c_int, [_P, _P, _I32, _I32, _P, _I32, _I32, _P, _P, _P, _I32, _I32, _I32, _I32, _F, _U64, _P]),
     "md_wgrad_wino_workspace_bytes": (_I64, [_I32, _I32, _I32]),
     "md_wgrad_wino": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I64, _I64, _I64, _P]),
+    "md_wgrad_nin_workspace_bytes": (_I64, [_I32, _I32, _I32]),
+    "md_wgrad_nin": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _I32, _I32, _I64, _I32, _I64, _I64, _P]),
     "md_attn_fwd": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _F, _P]),
     "md_softmax_keys": (C.c_int, [_P, _P, _I32, _I32, _I32, _P]),
     "md_ancestral_step": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I64, _P]),

@@ -345,6 +345,154 @@ __global__ void md_wgrad_wino_reduce_kernel(const float* __restrict__ partial, f
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// md_wgrad_nin: weight gradient of a 1x1x1 NIN layer (autograd of layers.py:573-582) straight from the S16B tensors the
+// backward already holds -- dW[ci][co] += sum_{sample, position} x[ci][pos] dY[co][pos] -- with the same machinery: channel-
+// innermost operands, transpose reads, wave-private element streams (16 positions per step), no barrier.  Replaces
+// md_to_pb16 (x and dY) + md_wgrad<taps = 1> for the ResnetBlock shortcuts: the re-layout passes were 3x the contraction.
+// One wave = a 64 co x 64 ci tile over a range of elements; 12 MFMAs per 8 KB of operands: HBM / L2 bound.
+struct WnArgsNin {
+  const uint4* DY;     // S16B [B][co/8][2][P] items of 16 B
+  const uint4* X;      // S16B [B][ci/8][2][P]
+  float* partial;      // [ksplit][co][ci]
+  int batch, co, ci;
+  int64_t P;
+  int ksplit;
+};
+
+__global__ __launch_bounds__(WW_THREADS) void md_wgrad_nin_kernel(const WnArgsNin g) {
+  constexpr int WAVEB = 4 * WW_ELB;                // two U and two T elements
+  __shared__ __attribute__((aligned(16))) unsigned char smem[4 * WAVEB];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  unsigned char* const tbuf = smem + wv * WAVEB;
+  unsigned char* const ubuf = tbuf + 2 * WW_ELB;
+  const int ct2 = g.ci >> 7;
+  const int units = (g.co >> 7) * ct2;
+  const int bx = blockIdx.x;
+  if (bx >= g.ksplit * units) return;
+  const int r = bx / units, u = bx - r * units;
+  const int tci = (u % ct2) * 2 + (wv & 1), tco = (u / ct2) * 2 + (wv >> 1);
+  const int64_t P = g.P;
+  const int epb = (int)(P >> 4);                   // elements per sample
+  const int64_t NE = (int64_t)g.batch * epb;
+  const int e0 = (int)(NE * r / g.ksplit), e1 = (int)(NE * (r + 1) / g.ksplit);
+
+  int64_t goff[4];
+  int loff[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int plane = q & 1, sg = q >> 1;
+    const int cg = lane >> 3, k = lane & 7;
+    goff[q] = ((int64_t)cg * 2 + plane) * P + sg * 8 + k;
+    loff[q] = plane * 2048 + sg * 1024 + (cg >> 2) * 512 + k * 64 + (((cg & 3) ^ (k >> 1)) * 16);
+  }
+  const uint4* const ubase = g.DY + ((int64_t)tco * 8) * 2 * P;
+  const uint4* const tbase = g.X + ((int64_t)tci * 8) * 2 * P;
+  const int64_t u_bstride = (int64_t)(g.co >> 3) * 2 * P, t_bstride = (int64_t)(g.ci >> 3) * 2 * P;
+  const int s = lane >> 5, sub = (lane >> 4) & 1, i = lane & 15;
+  const int chunk = sub * 2 + ((i & 3) >> 1);
+  const int frag_lo = s * 1024 + (i >> 2) * 64 + ((chunk ^ (i >> 3)) * 16) + (i & 1) * 8;
+  const int frag_d = 256 + (((chunk ^ (2 + (i >> 3))) - (chunk ^ (i >> 3))) * 16);
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[rt][ct][e] = 0.f;
+
+  const int nreal = e1 - e0;
+  const int nsteps = (nreal + 3) / 4 * 4;
+  uint4 st_u[4][4], st_t[4][4];
+  // element e of the range (beyond its end: the 16 zero bytes)
+  auto request = [&](int set, int e) {
+    const bool live = e < e1;
+    const int b = e / epb, p0 = (e - b * epb) << 4;
+    const uint4* up = ubase + (int64_t)b * u_bstride + p0;
+    const uint4* tp = tbase + (int64_t)b * t_bstride + p0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      st_u[set][q] = ww_gload16(live ? up + goff[q] : &ww_zero16);
+      st_t[set][q] = ww_gload16(live ? tp + goff[q] : &ww_zero16);
+    }
+  };
+  auto store = [&](int set, int slot) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      *(uint4*)(ubuf + slot * WW_ELB + loff[q]) = st_u[set][q];
+      *(uint4*)(tbuf + slot * WW_ELB + loff[q]) = st_t[set][q];
+    }
+  };
+  auto read4 = [&](const unsigned char* el, bf16x8 (&dst)[4]) {
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2) {
+      dst[t2 * 2] = ww_frag(el + t2 * 512 + frag_lo, frag_d);
+      dst[t2 * 2 + 1] = ww_frag(el + t2 * 512 + 2048 + frag_lo, frag_d);
+    }
+  };
+  if (nreal > 0) {
+    // prologue: element 0 in LDS slot 0, sets 1, 2, 3, 0 = elements 1..4 in flight (element m travels in set m % 4)
+    request(0, e0);
+    store(0, 0);
+    request(1, e0 + 1); request(2, e0 + 2); request(3, e0 + 3); request(0, e0 + 4);
+    bf16x8 A[2][4], Bq[2][4];
+    read4(ubuf, A[0]);
+    read4(tbuf, Bq[0]);
+    for (int n0 = 0; n0 < nsteps; n0 += 4) {
+#pragma unroll
+      for (int uu = 0; uu < 4; ++uu) {
+        // step n = n0 + uu on element n (fragments in A / Bq[n & 1], LDS slot n & 1): stores element n + 1 (register set
+        // (n + 1) % 4) into the other slot, requests element n + 4 into the set just stored
+        const int n = n0 + uu, pb = uu & 1;
+        store((uu + 1) & 3, pb ^ 1);
+        request((uu + 1) & 3, e0 + n + 5);
+        read4(ubuf + (pb ^ 1) * WW_ELB, A[pb ^ 1]);
+        read4(tbuf + (pb ^ 1) * WW_ELB, Bq[pb ^ 1]);
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+          acc[m >> 1][m & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[pb][(m >> 1) * 2 + 1], Bq[pb][(m & 1) * 2], acc[m >> 1][m & 1], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+          acc[m >> 1][m & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[pb][(m >> 1) * 2], Bq[pb][(m & 1) * 2 + 1], acc[m >> 1][m & 1], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+          acc[m >> 1][m & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[pb][(m >> 1) * 2], Bq[pb][(m & 1) * 2], acc[m >> 1][m & 1], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+  const int half = lane >> 5, l31 = lane & 31;
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      float* o = g.partial + ((int64_t)r * g.co + tco * 64 + rt * 32) * g.ci + tci * 64 + ct * 32 + l31;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = (e & 3) + 8 * (e >> 2) + 4 * half;
+        o[(int64_t)row * g.ci] = acc[rt][ct][e];
+      }
+    }
+}
+
+// dw[co*s_row + ci*s_k] += sum_r partial[r][co][ci]
+__global__ void md_wgrad_nin_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int co, int ci, int ksplit,
+                                           int64_t s_row, int64_t s_k) {
+  const int64_t tile = (int64_t)co * ci;
+  for (int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; id < tile; id += (int64_t)gridDim.x * blockDim.x) {
+    // consecutive threads walk the FASTER dimension of dw (NIN: W[ci][co], s_row = 1): the slabs are then read with stride ci,
+    // a few MB in all -- better than scattering the read-modify-writes
+    int row, col;
+    if (s_row <= s_k) { row = (int)(id % co); col = (int)(id / co); } else { col = (int)(id % ci); row = (int)(id / ci); }
+    const float* p = partial + (int64_t)row * ci + col;
+    float sum = 0.f;
+    for (int r = 0; r < ksplit; ++r) sum += p[r * tile];
+    dw[row * s_row + col * s_k] += sum;
+  }
+}
 }  // namespace
 
 extern "C" int64_t md_wgrad_wino_workspace_bytes(int32_t co, int32_t ci, int32_t ksplit) {
@@ -387,6 +535,35 @@ extern "C" int md_wgrad_wino(const void* u_dy, const void* t_act, float* dw, voi
   if (rb > 4096) rb = 4096;
   hipLaunchKernelGGL(md_wgrad_wino_reduce_kernel, dim3((unsigned)rb), dim3(256), 0, (hipStream_t)stream, (const float*)workspace,
                      dw, co, ci, ksplit, s_row, s_k, s_tap);
+  MD_HIP_CHECK_LAUNCH();
+  return MD_OK;
+}
+
+extern "C" int64_t md_wgrad_nin_workspace_bytes(int32_t co, int32_t ci, int32_t ksplit) {
+  if (co <= 0 || ci <= 0 || (co % 128) || (ci % 128) || ksplit <= 0) return MD_ERR_BAD_ARG;
+  return (int64_t)ksplit * co * ci * 4;
+}
+
+extern "C" int md_wgrad_nin(const void* dy_s16, const void* x_s16, float* dw, void* workspace, int64_t workspace_bytes,
+                            int32_t batch, int32_t co, int32_t ci, int64_t P, int32_t ksplit, int64_t s_row, int64_t s_k,
+                            void* stream) {
+  if (!dy_s16 || !x_s16 || !dw || !workspace || batch <= 0 || ksplit <= 0 || P <= 0) return MD_ERR_BAD_ARG;
+  if ((co % 128) || (ci % 128) || co <= 0 || ci <= 0 || (P % 16)) return MD_ERR_UNSUPPORTED;
+  if ((int64_t)batch * (P / 16) >= ((int64_t)1 << 31) || ksplit > (int64_t)batch * (P / 16)) return MD_ERR_BAD_ARG;
+  if (workspace_bytes < md_wgrad_nin_workspace_bytes(co, ci, ksplit)) return MD_ERR_BAD_ARG;
+  WnArgsNin g;
+  g.DY = (const uint4*)dy_s16; g.X = (const uint4*)x_s16; g.partial = (float*)workspace;
+  g.batch = batch; g.co = co; g.ci = ci; g.P = P; g.ksplit = ksplit;
+  const int64_t blocks = (int64_t)ksplit * (co / 128) * (ci / 128);
+  if (blocks > 0x7fffffff) return MD_ERR_UNSUPPORTED;
+  MD_HIP_CLEAR_ERROR();
+  hipLaunchKernelGGL(md_wgrad_nin_kernel, dim3((unsigned)blocks), dim3(WW_THREADS), 0, (hipStream_t)stream, g);
+  MD_HIP_CHECK_LAUNCH();
+  const int64_t total = (int64_t)co * ci;
+  int rb = (int)((total + 255) / 256);
+  if (rb > 4096) rb = 4096;
+  hipLaunchKernelGGL(md_wgrad_nin_reduce_kernel, dim3((unsigned)rb), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, dw,
+                     co, ci, ksplit, s_row, s_k);
   MD_HIP_CHECK_LAUNCH();
   return MD_OK;
 }

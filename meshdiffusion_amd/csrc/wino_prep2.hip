@@ -21,8 +21,9 @@ constexpr int P2_STRIDE = 12;             // floats per position in LDS (8 + pad
 template <bool DUAL>
 __global__ __launch_bounds__(256) void md_wino_prep2_kernel(const float* __restrict__ x1, const float* __restrict__ x2,
                                                             int c1, int c2, const float* __restrict__ ac, int silu, int ups,
-                                                            uint4* __restrict__ T, uint4* __restrict__ U, int batch, int D, int H,
-                                                            int W, uint32_t thr16, float drop_scale, uint64_t seed) {
+                                                            uint4* __restrict__ T, uint4* __restrict__ U, float* __restrict__ sums,
+                                                            int batch, int D, int H, int W, uint32_t thr16, float drop_scale,
+                                                            uint64_t seed) {
   __shared__ __attribute__((aligned(16))) float act[P2_POS * P2_STRIDE];
   const int tid = threadIdx.x;
   const int Wp = W >> 1;
@@ -77,6 +78,26 @@ __global__ __launch_bounds__(256) void md_wino_prep2_kernel(const float* __restr
     *(f32x4*)(dst + 4) = f32x4{yv[4], yv[5], yv[6], yv[7]};
   }
   __syncthreads();
+  if constexpr (DUAL) {
+    // per-(sample, channel) sums of the tensor (the bias gradient when it is an output gradient: replaces an md_channel_sums
+    // pass over the same 4 bytes per element): wave 0 adds up the 256 staged positions, one float atomic per channel and block
+    if (sums != nullptr && tid < 64) {
+      float s8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float* a = act + (tid + 64 * k) * P2_STRIDE;
+        const f32x4 u0 = *(const f32x4*)a, u1 = *(const f32x4*)(a + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { s8[e] += u0[e]; s8[4 + e] += u1[e]; }
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s8[e] = md_wave_sum(s8[e]);
+      if (tid == 0) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) atomicAdd(sums + (int64_t)b * (c1 + c2) + cg * 8 + e, s8[e]);
+      }
+    }
+  }
   // ---- phase 2 ----------------------------------------------------------------------------------------------------
   {
     const int pi = tid & 127, fh = tid >> 7;                         // pair of the workgroup, frequency half (wave-uniform)
@@ -132,7 +153,7 @@ __global__ __launch_bounds__(256) void md_wino_prep2_kernel(const float* __restr
 }
 
 static int md_wino_prep2_launch(const float* x1, const float* x2, int32_t c1, int32_t c2, const float* ac, int32_t silu,
-                                int32_t ups, void* t_out, void* u_out, int32_t batch, int32_t D, int32_t H, int32_t W, float drop_p,
+                                int32_t ups, void* t_out, void* u_out, float* sums, int32_t batch, int32_t D, int32_t H, int32_t W, float drop_p,
                                 uint64_t drop_seed, void* stream) {
   if (!x1 || !t_out || batch <= 0 || c1 <= 0 || c2 < 0 || (c1 & 7) || (c2 & 7) || (c2 > 0 && !x2)) return MD_ERR_BAD_ARG;
   if (silu && !ac) return MD_ERR_BAD_ARG;      // SiLU is applied together with the folded GroupNorm affine only
@@ -145,12 +166,12 @@ static int md_wino_prep2_launch(const float* x1, const float* x2, int32_t c1, in
   MD_HIP_CLEAR_ERROR();
   if (u_out)
     hipLaunchKernelGGL((md_wino_prep2_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x1, x2, c1, c2, ac,
-                       silu, ups, (uint4*)t_out, (uint4*)u_out, batch, D, H, W, md_drop_thr16(drop_p), 1.0f / (1.0f - drop_p),
+                       silu, ups, (uint4*)t_out, (uint4*)u_out, sums, batch, D, H, W, md_drop_thr16(drop_p), 1.0f / (1.0f - drop_p),
                        drop_seed);
   else
     hipLaunchKernelGGL((md_wino_prep2_kernel<false>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x1, x2, c1, c2, ac,
-                       silu, ups, (uint4*)t_out, (uint4*)nullptr, batch, D, H, W, md_drop_thr16(drop_p), 1.0f / (1.0f - drop_p),
-                       drop_seed);
+                       silu, ups, (uint4*)t_out, (uint4*)nullptr, (float*)nullptr, batch, D, H, W, md_drop_thr16(drop_p),
+                       1.0f / (1.0f - drop_p), drop_seed);
   MD_HIP_CHECK_LAUNCH();
   return MD_OK;
 }
@@ -158,12 +179,12 @@ static int md_wino_prep2_launch(const float* x1, const float* x2, int32_t c1, in
 extern "C" int md_wino_prep_v2(const float* x1, const float* x2, int32_t c1, int32_t c2, const float* ac, int32_t silu,
                                int32_t ups, void* t_out, int32_t batch, int32_t D, int32_t H, int32_t W, float drop_p,
                                uint64_t drop_seed, void* stream) {
-  return md_wino_prep2_launch(x1, x2, c1, c2, ac, silu, ups, t_out, nullptr, batch, D, H, W, drop_p, drop_seed, stream);
+  return md_wino_prep2_launch(x1, x2, c1, c2, ac, silu, ups, t_out, nullptr, nullptr, batch, D, H, W, drop_p, drop_seed, stream);
 }
 
 extern "C" int md_wino_prep_dual(const float* x1, const float* x2, int32_t c1, int32_t c2, const float* ac, int32_t silu,
-                                 int32_t ups, void* t_out, void* u_out, int32_t batch, int32_t D, int32_t H, int32_t W,
-                                 float drop_p, uint64_t drop_seed, void* stream) {
-  if (!u_out) return MD_ERR_BAD_ARG;
-  return md_wino_prep2_launch(x1, x2, c1, c2, ac, silu, ups, t_out, u_out, batch, D, H, W, drop_p, drop_seed, stream);
+                                 int32_t ups, void* t_out, void* u_out, float* sums, int32_t batch, int32_t D, int32_t H,
+                                 int32_t W, float drop_p, uint64_t drop_seed, void* stream) {
+  if (!u_out || (sums && ups)) return MD_ERR_BAD_ARG;
+  return md_wino_prep2_launch(x1, x2, c1, c2, ac, silu, ups, t_out, u_out, sums, batch, D, H, W, drop_p, drop_seed, stream);
 }

@@ -260,6 +260,28 @@ def wino_ok(rows, kdim, S, B):
             and B * (S ** 3 // 256) * (rows // 128) >= WINO_MIN_WGS)
 
 
+WGRAD_NIN = os.environ.get("MD_WGRAD_NIN", "1") == "1"   # NIN weight gradients straight from S16B tensors (md_wgrad_nin)
+
+
+def wgrad_nin_ok(co, ci, P):
+    return WGRAD_NIN and co % 128 == 0 and ci % 128 == 0 and P % 16 == 0
+
+
+def wgrad_nin(dy_s16, x_s16, B, co, ci, P, dw):
+    """dw[ci][co] += sum x[ci] dy[co] over samples and positions, both operands S16B -- md_wgrad_nin (no PB16 tensors)."""
+    lib = _lib.load()
+    units = (co // 128) * (ci // 128)
+    ksplit = max(1, min(256 // units, B * P // 16 // 8))
+    nbytes = lib.md_wgrad_nin_workspace_bytes(co, ci, ksplit)
+    if nbytes <= 0:
+        raise _lib.MeshDiffusionHipError("md_wgrad_nin_workspace_bytes: unsupported shape")
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=dy_s16.device)
+    ev = _prof_begin()
+    check(lib.md_wgrad_nin(_ptr(dy_s16), _ptr(x_s16), _ptr(dw), _ptr(ws), nbytes, B, co, ci, P, ksplit, 1, co, _stream()),
+          "md_wgrad_nin")
+    _prof_end(ev, "wgrad_nin", 2.0 * B * co * ci * P, 4.0 * B * (co + ci) * P, f"{ci}->{co}@{P}")
+
+
 _WINO_SCRATCH = {}
 
 
@@ -282,11 +304,12 @@ def release_scratch():
     _WINO_SCRATCH.clear()
 
 
-def wino_prep(parts, ac, silu, ups, B, S, drop=None, keep=False, dual=False):
+def wino_prep(parts, ac, silu, ups, B, S, drop=None, keep=False, dual=False, sums=None):
     """fp32 F32B parts (+ folded GroupNorm affine, SiLU, nearest-x2 upsampling) -> transformed split operand T.
     drop = (p, seed): training dropout after SiLU, the mask gn_apply(drop=...) produces for the same pair.
     keep: T goes to its own tensor instead of the shared scratch buffer (training forward: the Winograd weight gradient of the
-    backward reads it again).  dual: returns (T, U) -- U = the dY operand of md_wgrad_wino (md_wino_prep_dual)."""
+    backward reads it again).  dual: returns (T, U) -- U = the dY operand of md_wgrad_wino (md_wino_prep_dual); sums (with dual):
+    zeroed float [B, C] receiving the per-(sample, channel) sums of the tensor in the same pass (bias gradients)."""
     lib = _lib.load()
     cin = sum(c for _, c in parts)
     assert 1 <= len(parts) <= 2
@@ -304,7 +327,7 @@ def wino_prep(parts, ac, silu, ups, B, S, drop=None, keep=False, dual=False):
         if 256 % S:
             raise _lib.MeshDiffusionHipError("md_wino_prep_dual needs W | 256")
         u = _wino_scratch(nbytes // 2, dev, slot="u")
-        check(lib.md_wino_prep_dual(*args, _ptr(t), _ptr(u), *tail), "md_wino_prep_dual")
+        check(lib.md_wino_prep_dual(*args, _ptr(t), _ptr(u), _ptr(sums), *tail), "md_wino_prep_dual")
     else:
         fn = lib.md_wino_prep_v2 if (WINO_PREP_V2 and 256 % S == 0) else lib.md_wino_prep
         check(fn(*args, _ptr(t), *tail), "md_wino_prep")

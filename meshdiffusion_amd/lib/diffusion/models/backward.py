@@ -174,7 +174,7 @@ def dgrad_wino_weight(layer, name, conv):
 
 
 def conv3_backward(layer, name, conv, dy, act_s16, B, S_out, ups=0, stride=1, need_dx=True, act_channels=None,
-                   bias_sums=None, shared=None, t_act=None):
+                   bias_sums=None, shared=None, t_act=None, bias_sums_out=False):
     """Backward of y = conv k^3 (act) (+bias), k = 3 (any layer) or 5 (stem / head of ddpm_res128, stride 1).
     dy: F32B [B][co][S_out^3]; act_s16: S16B input operand of the forward (coarse grid when ups, fine grid 2*S_out
     when stride 2).  Returns dx (F32B) or None.
@@ -182,7 +182,8 @@ def conv3_backward(layer, name, conv, dy, act_s16, B, S_out, ups=0, stride=1, ne
     gradient (the ResnetBlock's Conv_1 and shortcut NIN_0 both start from the block's output gradient).
     t_act: the forward conv's Winograd operand T (layers on the Winograd path, hip_ops.wgrad_wino_ok) in place of `act_s16`:
     ONE pass over dy (md_wino_prep_dual) feeds the Winograd data-gradient conv and the Winograd weight gradient (md_wgrad_wino);
-    no S16B / PB16 tensors at all."""
+    no S16B / PB16 tensors at all.  bias_sums_out (with t_act): `bias_sums` is a ZEROED [B, co] float tensor that this call
+    fills (the operand pass over dy adds up its channels) for the caller's other consumers of the same sums."""
     from . import layers
     co, ci, ksz = conv.weight.shape[0], conv.weight.shape[1], conv.weight.shape[-1]
     taps, pad = ksz ** 3, ksz // 2
@@ -191,12 +192,18 @@ def conv3_backward(layer, name, conv, dy, act_s16, B, S_out, ups=0, stride=1, ne
     dev = dy.device
     co_t = dy.shape[1] * 8            # channels of the dy tensor (co rounded up to 8)
     # bias
-    if bias_sums is not False:   # False: the caller owns the bias gradient (ResnetBlock Conv_0: FiLM shares the sums)
+    fused_sums = t_act is not None and bias_sums is not False and (bias_sums is None or bias_sums_out)
+    if bias_sums is not False and not fused_sums:   # False: the caller owns the bias gradient (ResnetBlock Conv_0: FiLM shares the sums)
         bs = bias_sums if bias_sums is not None else channel_sums(dy, B, co_t, P)
         _grad_of(conv.bias).add_(bs.sum(0)[:co])
     if t_act is not None:
         assert ksz == 3 and stride == 1 and co == co_t
-        t_dy, u_dy = ops.wino_prep([(dy, co)], None, False, False, B, S_out, dual=True)
+        bs = None
+        if fused_sums:      # the operand pass over dy also adds up its channels: no md_channel_sums pass
+            bs = bias_sums if bias_sums is not None else torch.zeros((B, co), dtype=torch.float32, device=dev)
+        t_dy, u_dy = ops.wino_prep([(dy, co)], None, False, False, B, S_out, dual=True, sums=bs)
+        if fused_sums:
+            _grad_of(conv.bias).add_(bs.sum(0)[:co])
         ops.wgrad_wino(u_dy, t_act, B, co, ci, S_out, _grad_of(conv.weight))
         if not need_dx:
             return None
@@ -300,18 +307,26 @@ def nin_backward(nin, dy, xs_s16, B, P, S, need_dx=True, with_bias=True, bias_su
     if with_bias:
         bs = bias_sums if bias_sums is not None else channel_sums(dy, B, co, P)
         _grad_of(nin.b).add_(bs.sum(0)[:co])
-    dy_pb = shared.get("dy_pb") if shared is not None else None
-    if dy_pb is None:
-        dy_pb = to_pb16(dy, B, co, S, 0, zhalo=False)
-        if shared is not None:
-            shared["dy_pb"] = dy_pb
-    wgrad_nin(dy_pb, xs_s16, B, co, ci, S, _grad_of(nin.W))
-    del dy_pb
+    dy16 = shared.get("dy_s16") if shared is not None else None
+    if ops.wgrad_nin_ok(co, ci, P):
+        # both operands as they are (S16B): no PB16 re-layout; the same split of dy feeds the data-gradient GEMM below
+        if dy16 is None:
+            dy16 = split_f32b(dy, B, co, P)
+            if shared is not None:
+                shared["dy_s16"] = dy16
+        ops.wgrad_nin(dy16, xs_s16, B, co, ci, P, _grad_of(nin.W))
+    else:
+        dy_pb = shared.get("dy_pb") if shared is not None else None
+        if dy_pb is None:
+            dy_pb = to_pb16(dy, B, co, S, 0, zhalo=False)
+            if shared is not None:
+                shared["dy_pb"] = dy_pb
+        wgrad_nin(dy_pb, xs_s16, B, co, ci, S, _grad_of(nin.W))
+        del dy_pb
     if not need_dx:
         return None
     cfg = ops.gemm_cfg_for(P, ci)
     pw = nin._cached(f"dgrad{cfg}", [nin.W], lambda: ops.PackedWeight(nin.W, "rows", cfg, nin.W.device))
-    dy16 = shared.get("dy_s16") if shared is not None else None
     if dy16 is None:
         dy16 = split_f32b(dy, B, co, P)
         if shared is not None:

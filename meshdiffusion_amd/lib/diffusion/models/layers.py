@@ -479,8 +479,12 @@ class ResnetBlockDDPM(HipLayer):
         # Conv_1 and the shortcut NIN_0 both start from the block's output gradient: its channel sums (both biases), its PB16
         # operand (both weight gradients) and its bf16 split (both data gradients) are computed once
         shared = {} if self.in_ch != self.out_ch else None
-        bsum = bw.channel_sums(dy, B, self.out_ch, P)
-        d_a1 = bw.conv3_backward(self, "w1", self.Conv_1, dy, sv["a1"], B, S, bias_sums=bsum, shared=shared, t_act=sv.get("t1"))
+        if sv.get("t1") is not None:     # Winograd backward: Conv_1's operand pass over dy fills the channel sums on its way
+            bsum = torch.zeros((B, self.out_ch), dtype=torch.float32, device=dy.device)
+        else:
+            bsum = bw.channel_sums(dy, B, self.out_ch, P)
+        d_a1 = bw.conv3_backward(self, "w1", self.Conv_1, dy, sv["a1"], B, S, bias_sums=bsum, shared=shared, t_act=sv.get("t1"),
+                                 bias_sums_out=sv.get("t1") is not None)
         dbias0 = torch.zeros((B, self.out_ch), dtype=torch.float32, device=dy.device)
         d_h = bw.gn_backward([(sv["h"], self.out_ch)], d_a1, sv["prm1"], self.GroupNorm_1, B, P, silu=True,
                              drop=sv.get("drop"), sums_out=dbias0)[0]     # d(bias0) = channel sums of d_h, same pass

@@ -144,7 +144,7 @@ def test_bad_arguments_are_rejected_without_a_gpu(hip_lib):
     p = ctypes.cast(buf, ctypes.c_void_p)
     for fn in (hip_lib.md_wino_prep, hip_lib.md_wino_prep_v2):
         assert fn(p, None, 8, 0, None, 1, 0, p, 1, 8, 8, 8, 0.0, 0, None) == -1
-    assert hip_lib.md_wino_prep_dual(p, None, 8, 0, None, 0, 0, p, None, 1, 8, 8, 8, 0.0, 0, None) == -1     # no second output
+    assert hip_lib.md_wino_prep_dual(p, None, 8, 0, None, 0, 0, p, None, None, 1, 8, 8, 8, 0.0, 0, None) == -1     # no second output
     # Winograd weight gradient: workspace size, shapes it does not take (channels % 128, W not in {32, 64}), K-range bound
     assert hip_lib.md_wgrad_wino_workspace_bytes(128, 256, 10) == 10 * 36 * 128 * 256 * 4
     assert hip_lib.md_wgrad_wino_workspace_bytes(96, 128, 1) < 0

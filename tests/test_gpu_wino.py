@@ -268,8 +268,11 @@ def test_wino_prep_dual_second_output_bit_exact(ops):
     x = _rand((B, cin, S, S, S), 31)
     parts = [(ops.ncdhw_to_f32b(x.cuda()), cin)]
     t_ref = ops.wino_prep(parts, None, False, False, B, S).clone()
-    t, u = ops.wino_prep(parts, None, False, False, B, S, dual=True)
+    sums = torch.zeros((B, cin), device="cuda")
+    t, u = ops.wino_prep(parts, None, False, False, B, S, dual=True, sums=sums)
     assert torch.equal(t.view(torch.int16), t_ref.view(torch.int16))
+    ref_s = x.double().sum(dim=(2, 3, 4))                      # the same pass adds up the channels (bias gradients)
+    assert float((sums.cpu().double() - ref_s).abs().max()) < 1e-4 * float(x.double().abs().sum(dim=(2, 3, 4)).max())
     u = u.cpu().view(B, cin // 8, 4, 2, S, S, S // 2, 8)
     v0, v1 = x[..., 0::2], x[..., 1::2]
     tr = [v0, v0 + v1, v0 - v1, v1]
@@ -318,3 +321,31 @@ def test_wgrad_wino_vs_torch(ops, case):
     dw2 = dw0.clone()
     ops.wgrad_wino(u_dy, t_act, B, co, ci, S, dw2)
     assert torch.equal(dw2, dw)                              # fixed reduction order: run-to-run identical
+
+
+@pytest.mark.parametrize("case", ["k256_r128_32", "k128_r256_odd_batch"])
+def test_wgrad_nin_s16b_vs_torch(ops, case):
+    """md_wgrad_nin: NIN weight gradient dW[ci][co] = sum_{b, p} x[ci] dy[co] straight from the S16B tensors (no PB16 operands)
+    against float64 einsum and against md_to_pb16 + md_wgrad (taps = 1); accumulates into a non-zero dW; repeatable."""
+    from meshdiffusion_amd.lib.diffusion.models import backward as bw
+    cfg = {"k256_r128_32": dict(B=2, ci=256, co=128, S=32), "k128_r256_odd_batch": dict(B=3, ci=128, co=256, S=16)}[case]
+    B, ci, co, S = cfg["B"], cfg["ci"], cfg["co"], cfg["S"]
+    P = S ** 3
+    x = _rand((B, ci, S, S, S), 80)
+    dy = _rand((B, co, S, S, S), 81, 0.1)
+    x_f, dy_f = ops.ncdhw_to_f32b(x.cuda()), ops.ncdhw_to_f32b(dy.cuda())
+    xs, dys = bw.split_f32b(x_f, B, ci, P), bw.split_f32b(dy_f, B, co, P)
+    dw0 = _rand((ci, co), 82, 0.01).cuda()
+    dw = dw0.clone()
+    ops.wgrad_nin(dys, xs, B, co, ci, P, dw)
+    got = (dw - dw0).cpu().double()
+    ref = torch.einsum("bip,bop->io", x.double().reshape(B, ci, P), dy.double().reshape(B, co, P))
+    e = rel_l2(got, ref)
+    ref_k = torch.zeros((ci, co), device="cuda")
+    bw.wgrad_nin(bw.to_pb16(dy_f, B, co, S, 0, zhalo=False), xs, B, co, ci, S, ref_k)
+    e_k = rel_l2(got, ref_k.cpu().double())
+    print(f"wgrad_nin ({case}): vs float64 {e:.2e}, vs md_to_pb16 + md_wgrad {e_k:.2e}")
+    assert e < TOL_MFMA and e_k < TOL_MFMA
+    dw2 = dw0.clone()
+    ops.wgrad_nin(dys, xs, B, co, ci, P, dw2)
+    assert torch.equal(dw2, dw)
