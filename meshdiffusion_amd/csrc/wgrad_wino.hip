@@ -319,32 +319,32 @@ __global__ __launch_bounds__(WW_THREADS) void md_wgrad_wino_kernel(const WwArgs 
 }
 
 // dw[co*s_row + ci*s_k + ((kd*3 + kh)*3 + kw)*s_tap] += output transform of sum_r partial[r][f][kd][kh][co][ci]
+// One thread = one (co, ci, kd, kh) and its 3 kw taps (measured alternative: one thread per (co, ci) and all 27 taps as one
+// contiguous run: 6x slower -- 9x fewer threads).
 __global__ void md_wgrad_wino_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int co, int ci, int ksplit,
                                             int64_t s_row, int64_t s_k, int64_t s_tap) {
+  const int64_t total = (int64_t)9 * co * ci;
   const int64_t tile = (int64_t)co * ci;           // one (f, kd, kh) slab
   const int64_t slab = 36 * tile;                  // one K range
-  // one thread = one (co, ci) and its 9 (kd, kh) x 3 kw taps: slabs read coalesced along ci, 27 taps written as one run
-  for (int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; id < tile; id += (int64_t)gridDim.x * blockDim.x) {
+  for (int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (int64_t)gridDim.x * blockDim.x) {
     const int col = (int)(id % ci);
-    const int row = (int)(id / ci);
-    float* d = dw + row * s_row + col * s_k;
-    for (int tap = 0; tap < 9; ++tap) {            // kd * 3 + kh
-      float n[4];
+    const int row = (int)((id / ci) % co);
+    const int tap = (int)(id / tile);              // kd * 3 + kh
+    float n[4];
 #pragma unroll
-      for (int f = 0; f < 4; ++f) {
-        const float* p = partial + ((int64_t)f * 9 + tap) * tile + id;
-        float sum = 0.f;
-        for (int r = 0; r < ksplit; ++r) sum += p[r * slab];
-        n[f] = sum;
-      }
-      const float h12 = 0.5f * (n[1] + n[2]);
-      d[(int64_t)(tap * 3) * s_tap] += n[0] + h12;
-      d[(int64_t)(tap * 3 + 1) * s_tap] += 0.5f * (n[1] - n[2]);
-      d[(int64_t)(tap * 3 + 2) * s_tap] += h12 - n[3];
+    for (int f = 0; f < 4; ++f) {
+      const float* p = partial + ((int64_t)f * 9 + tap) * tile + (int64_t)row * ci + col;
+      float sum = 0.f;
+      for (int r = 0; r < ksplit; ++r) sum += p[r * slab];
+      n[f] = sum;
     }
+    const float h12 = 0.5f * (n[1] + n[2]);
+    float* d = dw + row * s_row + col * s_k + (int64_t)(tap * 3) * s_tap;
+    d[0] += n[0] + h12;
+    d[s_tap] += 0.5f * (n[1] - n[2]);
+    d[2 * s_tap] += h12 - n[3];
   }
 }
-
 
 // ------------------------------------------------------------------------------------------------------------------
 // md_wgrad_nin: weight gradient of a 1x1x1 NIN layer (autograd of layers.py:573-582) straight from the S16B tensors the
@@ -530,7 +530,7 @@ extern "C" int md_wgrad_wino(const void* u_dy, const void* t_act, float* dw, voi
     else hipLaunchKernelGGL((md_wgrad_wino_kernel<1>), grid, blk, 0, (hipStream_t)stream, g);
   }
   MD_HIP_CHECK_LAUNCH();
-  const int64_t total = (int64_t)co * ci;
+  const int64_t total = (int64_t)9 * co * ci;
   int rb = (int)((total + 255) / 256);
   if (rb > 4096) rb = 4096;
   hipLaunchKernelGGL(md_wgrad_wino_reduce_kernel, dim3((unsigned)rb), dim3(256), 0, (hipStream_t)stream, (const float*)workspace,

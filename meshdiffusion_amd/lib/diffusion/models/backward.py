@@ -19,7 +19,11 @@ from .... import _lib
 from .... import hip_ops as ops
 from ....hip_ops import _ptr, _stream, check
 
+import os
+
 GUARD_EXTRA = 12
+# A/B switch: bias-gradient channel sums of dY from the dual operand pass (md_wino_prep_dual) instead of md_channel_sums
+FUSE_DY_SUMS = os.environ.get("MD_FUSE_DY_SUMS", "1") == "1"
 WGRAD_BLOCKS = 256     # one 512-thread wgrad workgroup per CU
 
 
@@ -192,7 +196,9 @@ def conv3_backward(layer, name, conv, dy, act_s16, B, S_out, ups=0, stride=1, ne
     dev = dy.device
     co_t = dy.shape[1] * 8            # channels of the dy tensor (co rounded up to 8)
     # bias
-    fused_sums = t_act is not None and bias_sums is not False and (bias_sums is None or bias_sums_out)
+    fused_sums = FUSE_DY_SUMS and t_act is not None and bias_sums is not False and (bias_sums is None or bias_sums_out)
+    if bias_sums_out and not fused_sums:          # the caller handed a zeroed tensor to fill: fill it the separate way
+        bias_sums.copy_(channel_sums(dy, B, co_t, P))
     if bias_sums is not False and not fused_sums:   # False: the caller owns the bias gradient (ResnetBlock Conv_0: FiLM shares the sums)
         bs = bias_sums if bias_sums is not None else channel_sums(dy, B, co_t, P)
         _grad_of(conv.bias).add_(bs.sum(0)[:co])

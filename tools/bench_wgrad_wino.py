@@ -56,7 +56,11 @@ def main():
         os.environ.pop("MD_WW_DBG", None)
         ms_p = timed(lambda: ops.wino_prep([(dy, co)], None, False, False, B, S, dual=True))
         ms_p1 = timed(lambda: ops.wino_prep([(dy, co)], None, False, False, B, S))
+        sm = torch.zeros((B, co), device="cuda")
+        ms_ps = timed(lambda: ops.wino_prep([(dy, co)], None, False, False, B, S, dual=True, sums=sm))
+        ms_cs = timed(lambda: bw.channel_sums(dy, B, co, P))
         rows.append(dict(shape=sh, kernel="md_wino_prep_dual(dy)", ms=round(ms_p, 3), single_ms=round(ms_p1, 3),
+                         with_sums_ms=round(ms_ps, 3), channel_sums_ms=round(ms_cs, 3),
                          tbs=round((4.0 + 16.0) * B * co * P / ms_p / 1e9, 2)))
         # the PB16 path
         xs = bw.split_f32b(x, B, ci, P)
