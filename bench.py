@@ -189,6 +189,25 @@ def main():
                 "parity": "999-step sampled grids 6.9e-5 rel-L2 vs fp32 (profiles/r01_longrun_999step_act_fp16_experiment.json); "
                           "~1e-3 per U-Net evaluation"}
 
+    # ---- BASELINE configs[0] on the GPU: res64, batch 1 (single-sample latency), same weights ----
+    b1 = None
+    if world == 1 and B != 1 and not a.no_res128:
+        st1 = sampling.AncestralStepper(sde, (1, cfg.data.num_channels, R, R, R), eps=1e-3, device=dev, grid_mask=mask)
+        with torch.no_grad():
+            x1 = st1.prior()
+            for k in range(3):
+                x1, _ = st1.step(model_fn, x1, k)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for k in range(10):
+                x1, xm1 = st1.step(model_fn, x1, 3 + k)
+            torch.cuda.synchronize()
+            d1 = (time.perf_counter() - t1) / 10
+        b1 = {"workload": "BASELINE configs[0] on the GPU: res64 4-ch grid, batch=1, DDPM ancestral sampling steps",
+              "ms_per_step": round(d1 * 1e3, 2), "sample_steps_per_s": round(1.0 / d1, 3), "steps": 10,
+              "mfma_frac_step": round(FLOPS_PER_SAMPLE_STEP / d1 / (PEAK_BF16_TFLOPS * 1e12), 4)}
+        del st1, x1, xm1
+
     wall_t = torch.tensor([wall], dtype=torch.float64, device=dev)
     if dist is not None:
         dist.all_reduce(wall_t, op=dist.ReduceOp.MAX)
@@ -235,6 +254,8 @@ def main():
         other = None
         if world == 1 and not a.no_res128:
             other = {"res128_b2": res128_step(dev)}
+            if b1 is not None:
+                other["res64_b1"] = b1
         cpu = None
         if world == 1 and not a.no_cpu_baseline:
             cpu = cpu_baseline(sd_cpu, cfg, synth)
