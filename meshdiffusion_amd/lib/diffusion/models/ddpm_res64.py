@@ -287,6 +287,7 @@ class DDPMUNet3D(layers.HipLayer):
             else:
                 acc(ins[0], layer.backward_blocked(sv, g))
             del g
+            sv.clear()          # the layer's saved tensors (Winograd operands T, S16B activations) are dead: free them now
             announce(layer)
         # stem: h0 = conv(x) + pos_layer(coords) + mask_layer(mask) (+ biases)
         g0 = grads.pop(ctx["v0"])
