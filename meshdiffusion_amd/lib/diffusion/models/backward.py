@@ -305,9 +305,13 @@ def wgrad_nin(dy_pb, xs_s16, B, co, ci, S, dw):
     wgrad(dy_pb, x_pb, B, co, ci, S, 1, dw, 1, co, 0)
 
 
-def nin_backward(nin, dy, xs_s16, B, P, S, need_dx=True, with_bias=True, bias_sums=None, shared=None):
+def nin_backward(nin, dy, xs_s16, B, P, S, need_dx=True, with_bias=True, bias_sums=None, shared=None, accumulate_into=None):
     """Backward of y[co] = sum_ci x[ci] W[ci][co] + b.  xs_s16: S16B of the forward input.
-    bias_sums / shared: per-(sample, channel) sums and dy-derived operands already computed for another consumer of `dy`."""
+    bias_sums / shared: per-(sample, channel) sums and dy-derived operands already computed for another consumer of `dy`.
+    accumulate_into: [(F32B tensor, channels), ...] covering the input channels in order -- the data gradient is ADDED to those
+    tensors by one GEMM per part (rows of W sliced, the tensor as residual and output) instead of being returned: no
+    concatenated gradient tensor and no separate add passes (the ResnetBlock shortcut: the parts already hold the GroupNorm_0
+    path's gradient)."""
     from . import layers
     ci, co = nin.W.shape
     if with_bias:
@@ -331,12 +335,22 @@ def nin_backward(nin, dy, xs_s16, B, P, S, need_dx=True, with_bias=True, bias_su
         del dy_pb
     if not need_dx:
         return None
-    cfg = ops.gemm_cfg_for(P, ci)
-    pw = nin._cached(f"dgrad{cfg}", [nin.W], lambda: ops.PackedWeight(nin.W, "rows", cfg, nin.W.device))
     if dy16 is None:
         dy16 = split_f32b(dy, B, co, P)
         if shared is not None:
             shared["dy_s16"] = dy16
+    if accumulate_into is not None:
+        off = 0
+        for t, c in accumulate_into:
+            cfg = ops.gemm_cfg_for(P, c)
+            pw = nin._cached(f"dgrad{cfg}/{off}+{c}", [nin.W],
+                             lambda off=off, c=c, cfg=cfg: ops.PackedWeight(nin.W[off:off + c], "rows", cfg, nin.W.device))
+            layers.run_gemm(pw, dy16, B, P, residual=t, out=t)
+            off += c
+        assert off == ci
+        return None
+    cfg = ops.gemm_cfg_for(P, ci)
+    pw = nin._cached(f"dgrad{cfg}", [nin.W], lambda: ops.PackedWeight(nin.W, "rows", cfg, nin.W.device))
     return layers.run_gemm(pw, dy16, B, P)
 
 

@@ -493,19 +493,12 @@ class ResnetBlockDDPM(HipLayer):
         d_a0 = bw.conv3_backward(self, "w0", self.Conv_0, d_h, sv["a0"], B, S, bias_sums=False, t_act=sv.get("t0"))
         del d_h
         if self.in_ch != self.out_ch:
-            d_xcat = bw.nin_backward(self.NIN_0, dy, sv["xs"], B, P, S, bias_sums=bsum, shared=shared)
-            shared.clear()
             dparts = bw.gn_backward(parts, d_a0, sv["prm0"], self.GroupNorm_0, B, P, silu=True)
-            off, outs = 0, []
-            for (t, c), g in zip(parts, dparts):
-                sl = d_xcat.view(B, self.in_ch // 8, P, 8)[:, off // 8:(off + c) // 8]
-                if len(parts) == 1:
-                    g.add_(d_xcat)
-                else:
-                    g.add_(sl)
-                outs.append(g)
-                off += c
-            return outs, dbias0
+            # the shortcut's data gradient is added onto the parts by the GEMMs themselves (no concatenated tensor, no add pass)
+            bw.nin_backward(self.NIN_0, dy, sv["xs"], B, P, S, bias_sums=bsum, shared=shared,
+                            accumulate_into=[(g, c) for g, (_, c) in zip(dparts, parts)])
+            shared.clear()
+            return dparts, dbias0
         d_x = bw.gn_backward(parts, d_a0, sv["prm0"], self.GroupNorm_0, B, P, silu=True, residual=dy)[0]
         return [d_x], dbias0
 
