@@ -167,7 +167,13 @@ class DDPMUNet3D(layers.HipLayer):
         temb = ops.linear(t1, mods[1].weight, mods[1].bias, silu_in=True); i += 1
         stem = mods[i]; i += 1
         xin = x if self.centered else 2 * x - 1.0
-        x16 = ops.ncdhw_to_s16b(xin, 16)            # unfolded operand: the stem's weight gradient contracts against it
+        # unfolded operand of the three input convolutions' weight gradients (stem on x, mask_layer on the mask, pos_layer on
+        # the coordinates all produce h0 and share its gradient): ONE 16-slot operand [x 0..3 | mask 4 | coords 5..7 | 0]
+        # and one md_wgrad launch instead of three 128 x 128-tile launches that each re-read dY nine times
+        srcs = [xin, self.mask.detach().expand(B, -1, -1, -1, -1)]
+        if self.USE_COORDS:
+            srcs.append(self.coords.detach().expand(B, -1, -1, -1, -1))
+        x16 = ops.ncdhw_to_s16b(torch.cat(srcs, dim=1).contiguous(), 16)
         h = self._stem_forward(stem, xin, B, R)
         fw, fb, foffs, ftot = self._film_table()
         film = ops.linear(temb, fw, fb, silu_in=True)
@@ -292,13 +298,20 @@ class DDPMUNet3D(layers.HipLayer):
         # stem: h0 = conv(x) + pos_layer(coords) + mask_layer(mask) (+ biases)
         g0 = grads.pop(ctx["v0"])
         stem = mods[2]
-        bsum = bw.channel_sums(g0, B, self.nf, P)     # all three biases receive the same sum of g0
-        bw.conv3_backward(self, "stem", stem, g0, ctx["x16"], B, R, need_dx=False, act_channels=16, bias_sums=bsum)
-        m8 = ops.ncdhw_to_s16b(self.mask.detach().expand(B, -1, -1, -1, -1).contiguous(), 8)
-        bw.conv3_backward(self, "mask_layer", self.mask_layer, g0, m8, B, R, need_dx=False, act_channels=8, bias_sums=bsum)
+        bsum = bw.channel_sums(g0, B, self.nf, P).sum(0)     # all three biases receive the same sum of g0
+        convs = [(stem, 0, stem.weight.shape[1]), (self.mask_layer, stem.weight.shape[1], 1)]
         if self.USE_COORDS:
-            c8 = ops.ncdhw_to_s16b(self.coords.detach().expand(B, -1, -1, -1, -1).contiguous(), 8)
-            bw.conv3_backward(self, "pos_layer", self.pos_layer, g0, c8, B, R, need_dx=False, act_channels=8, bias_sums=bsum)
+            convs.append((self.pos_layer, stem.weight.shape[1] + 1, 3))
+        ksz = stem.weight.shape[-1]
+        taps, pad = ksz ** 3, ksz // 2
+        dw = torch.zeros((self.nf, 16, taps), dtype=torch.float32, device=g0.device)
+        dy_pb = bw.to_pb16(g0, B, self.nf, R, 0, pad=pad, zhalo=False)
+        act_pb = bw.to_pb16(ctx["x16"], B, 16, R, 1, pad=pad)
+        bw.wgrad(dy_pb, act_pb, B, self.nf, 16, R, taps, dw, 16 * taps, taps, 1)
+        del dy_pb, act_pb
+        for conv, c0, c in convs:
+            bw._grad_of(conv.weight).add_(dw[:, c0:c0 + c].reshape(conv.weight.shape))
+            bw._grad_of(conv.bias).add_(bsum[:self.nf])
         del g0
         # FiLM table + timestep MLP (tiny [B,512] algebra: torch ops on the device)
         temb, t1, emb = ctx["temb"], ctx["t1"], ctx["emb"]
