@@ -276,6 +276,30 @@ __global__ void md_wgrad_reduce_kernel(const float* __restrict__ partial, float*
   }
 }
 
+
+// The same reduction for the 3x3x3 conv layout (dw[co][ci][27]: s_k == 27, s_tap == 1) with an LDS transpose: a block takes
+// one row and 64 columns, reads the 27 slot slabs in 256-byte runs along col and writes the 64 x 27 = 1728 floats of dW as ONE
+// contiguous run (the generic kernel's adjacent threads write 108 bytes apart: 16x write amplification, 0.1 ms for a
+// 512 x 512 layer, 6 ms per training step over the 8^3 / 4^3 levels).
+__global__ __launch_bounds__(256) void md_wgrad_reduce27_kernel(const float* __restrict__ partial, float* __restrict__ dw, int rows,
+                                                                int cols, int RT, int CT, int ksplit, int64_t s_row) {
+  __shared__ float tile[64 * 28];
+  const int tid = threadIdx.x;
+  const int cb = cols >> 6;
+  const int row = blockIdx.x / cb, c0 = (blockIdx.x % cb) << 6;
+  const int64_t plane = (int64_t)RT * CT, slab = 27 * plane;
+  const int c = tid & 63;
+  for (int slot = tid >> 6; slot < 27; slot += 4) {
+    const float* p = partial + (int64_t)slot * plane + (int64_t)row * CT + c0 + c;
+    float sum = 0.f;
+    for (int r = 0; r < ksplit; ++r) sum += p[r * slab];
+    tile[c * 28 + slot] = sum;
+  }
+  __syncthreads();
+  float* d = dw + (int64_t)row * s_row + (int64_t)c0 * 27;
+  for (int e = tid; e < 64 * 27; e += 256) d[e] += tile[(e / 27) * 28 + (e % 27)];
+}
+
 }  // namespace
 
 static int md_wgrad_debug = 0;
@@ -337,6 +361,12 @@ extern "C" int md_wgrad(const void* dy_pb, const void* act_pb, float* dw, void* 
   else hipLaunchKernelGGL((md_wgrad_kernel<1, false, 0>), grid, blk, 0, hs, g);
   MD_HIP_CHECK_LAUNCH();
   const int nslots = md_wgrad_slots(taps);
+  if (taps == 27 && s_tap == 1 && s_k == 27 && (cols % 64) == 0 && (int64_t)rows * (cols / 64) <= 0x7fffffff) {
+    hipLaunchKernelGGL(md_wgrad_reduce27_kernel, dim3((unsigned)(rows * (cols / 64))), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)workspace, dw, rows, cols, g.co_tiles * WG_TILE, g.ci_tiles * WG_TILE, ksplit, s_row);
+    MD_HIP_CHECK_LAUNCH();
+    return MD_OK;
+  }
   const int64_t total = (int64_t)nslots * rows * cols;
   int rb = (int)((total + 255) / 256);
   if (rb > 4096) rb = 4096;
