@@ -319,8 +319,9 @@ __global__ __launch_bounds__(WW_THREADS) void md_wgrad_wino_kernel(const WwArgs 
 }
 
 // dw[co*s_row + ci*s_k + ((kd*3 + kh)*3 + kw)*s_tap] += output transform of sum_r partial[r][f][kd][kh][co][ci]
-// One thread = one (co, ci, kd, kh) and its 3 kw taps (measured alternative: one thread per (co, ci) and all 27 taps as one
-// contiguous run: 6x slower -- 9x fewer threads).
+// One thread = one (co, ci, kd, kh) and its 3 kw taps (measured alternatives: one thread per (co, ci) and all 27 taps as one
+// contiguous run: 6x slower -- 9x fewer threads; the LDS-transposing form of md_wgrad_reduce27_kernel: 2.3x slower here --
+// these layers have 128-256 channels, i.e. 256-1024 blocks of it).
 __global__ void md_wgrad_wino_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int co, int ci, int ksplit,
                                             int64_t s_row, int64_t s_k, int64_t s_tap) {
   const int64_t total = (int64_t)9 * co * ci;
@@ -344,35 +345,6 @@ __global__ void md_wgrad_wino_reduce_kernel(const float* __restrict__ partial, f
     d[s_tap] += 0.5f * (n[1] - n[2]);
     d[2 * s_tap] += h12 - n[3];
   }
-}
-
-// LDS-transposing form for dw[co][ci][27] (s_k == 27, s_tap == 1): one row and 64 columns per block, the 36 (f, kd, kh) slabs read
-// in 256-byte runs, the 64 x 27 floats of dW written as one contiguous run
-__global__ __launch_bounds__(256) void md_wgrad_wino_reduce27_kernel(const float* __restrict__ partial, float* __restrict__ dw, int co,
-                                                                     int ci, int ksplit, int64_t s_row) {
-  __shared__ float tile[64 * 28];
-  const int tid = threadIdx.x;
-  const int cb = ci >> 6;
-  const int row = blockIdx.x / cb, c0 = (blockIdx.x % cb) << 6;
-  const int64_t tsz = (int64_t)co * ci, slab = 36 * tsz;
-  const int c = tid & 63;
-  for (int tap = tid >> 6; tap < 9; tap += 4) {            // kd * 3 + kh
-    float n[4];
-#pragma unroll
-    for (int f = 0; f < 4; ++f) {
-      const float* p = partial + ((int64_t)f * 9 + tap) * tsz + (int64_t)row * ci + c0 + c;
-      float sum = 0.f;
-      for (int r = 0; r < ksplit; ++r) sum += p[r * slab];
-      n[f] = sum;
-    }
-    const float h12 = 0.5f * (n[1] + n[2]);
-    tile[c * 28 + tap * 3] = n[0] + h12;
-    tile[c * 28 + tap * 3 + 1] = 0.5f * (n[1] - n[2]);
-    tile[c * 28 + tap * 3 + 2] = h12 - n[3];
-  }
-  __syncthreads();
-  float* d = dw + (int64_t)row * s_row + (int64_t)c0 * 27;
-  for (int e = tid; e < 64 * 27; e += 256) d[e] += tile[(e / 27) * 28 + (e % 27)];
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -559,12 +531,6 @@ extern "C" int md_wgrad_wino(const void* u_dy, const void* t_act, float* dw, voi
     else hipLaunchKernelGGL((md_wgrad_wino_kernel<1>), grid, blk, 0, (hipStream_t)stream, g);
   }
   MD_HIP_CHECK_LAUNCH();
-  if (s_tap == 1 && s_k == 27) {
-    hipLaunchKernelGGL(md_wgrad_wino_reduce27_kernel, dim3((unsigned)(co * (ci / 64))), dim3(256), 0, (hipStream_t)stream,
-                       (const float*)workspace, dw, co, ci, ksplit, s_row);
-    MD_HIP_CHECK_LAUNCH();
-    return MD_OK;
-  }
   const int64_t total = (int64_t)9 * co * ci;
   int rb = (int)((total + 255) / 256);
   if (rb > 4096) rb = 4096;
