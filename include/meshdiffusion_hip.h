@@ -42,7 +42,7 @@ extern "C" {
 #define MD_ERR_UNSUPPORTED (-2)
 #define MD_ERR_NO_DEVICE (-3)
 
-#define MD_ABI_VERSION 9
+#define MD_ABI_VERSION 10
 
 /* ---- tile configurations of md_gemm_conv (compile-time instantiations) ---- */
 enum {
@@ -280,6 +280,20 @@ int md_wino_pack_weights(const float* w, void* wpk, int32_t cout, int32_t cin, i
 int md_conv3_wino(const void* t_in, const void* wpk, float* out, const float* bias, int64_t bias_bstride,
                   const float* residual, int64_t res_bstride, double* stats, int32_t batch, int32_t cin, int32_t cout,
                   int32_t D, int32_t H, int32_t W, int32_t variant, void* stream);
+
+/*
+ * md_conv3_s2: the stride-2 3x3x3 convolution of Downsample (layers.py:626-643: F.pad(x, (0, 1, 0, 1, 0, 1)) +
+ * nn.Conv3d(C, C, 3, stride=2, padding=0)) for inference, reading the raw fp32 tensor (csrc/conv3_s2.hip): replaces the
+ * split pass md_gn_apply(norm = 0) + md_gemm_conv(MD_CFG_C3_S2).  bf16x3 products, fp32 accumulation.
+ *   x      : F32B [B][cin/8][(2D)(2H)(2W)][8]
+ *   wpk    : md_pack_weights(W, rows = cout, kdim = cin, taps = 27, nt = 128, kc = 16)
+ *   out    : F32B [B][rows_alloc/8][D*H*W][8] = conv + bias[b*bias_bstride + co]   (D, H, W: OUTPUT grid)
+ *   stats  : optional zeroed double [B][rows_alloc][2] += per-(sample, channel) (sum, sum of squares) of out
+ * Supported: cin % 32 == 0, D % 4 == 0, H % 8 == 0, W % 8 == 0, D*H*W < 2^27; else MD_ERR_UNSUPPORTED (md_gemm_conv
+ * with MD_CFG_C3_S2 handles every shape).
+ */
+int md_conv3_s2(const float* x, const void* wpk, float* out, const float* bias, int64_t bias_bstride, double* stats,
+                int32_t batch, int32_t cin, int32_t rows, int32_t rows_alloc, int32_t D, int32_t H, int32_t W, void* stream);
 
 /* md_wino_prep in two phases through LDS (csrc/wino_prep2.hip), bit-identical output, 13 % faster (the host package's default);
  * additionally needs W | 256 and D*H*W % 256 == 0 (whole rows per workgroup), else MD_ERR_UNSUPPORTED. */

@@ -41,7 +41,7 @@ class MdGemmConvArgs(C.Structure):
     ]
 
 
-ABI_VERSION = 9      # MD_ABI_VERSION of include/meshdiffusion_hip.h this host code was written against
+ABI_VERSION = 10     # MD_ABI_VERSION of include/meshdiffusion_hip.h this host code was written against
 _P, _I32, _I64, _F, _U64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint64
 
 # name -> (restype, argtypes); exactly the entry points of include/meshdiffusion_hip.h
@@ -72,6 +72,7 @@ SIGNATURES = {
     "md_wino_weight_bytes": (_I64, [_I32, _I32]),
     "md_wino_pack_weights": (C.c_int, [_P, _P, _I32, _I32, _I64, _I64, _I32, _P]),
     "md_conv3_wino": (C.c_int, [_P, _P, _P, _P, _I64, _P, _I64, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P]),
+    "md_conv3_s2": (C.c_int, [_P, _P, _P, _P, _I64, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P]),
     "md_wino_prep_v2": (C.c_int, [_P, _P, _I32, _I32, _P, _I32, _I32, _P, _I32, _I32, _I32, _I32, _F, _U64, _P]),
     "md_wino_prep_dual": (C.c_int, [_P, _P, _I32, _I32, _P, _I32, _I32, _P, _P, _P, _I32, _I32, _I32, _I32, _F, _U64, _P]),
     "md_wgrad_wino_workspace_bytes": (_I64, [_I32, _I32, _I32]),

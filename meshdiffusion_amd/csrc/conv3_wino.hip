@@ -372,15 +372,17 @@ __global__ __launch_bounds__(WN_THREADS) void md_conv3_wino_kernel(const WnArgs 
   const float* resp = A.residual ? A.residual + (int64_t)b * A.res_bstride : nullptr;
   const float* biasp = A.bias ? A.bias + (int64_t)b * A.bias_bstride : nullptr;
   const bool want_stats = A.stats != nullptr;
-  // this wave finishes column tile `wid`: output plane z0 + wid, row y0 + (j >> 2), x = x0 + 2 (j & 3) + {0, 1}
-  const int64_t gp0 = ((int64_t)(z0 + wid) * H + (y0 + (j >> 2))) * W + x0 + 2 * (j & 3);
-  auto row_sum = [](float v) {
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
-    return v;
-  };
+  // Write side (MFMA layout): lane (j, h) holds column j of a column tile, rows 8 q + 4 h + {0..3}.
+  // Read side: this wave finishes column tile `wid` (output plane z0 + wid).  A lane takes FOUR output channels
+  // (4 cq .. 4 cq + 3: one 16-byte store per position) of the EIGHT positions of one tile row (y0 + yr, the 4 pairs along
+  // w), so that the GroupNorm sums of a channel are mostly in-lane adds: 8 positions per lane, then 2 DPP steps over the 4
+  // lanes of a DPP row that share the channel quad (the first form held 16 channels x 2 positions per lane: 32 values x 4
+  // DPP steps per round, a dependent chain that was 1/4 of the epilogue).  Lane bits: [1:0] cq low, [3:2] yr low, [4] yr
+  // high, [5] cq high -- the 16 lanes of a ds_read_b128 group read 16 different 16-byte bank groups (row stride 36 floats:
+  // (4 yr + pr) * 9 + cq = 4 yr + cq mod 16).
+  const int cq = (lane & 3) | ((lane >> 5) << 2), yr = (lane >> 2) & 7;
+  // positions: plane z0 + wid, row y0 + yr, x = x0 + 2 pr + {0, 1}
+  const int64_t gp0 = ((int64_t)(z0 + wid) * H + (y0 + yr)) * W + x0;
   auto flush_stats = [&](int r) {     // after the barrier that follows round r's red[] writes: 64 fp64 atomics
     if (tid < 64) {
       const int ch = tid >> 1, which = tid & 1;
@@ -394,21 +396,27 @@ __global__ __launch_bounds__(WN_THREADS) void md_conv3_wino_kernel(const WnArgs 
   };
   // bias / residual of round r are requested one round ahead (round 0: before the first barrier): the rounds are short and a
   // load issued where it is used would expose one HBM latency per round
-  f32x4 pbias[2][4], pres[2][4][2];
+  f32x4 pbias[2], pres[2][4][2];
   auto prefetch = [&](int r) {
+    const int row = rtb * 128 + r * 32 + 4 * cq;
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    pbias[r & 1] = biasp != nullptr ? *(const f32x4*)(biasp + row) : z;
+    if (resp != nullptr) {
+      const float* rp = resp + ((int64_t)(row >> 3) * P + gp0) * 8 + (row & 7);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int row = rtb * 128 + r * 32 + 8 * q + 4 * h;
-      f32x4 z = {0.f, 0.f, 0.f, 0.f};
-      pbias[r & 1][q] = biasp != nullptr ? *(const f32x4*)(biasp + row) : z;
-      if (resp != nullptr) {
-        const float* rp = resp + ((int64_t)(row >> 3) * P + gp0) * 8 + (row & 7);
-        pres[r & 1][q][0] = *(const f32x4*)rp;
-        pres[r & 1][q][1] = *(const f32x4*)(rp + 8);
-      } else {
-        pres[r & 1][q][0] = z; pres[r & 1][q][1] = z;
+      for (int pr = 0; pr < 4; ++pr) {
+        pres[r & 1][pr][0] = *(const f32x4*)(rp + pr * 16);
+        pres[r & 1][pr][1] = *(const f32x4*)(rp + pr * 16 + 8);
       }
+    } else {
+#pragma unroll
+      for (int pr = 0; pr < 4; ++pr) { pres[r & 1][pr][0] = z; pres[r & 1][pr][1] = z; }
     }
+  };
+  auto quad_sum = [](float v) {       // over the 4 lanes of a DPP row with the same lane & 3 (row_ror 8, row_ror 4)
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xF, 0xF, true));
+    return v;
   };
   prefetch(0);
   __syncthreads();                                       // every wave is done with its private buffers (the exchange area aliases them)
@@ -431,40 +439,31 @@ __global__ __launch_bounds__(WN_THREADS) void md_conv3_wino_kernel(const WnArgs 
 #pragma unroll
     for (int ff = 0; ff < 4; ++ff)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) m[ff][q] = *(const f32x4*)(xr + ((ff * 128 + wid * 32 + j) * WN_XSTRIDE + 8 * q + 4 * h));
-    float s1[4][4], s2[4][4];
+      for (int pr = 0; pr < 4; ++pr)
+        m[ff][pr] = *(const f32x4*)(xr + ((ff * 128 + wid * 32 + yr * 4 + pr) * WN_XSTRIDE + 4 * cq));
+    const int row = rtb * 128 + r * 32 + 4 * cq;
+    float* op = outp + ((int64_t)(row >> 3) * P + gp0) * 8 + (row & 7);
+    const f32x4 bv = pbias[r & 1];
+    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int row = rtb * 128 + r * 32 + 8 * q + 4 * h;
-      const f32x4 bv = pbias[r & 1][q], r0 = pres[r & 1][q][0], r1 = pres[r & 1][q][1];
-      float* op = outp + ((int64_t)(row >> 3) * P + gp0) * 8 + (row & 7);
-      f32x4 o0, o1;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float v0 = (m[0][q][e] + m[1][q][e]) + m[2][q][e];
-        float v1 = (m[1][q][e] - m[2][q][e]) - m[3][q][e];
-        v0 += bv[e]; v1 += bv[e];
-        v0 += r0[e]; v1 += r1[e];
-        o0[e] = v0; o1[e] = v1;
-        s1[q][e] = v0 + v1;
-        s2[q][e] = v0 * v0 + v1 * v1;
-      }
-      *(f32x4*)op = o0;
-      *(f32x4*)(op + 8) = o1;
+    for (int pr = 0; pr < 4; ++pr) {
+      f32x4 o0 = ((m[0][pr] + m[1][pr]) + m[2][pr]) + bv + pres[r & 1][pr][0];
+      f32x4 o1 = ((m[1][pr] - m[2][pr]) - m[3][pr]) + bv + pres[r & 1][pr][1];
+      *(f32x4*)(op + pr * 16) = o0;
+      *(f32x4*)(op + pr * 16 + 8) = o1;
+      s1 += o0 + o1;
+      s2 += o0 * o0 + o1 * o1;
     }
     if (want_stats) {
-      float* rb = red + (r & 1) * WN_RED;
+      f32x4 a1, a2;
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float a1 = row_sum(s1[q][e]), a2 = row_sum(s2[q][e]);
-          if ((lane & 15) == 0) {
-            const int jr = (lane >> 4) & 1, ch = 8 * q + 4 * h + e;
-            rb[((wid * 2 + jr) * 32 + ch) * 2] = a1;
-            rb[((wid * 2 + jr) * 32 + ch) * 2 + 1] = a2;
-          }
-        }
+      for (int e = 0; e < 4; ++e) { a1[e] = quad_sum(s1[e]); a2[e] = quad_sum(s2[e]); }
+      if ((lane & 12) == 0) {         // one lane per (channel quad, half of the tile rows): 8 consecutive floats of red[]
+        float* rb = red + (r & 1) * WN_RED + ((wid * 2 + ((lane >> 4) & 1)) * 32 + 4 * cq) * 2;
+        const f32x4 w0 = {a1[0], a2[0], a1[1], a2[1]}, w1 = {a1[2], a2[2], a1[3], a2[3]};
+        *(f32x4*)rb = w0;
+        *(f32x4*)(rb + 4) = w1;
+      }
     }
   }
   if (want_stats) {

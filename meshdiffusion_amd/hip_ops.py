@@ -379,6 +379,31 @@ def conv3_wino(ww, t, B, S, *, bias=None, bias_bstride=0, residual=None, res_bst
     return out
 
 
+# Stride-2 3x3x3 convolution of Downsample on the raw fp32 tensor (csrc/conv3_s2.hip): no split pass, slab-wise K loop
+CONV3_S2 = os.environ.get("MD_CONV3_S2", "1") == "1"   # A/B switch: 0 = md_gn_apply (split) + md_gemm_conv(CFG_C3_S2)
+CFG_S2_PACK = CFG_C3_128_K16                           # tile geometry of its packed weights: nt = 128, kc = 16, 27 taps
+
+
+def conv3_s2_ok(rows, kdim, S_out):
+    return CONV3_S2 and PRECISION == "bf16x3" and kdim % 32 == 0 and rows % 8 == 0 and S_out % 8 == 0
+
+
+def conv3_s2(pw, x, B, S_out, *, bias=None, bias_bstride=0, stats=None, out=None):
+    """out F32B [B][rows][S_out^3] = stride-2 conv (pad (0, 1)) of the F32B tensor x [B][kdim/8][(2 S_out)^3][8] with the
+    CFG_S2_PACK tiles `pw` -- md_conv3_s2."""
+    lib = _lib.load()
+    P = S_out ** 3
+    rows_alloc = ((pw.rows + 7) // 8) * 8
+    if out is None:
+        out = f32b_empty(B, rows_alloc, P, x.device)
+    ev = _prof_begin()
+    check(lib.md_conv3_s2(_ptr(x), _ptr(pw.data), _ptr(out), _ptr(bias), bias_bstride, _ptr(stats), B, pw.kdim, pw.rows,
+                          rows_alloc, S_out, S_out, S_out, _stream()), "md_conv3_s2")
+    _prof_end(ev, "s2", 2.0 * B * pw.rows * pw.kdim * 27 * P, 4.0 * (B * pw.kdim * 8 * P + pw.rows * pw.kdim * 27 + B * pw.rows * P),
+              f"{pw.kdim}->{pw.rows}@{S_out}x{S_out}x{S_out}" + ("/stats" if stats is not None else ""))
+    return out
+
+
 # ---- EXPERIMENTAL: Winograd F(4,3) along w (csrc/experimental/conv3_wino43.hip, MD_BUILD_EXPERIMENTAL=1 builds only);
 # ---- tools/bench_wino.py --f43, tests/test_gpu_wino.py.  Nothing on the product path uses it.
 def _need_experimental():

@@ -333,6 +333,15 @@ class Downsample(HipLayer):
 
     def forward_blocked(self, x, Cc, B, P, tape=None):
         s_out = _spatial_edge(P) // 2
+        if tape is None and ops.conv3_s2_ok(self.Conv_0.weight.shape[0], Cc, s_out):
+            # inference: one kernel on the raw fp32 tensor (no split pass), GroupNorm sums of the output from its epilogue
+            pw = self._cached("w/s2", [self.Conv_0.weight],
+                              lambda: ops.PackedWeight(self.Conv_0.weight, "conv", ops.CFG_S2_PACK, self.Conv_0.weight.device))
+            stats = torch.zeros((B, pw.rows, 2), dtype=torch.float64, device=x.device) if ops.FUSE_GN_STATS and pw.rows % 8 == 0 else None
+            out = ops.conv3_s2(pw, x, B, s_out, bias=self.Conv_0.bias, stats=stats)
+            if stats is not None:
+                out._md_sums = stats
+            return out
         act = ops.gn_apply([(x, Cc)], None, B, P, norm=False, silu=False)
         pw = conv3_packed(self, "w", self.Conv_0, ops.conv_cfg_for(s_out, stride=2))
         if tape is not None:

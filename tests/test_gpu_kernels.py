@@ -146,6 +146,39 @@ def test_conv3_stride2(ops, S_in):
     assert rel_l2(ops.f32b_to_ncdhw(out, (So, So, So)).cpu(), ref) < TOL_MFMA
 
 
+@pytest.mark.parametrize("B,cin,cout,S_out", [(2, 32, 64, 8), (1, 64, 128, 16), (2, 128, 136, 8), (3, 32, 256, 16)])
+def test_conv3_s2_fp32_operand_kernel(ops, B, cin, cout, S_out):
+    """md_conv3_s2 (csrc/conv3_s2.hip: Downsample's pad (0, 1) + stride-2 conv on the raw fp32 tensor, (chunk, kd) slabs
+    with the x parity de-interleaved in LDS) against torch fp32, against the generic tile it replaces (md_gn_apply split +
+    MD_CFG_C3_S2), its GroupNorm sums against float64 sums of what it wrote, bit-identical between launches.
+    Cases: one tile / several tiles per axis (far-face padding in every tile position), 2-8 chunks, a partial row tile,
+    two row tiles."""
+    S_in = 2 * S_out
+    x = _rand((B, cin, S_in, S_in, S_in), 70 + cin); w = _rand((cout, cin, 3, 3, 3), 71, 0.05); b = _rand((cout,), 72)
+    xf = ops.ncdhw_to_f32b(x.cuda())
+    pw = ops.PackedWeight(w.cuda(), "conv", ops.CFG_S2_PACK, "cuda")
+    assert ops.conv3_s2_ok(cout, cin, S_out)
+    stats = torch.zeros((B, cout, 2), dtype=torch.float64, device="cuda")
+    out = ops.conv3_s2(pw, xf, B, S_out, bias=b.cuda(), stats=stats)
+    got = ops.f32b_to_ncdhw(out, (S_out,) * 3).cpu()
+    ref = F.conv3d(F.pad(x, (0, 1, 0, 1, 0, 1)), w, b, stride=2)
+    e = rel_l2(got, ref)
+    print(f"conv3_s2 {cin}->{cout} @ {S_in}^3 -> {S_out}^3: vs torch fp32 {e:.2e}")
+    assert e < TOL_MFMA
+    g64 = got.double()
+    ref_sums = torch.stack([g64.sum(dim=(2, 3, 4)), (g64 * g64).sum(dim=(2, 3, 4))], dim=-1)
+    assert torch.allclose(stats.cpu(), ref_sums, rtol=1e-5, atol=1e-3)
+    # the path it replaces
+    s16, _, _ = _to_s16(ops, x)
+    pw_old = ops.PackedWeight(w.cuda(), "conv", ops.CFG_C3_S2, "cuda")
+    old = ops.f32b_empty(B, cout, S_out ** 3, "cuda")
+    ops.gemm_conv(cfg=ops.CFG_C3_S2, a=pw_old.data, b=s16, out=old, batch=B, rows=cout, rows_alloc=cout, kdim=cin,
+                  dims=(S_out,) * 3, bias=b.cuda())
+    assert rel_l2(got, ops.f32b_to_ncdhw(old, (S_out,) * 3).cpu()) < 1e-5
+    out2 = ops.conv3_s2(pw, xf, B, S_out, bias=b.cuda())
+    assert torch.equal(out, out2)
+
+
 @pytest.mark.parametrize("S_in,cfg_name", [(4, "CFG_C3_128"), (8, "CFG_C3_128"), (4, "CFG_C3_128_FAST"), (8, "CFG_C3_128_FAST")])
 def test_conv3_upsample_fold(ops, S_in, cfg_name):
     cfg = getattr(ops, cfg_name)
