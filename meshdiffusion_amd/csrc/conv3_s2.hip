@@ -187,7 +187,7 @@ __global__ __launch_bounds__(S2_THREADS) void md_conv3_s2_kernel(const S2Args A)
   // ---- main loop: two slabs (18 taps) per iteration.  Row r6 = u / 3 of the iteration reads weight stage r6 & 1; tap u
   // multiplies fragment set u & 1 while set (u + 1) & 1 is read for tap u + 1.  Per row:
   //   tap 0: W(R + 1) -> the other stage (its last readers passed the barrier of the row before), W(R + 2) requested;
-  //          at kh = 0 the next slab's fp32 items are requested, at kh = 1 they are split (VALU beside the MFMAs)
+  //          at kh = 0 the next slab's fp32 items are requested, at tap 1 of kh = 2 they are split (VALU beside the MFMAs)
   //   tap 2: barrier (at kh = 2: barrier, slab commit, barrier) BEFORE its MFMAs, whose operands are already in registers,
   //          then the fragments of the next row's first tap are read behind them.
   for (int sl = 0; sl < nslabs; sl += 2) {
@@ -203,10 +203,10 @@ __global__ __launch_bounds__(S2_THREADS) void md_conv3_s2_kernel(const S2Args A)
         w_commit(stage ^ 1);
         w_issue(R + 2 < nrows ? R + 2 : nrows - 1);
         if (kh == 0) act_issue(more ? slab + 1 : slab);
-        if (kh == 1) {
+      }
+      if (kh == 2 && kw == 1) {        // two rows (~2.5 us) after the request
 #pragma unroll
-          for (int i = 0; i < S2_IT; ++i) act_transform(i);
-        }
+        for (int i = 0; i < S2_IT; ++i) act_transform(i);
       }
       if (kw < 2) {
         S2_LOAD_FRAGS(Fn, stage, kh, kw + 1)

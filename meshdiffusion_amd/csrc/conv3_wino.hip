@@ -185,7 +185,8 @@ struct WnArgs {
 // ABL (timing only, results invalid; -DMD_BUILD_ABLATIONS, tools/bench_wino.py): bit 0 no halo traffic, bit 1 halo traffic in the
 //   prologue only (real data stays in LDS), bit 2 weight loads in the prologue only (three real sets reused), bit 3 no LDS fragment
 //   reads, bit 4 no epilogue, bit 5 halo read from a private L2-resident 30 KB, bit 6 halo read as a private contiguous
-//   HBM stream.  NOTE: with bit 0 / 3 the MFMAs run on constant operands and the chip clocks higher (data-dependent power):
+//   HBM stream, bit 7 (valid results, no statistics) per-wave s_memtime stamps of the first 1024 workgroups into the buffer
+//   passed as `stats` (tools/bench_wino.py --stamps: where a workgroup's time goes).  NOTE: with bit 0 / 3 the MFMAs run on constant operands and the chip clocks higher (data-dependent power):
 //   such runs bound the MFMA time from below, they do not price the removed traffic.
 template <int ABL>
 __global__ __launch_bounds__(WN_THREADS) void md_conv3_wino_kernel(const WnArgs A) {
@@ -193,6 +194,9 @@ __global__ __launch_bounds__(WN_THREADS) void md_conv3_wino_kernel(const WnArgs 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);       // = frequency f of this wave
   const int j = lane & 31, h = lane >> 5;
+  uint64_t stamp[10];
+  auto mark = [&](int k) { if constexpr (ABL & 128) stamp[k] = __builtin_amdgcn_s_memtime(); };
+  mark(0);
 
   const int D = A.D, H = A.H, W = A.W, Wp = W >> 1;
   const int64_t P = (int64_t)D * H * W, Ph = P >> 1;
@@ -289,6 +293,7 @@ __global__ __launch_bounds__(WN_THREADS) void md_conv3_wino_kernel(const WnArgs 
     }
   }
   read_B(0, 0, Bf[0], true);
+  mark(1);
 
   // ---- main loop: two chunks (18 steps) per iteration so that every register-set index is a compile-time constant ----
   // No LDS-DMA: an LDS-DMA instruction costs the issuing wave 150-230 cycles (measured; with one wave per SIMD nobody else
@@ -355,6 +360,7 @@ __global__ __launch_bounds__(WN_THREADS) void md_conv3_wino_kernel(const WnArgs 
   }
 #undef WN_MFMA
 
+  mark(2);
   // ---- epilogue: the four frequencies of an output pair meet through LDS, one 32-row tile per round ----------------------
   if constexpr (ABL & 16) {                              // timing only: keep the accumulators alive, write nothing
     float keep = 0.f;
@@ -371,7 +377,7 @@ __global__ __launch_bounds__(WN_THREADS) void md_conv3_wino_kernel(const WnArgs 
   float* outp = A.out + (int64_t)b * rows_total * P;
   const float* resp = A.residual ? A.residual + (int64_t)b * A.res_bstride : nullptr;
   const float* biasp = A.bias ? A.bias + (int64_t)b * A.bias_bstride : nullptr;
-  const bool want_stats = A.stats != nullptr;
+  const bool want_stats = (ABL & 128) ? false : A.stats != nullptr;
   // Write side (MFMA layout): lane (j, h) holds column j of a column tile, rows 8 q + 4 h + {0..3}.
   // Read side: this wave finishes column tile `wid` (output plane z0 + wid).  A lane takes FOUR output channels
   // (4 cq .. 4 cq + 3: one 16-byte store per position) of the EIGHT positions of one tile row (y0 + yr, the 4 pairs along
@@ -418,11 +424,9 @@ __global__ __launch_bounds__(WN_THREADS) void md_conv3_wino_kernel(const WnArgs 
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xF, 0xF, true));
     return v;
   };
-  prefetch(0);
-  __syncthreads();                                       // every wave is done with its private buffers (the exchange area aliases them)
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    float* xr = xreg + (r & 1) * WN_XREGION;
+  // The accumulators of round r go to LDS in MFMA layout (AccVGPRs straight into ds_write_b128).
+  auto write_round = [&](int r) {
+    float* xw = xreg + (r & 1) * WN_XREGION;
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
@@ -430,8 +434,19 @@ __global__ __launch_bounds__(WN_THREADS) void md_conv3_wino_kernel(const WnArgs 
         f32x4 v;
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = acc[r][ct][q * 4 + e];
-        *(f32x4*)(xr + ((wid * 128 + ct * 32 + j) * WN_XSTRIDE + 8 * q + 4 * h)) = v;
+        *(f32x4*)(xw + ((wid * 128 + ct * 32 + j) * WN_XSTRIDE + 8 * q + 4 * h)) = v;
       }
+  };
+  prefetch(0);
+  __syncthreads();                                       // every wave is done with its private buffers (the exchange area aliases them)
+  mark(3);
+  // (measured and dropped, profiles/r03_wino_epilogue_ab.txt: writing round r + 1 to the other region before round r is read and
+  // combined -- 2.878 vs 2.853 ms; pulling the first halo chunk of the workgroup that follows on this XCD into L2 at the end --
+  // 3.06 vs 2.85 ms: the lines are evicted before use and fetched twice)
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float* xr = xreg + (r & 1) * WN_XREGION;
+    write_round(r);
     if (r < 3) prefetch(r + 1);
     __syncthreads();
     if (want_stats && r > 0) flush_stats(r - 1);
@@ -465,10 +480,23 @@ __global__ __launch_bounds__(WN_THREADS) void md_conv3_wino_kernel(const WnArgs 
         *(f32x4*)(rb + 4) = w1;
       }
     }
+    mark(4 + r);
   }
   if (want_stats) {
     __syncthreads();
     flush_stats(3);
+  }
+  if constexpr (ABL & 128) {      // stamps [workgroup][wave][10] of the first 1024 workgroups (dispatch order)
+    const unsigned lin = blockIdx.x + gridDim.x * blockIdx.y;
+    if (lin < 1024u && lane == 0) {
+      uint64_t* dst = (uint64_t*)A.stats + ((size_t)lin * 4 + wid) * 10;
+      // the stores are waited for by the end of the kernel, so the last stamp is taken before them
+      stamp[8] = __builtin_amdgcn_s_memtime();
+      stamp[9] = (uint64_t)(uint32_t)__builtin_amdgcn_s_getreg((31 << 11) | 4) |                 // HW_REG_HW_ID (CU / SE of the wave)
+                 ((uint64_t)(uint32_t)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);        // HW_REG_XCC_ID
+#pragma unroll
+      for (int k = 0; k < 10; ++k) dst[k] = stamp[k];
+    }
   }
 }
 
@@ -539,6 +567,7 @@ extern "C" int md_conv3_wino(const void* t_in, const void* wpk, float* out, cons
     case 25: WN_LAUNCH(25); break;
     case 32: WN_LAUNCH(32); break;
     case 64: WN_LAUNCH(64); break;
+    case 128: WN_LAUNCH(128); break;
 #endif
     default: return MD_ERR_UNSUPPORTED;
   }

@@ -20,8 +20,13 @@
 #include "md_common.h"
 
 template <int NT_, int KC_, int TZ_, int TY_, int TX_, int TAPS_, int STRIDE_, int WR_, int WC_,
-          int SW_ = 0, int PIPE_ = 0, int ABL_ = 0>
+          int SW_ = 0, int PIPE_ = 0, int ABL_ = 0, int BF_ = 0>
 struct GCfg {
+  // BF = 1: a conv configuration (TAPS > 1) that also takes its B operand as fp32 F32B parts (MD_B_F32B_GN) and applies the
+  // folded GroupNorm affine + SiLU + zero padding + the bf16 split while staging the halo tile -- what md_conv3_main_kernel's
+  // BF mode does for the 4x8x8 tile, here for the 4^3 level (MD_CFG_C3_LOW): no md_gn_apply pass.
+  // One thread = one 8-channel group (kg = tid / (NTHREADS / KG)) x BF_IT halo positions.
+  static constexpr int BF = BF_;
   static constexpr int ABL = ABL_;  // timing-only ablations (results invalid): 1 no LDS frag reads, 2 no MFMA,
                                     // 3 no barriers/weight commits, 4 no weight global loads
   static constexpr int NT = NT_, KC = KC_, TZ = TZ_, TY = TY_, TX = TX_, TAPS = TAPS_,
@@ -52,7 +57,10 @@ struct GCfg {
   static constexpr int W_ITEMS = KG * 2 * NT;  // uint4 items of one weight tile
   static constexpr int A_ITEMS = KG * 2 * HPOS;  // uint4 items loaded per activation halo tile
   static constexpr int W_PER_THREAD = (W_ITEMS + NTHREADS - 1) / NTHREADS;
-  static constexpr int A_PER_THREAD = (A_ITEMS + NTHREADS - 1) / NTHREADS;
+  static constexpr int BF_TPK = NTHREADS / KG;                          // threads per channel group in BF mode
+  static constexpr int BF_IT = (HPOS + BF_TPK - 1) / BF_TPK;            // halo positions per thread in BF mode
+  static constexpr int A_PER_THREAD_S16 = (A_ITEMS + NTHREADS - 1) / NTHREADS;
+  static constexpr int A_PER_THREAD = (BF && 2 * BF_IT > A_PER_THREAD_S16) ? 2 * BF_IT : A_PER_THREAD_S16;
   static constexpr int W_LDS_ITEMS = 2 * W_ITEMS;
   static constexpr int LDS_ITEMS = W_LDS_ITEMS + KG * 2 * HS;
   static constexpr int LDS_BYTES = LDS_ITEMS * 16;
@@ -63,6 +71,7 @@ struct GCfg {
   static_assert(NT % (32 * WR) == 0 && MT % (32 * WC) == 0, "tile / wave grid mismatch");
   static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
   static_assert(SW == 0 || (TAPS == 27 && STRIDE == 1 && TX == 8), "SW=1 layout is for 3x3x3, x-extent 8, stride 1");
+  static_assert(BF == 0 || (TAPS > 1 && STRIDE == 1 && NTHREADS % KG == 0), "BF: stride-1 conv configurations, whole thread groups per channel group");
 };
 
 template <class C>
@@ -205,10 +214,72 @@ __global__ __launch_bounds__(C::NTHREADS) void md_gemm_conv_kernel(const MdGemmC
       }
     }
   };
+  // BF (conv configurations): kg and the halo positions of this thread are fixed; per chunk it loads its 8 channels' folded
+  // affine (a, c) and BF_IT x 8 fp32 values; the transform runs right before the LDS store (act_commit)
+  const bool bf3 = C::BF && (C::TAPS > 1) && A.b_mode == MD_B_F32B_GN;
+  const int bf_kg = C::BF ? tid / C::BF_TPK : 0;
+  f32x4 bf_ac[C::BF ? 4 : 1];
+  unsigned bf_live = 0;              // bit i: halo position i of the chunk in flight lies inside the grid
+  auto act_issue_bf = [&](auto& hr, int cc) {
+    if constexpr (C::BF) {
+      const int g8 = (cc_lo + cc) * C::KG + bf_kg;
+      const uint4* cb = (g8 < (A.b_split >> 3)) ? bf_p1 + (int64_t)g8 * Pin * 2 : bf_p2 + (int64_t)(g8 - (A.b_split >> 3)) * Pin * 2;
+      bf_live = 0;
+#pragma unroll
+      for (int i = 0; i < C::BF_IT; ++i) {
+        const int r = (tid % C::BF_TPK) + i * C::BF_TPK;
+        const int hx = r % C::XH, hy = (r / C::XH) % C::YH, hz = r / (C::XH * C::YH);
+        const int uz = z0 + hz - C::PADLO, uy = y0 + hy - C::PADLO, ux = x0 + hx - C::PADLO_X;
+        const bool inb = (r < C::HPOS) & (uz >= 0) & (uz < Di) & (uy >= 0) & (uy < Hi) & (ux >= 0) & (ux < Wi);
+        uint4 v0 = make_uint4(0, 0, 0, 0), v1 = v0;
+        if (inb) {
+          const int64_t src = (((int64_t)uz * Hi + uy) * Wi + ux) * 2;
+          v0 = cb[src]; v1 = cb[src + 1];
+          bf_live |= 1u << i;
+        }
+        hr[2 * i] = v0; hr[2 * i + 1] = v1;
+      }
+      if (A.b_ac != nullptr) {
+        const f32x4* ap = (const f32x4*)(A.b_ac + ((int64_t)b * A.kdim + (int64_t)g8 * 8) * 2);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bf_ac[q] = ap[q];
+      }
+    }
+  };
+  auto act_commit_bf = [&](auto& hr) {
+    if constexpr (C::BF) {
+#pragma unroll
+      for (int i = 0; i < C::BF_IT; ++i) {
+        const int r = (tid % C::BF_TPK) + i * C::BF_TPK;
+        if (r >= C::HPOS) continue;
+        const uint4 r0 = hr[2 * i], r1 = hr[2 * i + 1];
+        const float v[8] = {__uint_as_float(r0.x), __uint_as_float(r0.y), __uint_as_float(r0.z), __uint_as_float(r0.w),
+                            __uint_as_float(r1.x), __uint_as_float(r1.y), __uint_as_float(r1.z), __uint_as_float(r1.w)};
+        const bool live = (bf_live >> i) & 1u;      // outside the grid the ACTIVATED tensor is zero padded
+        float yv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float y = v[e];
+          if (A.b_ac != nullptr) {
+            y = y * bf_ac[e >> 1][(e & 1) * 2] + bf_ac[e >> 1][(e & 1) * 2 + 1];
+            if (A.b_silu) y = y * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(y * -1.4426950408889634f));
+          }
+          yv[e] = live ? y : 0.f;
+        }
+        uint32_t hi[4], lo[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) md_split2(yv[2 * e], yv[2 * e + 1], hi[e], lo[e]);
+        const int slot = C::slot_of(r / (C::XH * C::YH), (r / C::XH) % C::YH, r % C::XH);
+        al[(bf_kg * 2) * C::HS + slot] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+        al[(bf_kg * 2 + 1) * C::HS + slot] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+      }
+    }
+  };
   auto act_issue = [&](auto& hr, int cc) {
     if (bf32) { act_issue_f32(hr, cc); return; }
+    if (bf3) { act_issue_bf(hr, cc); return; }
 #pragma unroll
-    for (int i = 0; i < C::A_PER_THREAD; ++i) {
+    for (int i = 0; i < C::A_PER_THREAD_S16; ++i) {
       const int item = tid + i * C::NTHREADS;
       uint4 v = make_uint4(0, 0, 0, 0);
       if (item < C::A_ITEMS) {
@@ -237,8 +308,9 @@ __global__ __launch_bounds__(C::NTHREADS) void md_gemm_conv_kernel(const MdGemmC
   };
   auto act_commit = [&](auto& hr) {
     if (bf32) { act_commit_f32(hr); return; }
+    if (bf3) { act_commit_bf(hr); return; }
 #pragma unroll
-    for (int i = 0; i < C::A_PER_THREAD; ++i) {
+    for (int i = 0; i < C::A_PER_THREAD_S16; ++i) {
       const int item = tid + i * C::NTHREADS;
       if (item < C::A_ITEMS) {
         const int gp = item / C::HPOS, r = item % C::HPOS;
@@ -459,11 +531,11 @@ using Cfg_ABL4 = GCfg<128, 32, 4, 8, 8, 27, 1, 2, 4, 1, 1, 4>;
 using Cfg_ABL5 = GCfg<128, 32, 4, 8, 8, 27, 1, 2, 4, 1, 1, 5>;
 using Cfg_C3_128_K16 = GCfg<128, 16, 4, 8, 8, 27, 1, 2, 4>;
 using Cfg_C3_32 = GCfg<32, 32, 4, 8, 8, 27, 1, 1, 8>;
-using Cfg_C3X_32 = GCfg<32, 32, 4, 8, 8, 9, 1, 1, 8>;        // 3x3x1 taps: dx-folded 3x3x3 head (rows = (co, dx))
+using Cfg_C3X_32 = GCfg<32, 32, 4, 8, 8, 9, 1, 1, 8>;        // (BF = 1 measured on the res64 head: 0.67 -> 1.39 ms, more than the md_gn_apply pass it saves: the unpipelined loader exposes the transform)        // 3x3x1 taps: dx-folded 3x3x3 head (rows = (co, dx))
 using Cfg_C5X_32_K16 = GCfg<32, 16, 4, 8, 8, 25, 1, 1, 8>;   // 5x5x1 taps: dx-folded 5x5x5 head of ddpm_res128
 using Cfg_C3X_128_K16 = GCfg<128, 16, 4, 8, 8, 9, 1, 2, 4>;   // (PIPE=1 measured slower here: 1.02 vs 0.67 ms)  // dx-folded 3x3x3 stem: K = 4 ch x 3 dx (12 -> 16)
 using Cfg_C5X_128 = GCfg<128, 32, 4, 8, 8, 25, 1, 2, 4>;     // dx-folded 5x5x5 stem: K = 4 ch x 5 dx (20 -> 32)
-using Cfg_C3_LOW = GCfg<128, 32, 4, 4, 4, 27, 1, 4, 2, 0, 1>;   // PIPE=1: weight / halo loads requested ahead of the MFMAs
+using Cfg_C3_LOW = GCfg<128, 32, 4, 4, 4, 27, 1, 4, 2, 0, 1, 0, 1>;   // PIPE=1: weight / halo loads requested ahead of the MFMAs
 // experiment: 4-wave workgroups on a 4x4x8 tile (78.8 KB of LDS => two independent workgroups per CU instead of one
 // 8-wave workgroup): +4.5 % on 128->128 @64^3, -3 % on 256->128 against Cfg_C3_128 -- decoupling the barriers does not pay
 // for the larger halo re-read factor (2.8 vs 2.3)
@@ -543,10 +615,14 @@ static int launch_cfg(const MdGemmConvArgs& a, hipStream_t stream) {
   }
   if (a.a_src == MD_A_S16B && a.a_rows <= 0) return MD_ERR_BAD_ARG;
   if (a.prec != MD_PREC_BF16X3) return MD_ERR_UNSUPPORTED;  // fp16x2 lives in the dedicated conv kernel only
-  if (a.b_mode != MD_B_S16B) {   // fp32 operand: split-only, 1x1x1 configurations whose tile is a whole number of pairs per thread
-    if (a.b_mode != MD_B_F32B_GN || C::TAPS != 1 || (C::A_PER_THREAD % 2) || (C::A_ITEMS % (2 * C::NTHREADS)) || a.b_ac != nullptr ||
-        (a.b_split & 7) || a.b_split <= 0 || (a.b_split < a.kdim && a.b2 == nullptr))
-      return MD_ERR_UNSUPPORTED;
+  if (a.b_mode != MD_B_S16B) {
+    if (a.b_mode != MD_B_F32B_GN || (a.b_split & 7) || a.b_split <= 0 || (a.b_split < a.kdim && a.b2 == nullptr)) return MD_ERR_UNSUPPORTED;
+    if (C::TAPS == 1) {          // fp32 operand: split-only, 1x1x1 configurations whose tile is a whole number of pairs per thread
+      if ((C::A_PER_THREAD % 2) || (C::A_ITEMS % (2 * C::NTHREADS)) || a.b_ac != nullptr) return MD_ERR_UNSUPPORTED;
+    } else {                     // conv configurations built with BF: GroupNorm affine (+ SiLU) + split in the halo loader
+      if (!C::BF || a.ups) return MD_ERR_UNSUPPORTED;
+      if (a.b_silu && a.b_ac == nullptr) return MD_ERR_BAD_ARG;
+    }
   }
   const int row_tiles = (a.rows + C::NT - 1) / C::NT;
   const int ks = a.ksplit > 1 ? a.ksplit : 1;

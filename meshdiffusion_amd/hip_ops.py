@@ -384,8 +384,14 @@ CONV3_S2 = os.environ.get("MD_CONV3_S2", "1") == "1"   # A/B switch: 0 = md_gn_a
 CFG_S2_PACK = CFG_C3_128_K16                           # tile geometry of its packed weights: nt = 128, kc = 16, 27 taps
 
 
-def conv3_s2_ok(rows, kdim, S_out):
-    return CONV3_S2 and PRECISION == "bf16x3" and kdim % 32 == 0 and rows % 8 == 0 and S_out % 8 == 0
+S2_MIN_WGS = int(os.environ.get("MD_S2_MIN_WGS", "100"))   # no split-K in md_conv3_s2: below this the generic tile (split-K) is faster
+
+
+def conv3_s2_ok(rows, kdim, S_out, B=None):
+    """Shapes md_conv3_s2 takes; with `B`: and is launched with enough workgroups for (measured, B = 8: 16^3 outputs 0.16 ms
+    against 0.20 + the split pass; 8^3 outputs = 32 workgroups 0.25 against 0.10)."""
+    ok = CONV3_S2 and PRECISION == "bf16x3" and kdim % 32 == 0 and rows % 8 == 0 and S_out % 8 == 0
+    return ok and (B is None or B * (S_out ** 3 // 256) * ((rows + 127) // 128) >= S2_MIN_WGS)
 
 
 def conv3_s2(pw, x, B, S_out, *, bias=None, bias_bstride=0, stats=None, out=None):

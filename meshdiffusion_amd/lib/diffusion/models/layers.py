@@ -117,8 +117,8 @@ def conv3_wino_packed(layer, name, conv):
 
 def fused_operand_ok(pw):
     """True when a conv on packed weights `pw` can take its input as fp32 F32B parts and apply GroupNorm + SiLU + the
-    bf16 split itself (MD_B_F32B_GN: dedicated kernel, bf16x3 arithmetic)."""
-    return ops.FUSE_GN_APPLY and pw.cfg == ops.CFG_C3_128_FAST and pw.prec == ops.PREC_BF16X3
+    bf16 split itself (MD_B_F32B_GN: the dedicated kernel, or the 4^3-level tile of the generic kernel; bf16x3 arithmetic)."""
+    return ops.FUSE_GN_APPLY and pw.cfg in (ops.CFG_C3_128_FAST, ops.CFG_C3_LOW) and pw.prec == ops.PREC_BF16X3
 
 
 def run_conv3(pw, act_s16, B, S_out, *, bias=None, bias_bstride=0, residual=None, res_bstride=None, ups=0,
@@ -333,7 +333,7 @@ class Downsample(HipLayer):
 
     def forward_blocked(self, x, Cc, B, P, tape=None):
         s_out = _spatial_edge(P) // 2
-        if tape is None and ops.conv3_s2_ok(self.Conv_0.weight.shape[0], Cc, s_out):
+        if tape is None and ops.conv3_s2_ok(self.Conv_0.weight.shape[0], Cc, s_out, B):
             # inference: one kernel on the raw fp32 tensor (no split pass), GroupNorm sums of the output from its epilogue
             pw = self._cached("w/s2", [self.Conv_0.weight],
                               lambda: ops.PackedWeight(self.Conv_0.weight, "conv", ops.CFG_S2_PACK, self.Conv_0.weight.device))

@@ -405,6 +405,38 @@ def test_conv3_fused_groupnorm_silu_operand(ops, case):
         assert e2 == 0.0          # no transcendental involved: the in-loader split is the same arithmetic
 
 
+@pytest.mark.parametrize("case", ["low_4cubed_two_parts_splitk", "low_4cubed_gn_no_silu"])
+def test_generic_conv_fused_groupnorm_silu_operand(ops, case):
+    """MD_B_F32B_GN on the generic conv configuration built with BF (csrc/gemm_conv.hip: the 4^3 level MD_CFG_C3_LOW):
+    GroupNorm affine + SiLU + zero padding + split in the halo loader, against torch fp32 and against the two-pass path
+    (md_gn_apply + the same configuration on S16B)."""
+    B, cs, rows, S, cfg, kshape, ks = 3, ([64, 32] if "two_parts" in case else [64]), 128, 4, ops.CFG_C3_LOW, (3, 3, 3), (2 if "splitk" in case else 1)
+    cin = sum(cs)
+    P = S ** 3
+    xs = [_rand((B, c, S, S, S), 40 + i) * (1.0 + i) + 0.3 * i for i, c in enumerate(cs)]
+    x = torch.cat(xs, 1)
+    gamma, beta = 1.0 + 0.2 * _rand((cin,), 41), 0.5 * _rand((cin,), 42)
+    w = _rand((rows, cin) + kshape, 43, 0.05)
+    bias = _rand((rows,), 44)
+    silu = "no_silu" not in case
+    parts = [(ops.ncdhw_to_f32b(t.cuda()), c) for t, c in zip(xs, cs)]
+    prm, ac = ops.gn_params(parts, gamma.cuda(), beta.cuda(), B, P, want_ac=True)
+    pw = ops.PackedWeight(w.cuda(), "conv", cfg, "cuda")
+    rows_alloc = ((rows + 7) // 8) * 8
+    kw = dict(cfg=cfg, a=pw.data, batch=B, rows=rows, rows_alloc=rows_alloc, kdim=cin, dims=(S, S, S), bias=bias.cuda(), ksplit=ks)
+    out = ops.gemm_conv(b=None, out=ops.f32b_empty(B, rows_alloc, P, "cuda"), b_f32=dict(parts=parts, ac=ac, silu=silu), **kw)
+    y = ops.f32b_to_ncdhw(out, (S, S, S)).cpu()[:, :rows]
+    ref_in = F.group_norm(x, 32, gamma, beta, eps=1e-6)
+    ref_in = F.silu(ref_in) if silu else ref_in
+    ref = F.conv3d(ref_in, w, bias, padding=(1, 1, 0) if kshape[2] == 1 else 1)
+    e = rel_l2(y, ref)
+    a16 = ops.gn_apply(parts, prm, B, P, norm=True, silu=silu)
+    out2 = ops.gemm_conv(b=a16, out=ops.f32b_empty(B, rows_alloc, P, "cuda"), **kw)
+    e2 = rel_l2(y, ops.f32b_to_ncdhw(out2, (S, S, S)).cpu()[:, :rows])
+    print(f"generic fused operand ({case}): vs torch fp32 {e:.2e}, vs two-pass HIP path {e2:.2e}")
+    assert e < TOL_MFMA and e2 < TOL_MFMA
+
+
 def test_gn_finalize_folded_affine(ops):
     B, Cc, S = 2, 64, 4
     x = _rand((B, Cc, S, S, S), 30) * 2.0 + 1.5

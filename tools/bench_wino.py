@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--f43", action="store_true", help="also time the experimental F(4,3) kernels (md_wino43_*)")
     ap.add_argument("--no-stats", action="store_true", help="launch without the GroupNorm-sum epilogue")
     ap.add_argument("--no-res", action="store_true", help="launch without the residual operand")
+    ap.add_argument("--stamps", action="store_true", help="variant 128 (MD_BUILD_ABLATIONS=1): per-wave s_memtime stamps of the first 1024 workgroups")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     rows = []
@@ -89,6 +90,39 @@ def main():
             rows.append(dict(shape=sh, kernel="md_conv3_wino", variant=v, what=VARIANTS.get(v, "?"), ms=round(ms, 4),
                              tflops_alg=round(flops / ms / 1e9, 1), issued_frac_of_peak=round(flops * 2 / 3 * 3 / ms / 1e9 / 2500.0, 4)))
             print(json.dumps(rows[-1]), flush=True)
+        if a.stamps:
+            dbg = torch.zeros((1024, 4, 10), dtype=torch.int64, device=dev)
+            for _ in range(2):
+                ops.conv3_wino(ww, t, B, S, bias=bias, bias_bstride=cout, residual=None if a.no_res else res,
+                               res_bstride=0 if a.no_res else cout * S ** 3, stats=dbg, out=out, variant=128)
+            torch.cuda.synchronize()
+            st = dbg.cpu().double()
+            st = st[st[:, 0, 0] > 0]
+            tt = st[:, :, :9]
+            names = ["start->first fragments (prologue)", "main loop", "loop end->barrier (wait for the slowest wave)",
+                     "round 0", "round 1", "round 2", "round 3", "after the last round"]
+            d = tt[:, :, 1:] - tt[:, :, :-1]
+            wg = tt[:, :, 8].max(1).values - tt[:, :, 0].min(1).values
+            # s_memtime ticks: report raw and relative to the workgroup's whole duration
+            rep = dict(shape=sh, kernel="md_conv3_wino stamps", n_wg=int(st.shape[0]), wg_ticks_mean=round(float(wg.mean()), 1),
+                       phases={n: round(float(d[:, :, k].mean()), 1) for k, n in enumerate(names)},
+                       phases_frac={n: round(float(d[:, :, k].mean() / wg.mean()), 4) for k, n in enumerate(names)},
+                       loop_end_skew_ticks=round(float((tt[:, :, 2].max(1).values - tt[:, :, 2].min(1).values).mean()), 1),
+                       first_gen_start_spread=round(float(tt[:256, :, 0].max() - tt[:256, :, 0].min()), 1))
+            # second generation: gap between a workgroup's end and the next start on the same CU (hw id + xcc id)
+            ids = dbg.cpu()[:, 0, 9][: st.shape[0]]
+            cu = {}
+            for i in range(st.shape[0]):
+                cu.setdefault(int(ids[i]) & ~0xF, []).append((float(tt[i, :, 0].min()), float(tt[i, :, 8].max())))
+            gaps = []
+            for v in cu.values():
+                v.sort()
+                gaps += [v[k + 1][0] - v[k][1] for k in range(len(v) - 1)]
+            if gaps:
+                rep["gap_between_workgroups_on_a_cu_ticks"] = round(sum(gaps) / len(gaps), 1)
+                rep["n_cu_ids"] = len(cu)
+            rows.append(rep)
+            print(json.dumps(rep), flush=True)
     if a.out:
         with open(a.out, "w") as f:
             json.dump(rows, f, indent=1)
