@@ -282,6 +282,23 @@ int md_conv3_wino(const void* t_in, const void* wpk, float* out, const float* bi
                   int32_t D, int32_t H, int32_t W, int32_t variant, void* stream);
 
 /*
+ * md_pack_batch: several md_pack_weights / md_wino_pack_weights jobs in one launch (csrc/pack_batch.hip; a training step
+ * re-packs every weight once: ~260 launches otherwise).  Bit-identical to the single-weight entry points.
+ *   jobs_dev     : DEVICE array of n_jobs MdPackJob, sorted by block0; job j owns blocks [block0, block0 + ceil(n_items / 256))
+ *   total_blocks : sum over jobs of ceil(n_items / 256)
+ * kind MD_PACK_WPK : fields as the arguments of md_pack_weights (n_items = md_packed_weight_bytes / 16)
+ * kind MD_PACK_WINO: rows = cout, kdim = cin, s_row, s_k, flip as md_wino_pack_weights (n_items = md_wino_weight_bytes / 16)
+ */
+enum { MD_PACK_WPK = 0, MD_PACK_WINO = 1 };
+typedef struct MdPackJob {
+  const float* w;
+  void* out;
+  int64_t s_row, s_k, s_tap, n_items, block0;
+  int32_t rows, kdim, taps, nt, kc, prec, flip, kind;
+} MdPackJob;
+int md_pack_batch(const MdPackJob* jobs_dev, int32_t n_jobs, int64_t total_blocks, void* stream);
+
+/*
  * md_conv3_s2: the stride-2 3x3x3 convolution of Downsample (layers.py:626-643: F.pad(x, (0, 1, 0, 1, 0, 1)) +
  * nn.Conv3d(C, C, 3, stride=2, padding=0)) for inference, reading the raw fp32 tensor (csrc/conv3_s2.hip): replaces the
  * split pass md_gn_apply(norm = 0) + md_gemm_conv(MD_CFG_C3_S2).  bf16x3 products, fp32 accumulation.

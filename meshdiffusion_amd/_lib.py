@@ -41,6 +41,15 @@ class MdGemmConvArgs(C.Structure):
     ]
 
 
+class MdPackJob(C.Structure):
+    _fields_ = [
+        ("w", C.c_void_p), ("out", C.c_void_p), ("s_row", C.c_int64), ("s_k", C.c_int64), ("s_tap", C.c_int64),
+        ("n_items", C.c_int64), ("block0", C.c_int64), ("rows", C.c_int32), ("kdim", C.c_int32), ("taps", C.c_int32),
+        ("nt", C.c_int32), ("kc", C.c_int32), ("prec", C.c_int32), ("flip", C.c_int32), ("kind", C.c_int32),
+    ]
+
+
+PACK_WPK, PACK_WINO = 0, 1
 ABI_VERSION = 10     # MD_ABI_VERSION of include/meshdiffusion_hip.h this host code was written against
 _P, _I32, _I64, _F, _U64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint64
 
@@ -72,6 +81,7 @@ SIGNATURES = {
     "md_wino_weight_bytes": (_I64, [_I32, _I32]),
     "md_wino_pack_weights": (C.c_int, [_P, _P, _I32, _I32, _I64, _I64, _I32, _P]),
     "md_conv3_wino": (C.c_int, [_P, _P, _P, _P, _I64, _P, _I64, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P]),
+    "md_pack_batch": (C.c_int, [_P, _I32, _I64, _P]),
     "md_conv3_s2": (C.c_int, [_P, _P, _P, _P, _I64, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P]),
     "md_wino_prep_v2": (C.c_int, [_P, _P, _I32, _I32, _P, _I32, _I32, _P, _I32, _I32, _I32, _I32, _F, _U64, _P]),
     "md_wino_prep_dual": (C.c_int, [_P, _P, _I32, _I32, _P, _I32, _I32, _P, _P, _P, _I32, _I32, _I32, _I32, _F, _U64, _P]),

@@ -14,7 +14,7 @@ INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 OBJDIR = os.path.join(CSRC, "build")
 LIB_PATH = os.path.join(HERE, "libmeshdiffusion_hip.so")
 ARCH = "gfx950"
-SOURCES = ["capi.hip", "gemm_conv.hip", "conv3_main.hip", "conv3_wino.hip", "conv3_s2.hip", "wino_prep2.hip", "norm.hip", "elementwise.hip", "attention.hip", "nin_stream.hip", "train.hip", "backward.hip", "wgrad.hip", "wgrad_wino.hip", "dmtet.hip"]
+SOURCES = ["capi.hip", "gemm_conv.hip", "conv3_main.hip", "conv3_wino.hip", "conv3_s2.hip", "pack_batch.hip", "wino_prep2.hip", "norm.hip", "elementwise.hip", "attention.hip", "nin_stream.hip", "train.hip", "backward.hip", "wgrad.hip", "wgrad_wino.hip", "dmtet.hip"]
 # default-off experiments (MD_BUILD_EXPERIMENTAL=1): declared in include/meshdiffusion_hip_experimental.h, bound lazily by _lib.py
 EXPERIMENTAL_SOURCES = ["experimental/conv3_wino43.hip"]
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", f"-I{INCLUDE}", f"-I{CSRC}",
@@ -43,7 +43,7 @@ def build(verbose=False, force=False):
     from concurrent.futures import ThreadPoolExecutor
     hipcc = _hipcc()
     os.makedirs(OBJDIR, exist_ok=True)
-    headers = [os.path.join(CSRC, "md_common.h"), os.path.join(INCLUDE, "meshdiffusion_hip.h")]
+    headers = [os.path.join(CSRC, "md_common.h"), os.path.join(CSRC, "md_pack.h"), os.path.join(INCLUDE, "meshdiffusion_hip.h")]
     flags = FLAGS + (["-DMD_BUILD_ABLATIONS"] if os.environ.get("MD_BUILD_ABLATIONS") == "1" else [])
     experimental = os.environ.get("MD_BUILD_EXPERIMENTAL") == "1"
     flags = flags + (["-DMD_BUILD_EXPERIMENTAL"] if experimental else [])

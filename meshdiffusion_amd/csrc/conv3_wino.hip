@@ -25,6 +25,7 @@
 //                        Only the epilogue meets: accumulators cross through LDS (m0..m3 of a pair live in 4 waves),
 //                        y0 / y1 + bias + residual + GroupNorm sums as in md_conv3_main_kernel.
 #include "md_common.h"
+#include "md_pack.h"
 
 namespace {
 constexpr int WN_THREADS = 256;
@@ -135,37 +136,7 @@ __global__ __launch_bounds__(256) void md_wino_pack_weights_kernel(const float* 
   const int64_t n = (int64_t)cout * cin * 36 / 4;        // items: cout * cin * 36 values * 2 planes / 8
   const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (id >= n) return;
-  int64_t r = id;
-  const int row = (int)(r % 32); r /= 32;
-  const int h = (int)(r % 2); r /= 2;
-  const int plane = (int)(r % 2); r /= 2;
-  const int rtile = (int)(r % 4); r /= 4;
-  const int f = (int)(r % 4); r /= 4;
-  const int tap = (int)(r % 9); r /= 9;
-  const int nchunk = cin / 16;
-  const int chunk = (int)(r % nchunk); r /= nchunk;
-  const int ct = (int)r;
-  const int co = (ct * 4 + rtile) * 32 + row;
-  uint32_t word[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    uint32_t half[2];
-#pragma unroll
-    for (int e2 = 0; e2 < 2; ++e2) {
-      const int ci = chunk * 16 + h * 8 + 2 * q + e2;
-      // element (row, k, kd, kh, kw) of the convolution being packed = w[row * s_row + k * s_k + t27], t27 = (kd*3+kh)*3+kw,
-      // or 26 - t27 when `flip` (data gradient: W'[ci][co][t] = W[co][ci][26 - t], read in place)
-      const float* g = w + (int64_t)co * s_row + (int64_t)ci * s_k;
-      const int t0 = tap * 3;
-      const float g0 = g[flip ? 26 - t0 : t0], g1 = g[flip ? 25 - t0 : t0 + 1], g2 = g[flip ? 24 - t0 : t0 + 2];
-      const float G = f == 0 ? g0 : f == 1 ? (g0 + g1 + g2) * 0.5f : f == 2 ? (g0 - g1 + g2) * 0.5f : g2;
-      uint32_t hi, lo;
-      md_split(G, hi, lo);
-      half[e2] = plane ? lo : hi;
-    }
-    word[q] = half[0] | (half[1] << 16);
-  }
-  wpk[id] = make_uint4(word[0], word[1], word[2], word[3]);
+  wpk[id] = md_pack_wino_item(w, cout, cin, s_row, s_k, flip, id);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -320,6 +291,8 @@ __global__ __launch_bounds__(WN_THREADS) void md_conv3_wino_kernel(const WnArgs 
       if constexpr (!(ABL & 4)) load_A(sw, Ar[(u + 2) % 3]);
       if (tap < 8) read_B(tap + 1, cpar, Bn, false);
       else read_B(0, cpar ^ 1, Bn, false);
+      // (MFMA order inside a step measured neutral, profiles/r03_wino_epilogue_ab.txt: column-tile-major passes, and the three
+      // products of a tile adjacent -- the kernel is power-limited, issue order does not change the energy)
 #pragma unroll
       for (int m = 0; m < 16; ++m) WN_MFMA(0, m, Aw, Bc);
 #pragma unroll

@@ -18,6 +18,7 @@
 //   8q + 4*(lane>>5) + {0..3}: four consecutive output channels of one position,
 //   i.e. one 16-byte store into the 8-channel blocked F32B layout.
 #include "md_common.h"
+#include "md_pack.h"
 
 template <int NT_, int KC_, int TZ_, int TY_, int TX_, int TAPS_, int STRIDE_, int WR_, int WC_,
           int SW_ = 0, int PIPE_ = 0, int ABL_ = 0, int BF_ = 0>
@@ -708,31 +709,9 @@ extern "C" int md_gemm_conv_cfg_info(int32_t cfg, int32_t* nt, int32_t* kc, int3
 __global__ void md_pack_weights_kernel(const float* __restrict__ w, uint4* __restrict__ out,
                                        int rows, int kdim, int taps, int64_t s_row, int64_t s_k,
                                        int64_t s_tap, int nt, int kc, int64_t n_items, int prec) {
-  const int kg = kc / 8;
-  const int ncc = (kdim + kc - 1) / kc;
   for (int64_t item = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; item < n_items;
-       item += (int64_t)gridDim.x * blockDim.x) {
-    int64_t r = item;
-    const int rr = (int)(r % nt); r /= nt;
-    const int part = (int)(r % 2); r /= 2;
-    const int g = (int)(r % kg); r /= kg;
-    const int tap = (int)(r % taps); r /= taps;
-    const int cc = (int)(r % ncc); r /= ncc;
-    const int rt = (int)r;
-    const int row = rt * nt + rr;
-    uint32_t v[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int k = cc * kc + g * 8 + e;
-      float x = 0.f;
-      if (row < rows && k < kdim) x = w[row * s_row + k * s_k + tap * s_tap];
-      uint32_t hi, lo;
-      if (prec == MD_PREC_FP16X2) md_split_f16(x, hi, lo); else md_split(x, hi, lo);
-      v[e] = part ? lo : hi;
-    }
-    out[item] = make_uint4(v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16),
-                           v[6] | (v[7] << 16));
-  }
+       item += (int64_t)gridDim.x * blockDim.x)
+    out[item] = md_pack_wpk_item(w, rows, kdim, taps, s_row, s_k, s_tap, nt, kc, prec, item);
 }
 
 extern "C" int64_t md_packed_weight_bytes(int32_t rows, int32_t kdim, int32_t taps, int32_t nt,

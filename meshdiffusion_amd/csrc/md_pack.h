@@ -1,0 +1,67 @@
+// Per-item bodies of the two weight-packing kernels, shared by the single-weight launches (md_pack_weights in gemm_conv.hip,
+// md_wino_pack_weights in conv3_wino.hip) and the batched launch md_pack_batch (pack_batch.hip): same arithmetic, same bits.
+#pragma once
+#include "md_common.h"
+
+// WPK tiles [rows/NT][K/KC][taps][KC/8][2][NT][8]: item = 16 bytes = 8 consecutive k of one row, one plane
+__device__ __forceinline__ uint4 md_pack_wpk_item(const float* __restrict__ w, int rows, int kdim, int taps, int64_t s_row, int64_t s_k,
+                                                  int64_t s_tap, int nt, int kc, int prec, int64_t item) {
+  const int kg = kc / 8;
+  const int ncc = (kdim + kc - 1) / kc;
+  int64_t r = item;
+  const int rr = (int)(r % nt); r /= nt;
+  const int part = (int)(r % 2); r /= 2;
+  const int g = (int)(r % kg); r /= kg;
+  const int tap = (int)(r % taps); r /= taps;
+  const int cc = (int)(r % ncc); r /= ncc;
+  const int rt = (int)r;
+  const int row = rt * nt + rr;
+  uint32_t v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int k = cc * kc + g * 8 + e;
+    float x = 0.f;
+    if (row < rows && k < kdim) x = w[row * s_row + k * s_k + tap * s_tap];
+    uint32_t hi, lo;
+    if (prec == MD_PREC_FP16X2) md_split_f16(x, hi, lo); else md_split(x, hi, lo);
+    v[e] = part ? lo : hi;
+  }
+  return make_uint4(v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16));
+}
+
+// Winograd F(2,3) weight fragments [cout/128][cin/16][tap (kd,kh) 9][f 4][row tile 4][plane 2][h 2][row 32][8 bf16]
+__device__ __forceinline__ uint4 md_pack_wino_item(const float* __restrict__ w, int cout, int cin, int64_t s_row, int64_t s_k, int flip,
+                                                   int64_t id) {
+  int64_t r = id;
+  const int row = (int)(r % 32); r /= 32;
+  const int h = (int)(r % 2); r /= 2;
+  const int plane = (int)(r % 2); r /= 2;
+  const int rtile = (int)(r % 4); r /= 4;
+  const int f = (int)(r % 4); r /= 4;
+  const int tap = (int)(r % 9); r /= 9;
+  const int nchunk = cin / 16;
+  const int chunk = (int)(r % nchunk); r /= nchunk;
+  const int ct = (int)r;
+  const int co = (ct * 4 + rtile) * 32 + row;
+  uint32_t word[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    uint32_t half[2];
+#pragma unroll
+    for (int e2 = 0; e2 < 2; ++e2) {
+      const int ci = chunk * 16 + h * 8 + 2 * q + e2;
+      // element (row, k, kd, kh, kw) of the convolution being packed = w[row * s_row + k * s_k + t27], t27 = (kd*3+kh)*3+kw,
+      // or 26 - t27 when `flip` (data gradient: W'[ci][co][t] = W[co][ci][26 - t], read in place)
+      const float* g = w + (int64_t)co * s_row + (int64_t)ci * s_k;
+      const int t0 = tap * 3;
+      const float g0 = g[flip ? 26 - t0 : t0], g1 = g[flip ? 25 - t0 : t0 + 1], g2 = g[flip ? 24 - t0 : t0 + 2];
+      const float G = f == 0 ? g0 : f == 1 ? (g0 + g1 + g2) * 0.5f : f == 2 ? (g0 - g1 + g2) * 0.5f : g2;
+      uint32_t hi, lo;
+      md_split(G, hi, lo);
+      half[e2] = plane ? lo : hi;
+    }
+    word[q] = half[0] | (half[1] << 16);
+  }
+  (void)cout;
+  return make_uint4(word[0], word[1], word[2], word[3]);
+}

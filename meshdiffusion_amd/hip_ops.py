@@ -119,21 +119,103 @@ class PackedWeight:
         self.kdim = ((kdim + kc - 1) // kc) * kc  # K padded to the chunk size (zero filled)
         self._src = (w, rows, kdim, taps, s_row, s_k, s_tap, nt, kc, base_off)   # `w` is this weight version (cache key)
         self._data = None
+        self._queued = False
 
-    @property
-    def data(self):
-        if self._data is None:
+    def request(self):
+        """Queue the packing job (no launch): the next `.data` access of ANY queued weight, or flush_packs(), packs all of
+        them in one md_pack_batch launch."""
+        if self._data is None and not self._queued:
             lib = _lib.load()
             w, rows, kdim, taps, s_row, s_k, s_tap, nt, kc, base_off = self._src
             nbytes = lib.md_packed_weight_bytes(rows, kdim, taps, nt, kc)
             if nbytes <= 0:
                 raise _lib.MeshDiffusionHipError("md_packed_weight_bytes failed")
-            self._data = torch.empty(nbytes // 2, dtype=torch.bfloat16, device=w.device)
-            wp = C.c_void_p(w.data_ptr() + 4 * base_off)
-            check(lib.md_pack_weights(wp, _ptr(self._data), rows, kdim, taps, s_row, s_k, s_tap, nt, kc,
-                                      self.prec, _stream()), "md_pack_weights")
-            self._src = None
+            self._queued = True
+            _PACK_QUEUE.append((self, dict(kind=_lib.PACK_WPK, w=w, w_off=4 * base_off, nbytes=nbytes, rows=rows, kdim=kdim, taps=taps,
+                                           s_row=s_row, s_k=s_k, s_tap=s_tap, nt=nt, kc=kc, prec=self.prec, flip=0)))
+
+    @property
+    def data(self):
+        if self._data is None:
+            self.request()
+            flush_packs()
         return self._data
+
+
+_PACK_QUEUE = []      # (owner, job) pairs waiting for flush_packs()
+PACK_BATCH = os.environ.get("MD_PACK_BATCH", "1") == "1"   # A/B switch: 0 = one md_pack_weights / md_wino_pack_weights launch per weight
+
+
+def flush_packs():
+    """Pack every queued weight: one md_pack_batch launch (PACK_BATCH) or one launch per weight."""
+    global _PACK_QUEUE
+    if not _PACK_QUEUE:
+        return
+    queue, _PACK_QUEUE = _PACK_QUEUE, []
+    lib = _lib.load()
+    outs = []
+    for owner, j in queue:
+        outs.append(torch.empty(j["nbytes"] // 2, dtype=torch.bfloat16, device=j["w"].device))
+    if PACK_BATCH and len(queue) > 1 and len({j["w"].device for _, j in queue}) == 1:
+        jobs = (_lib.MdPackJob * len(queue))()
+        block0 = 0
+        for i, ((owner, j), out) in enumerate(zip(queue, outs)):
+            J = jobs[i]
+            J.w, J.out = j["w"].data_ptr() + j["w_off"], out.data_ptr()
+            J.s_row, J.s_k, J.s_tap = j["s_row"], j["s_k"], j["s_tap"]
+            J.n_items, J.block0 = j["nbytes"] // 16, block0
+            J.rows, J.kdim, J.taps, J.nt, J.kc, J.prec, J.flip, J.kind = (j["rows"], j["kdim"], j["taps"], j["nt"], j["kc"],
+                                                                         j["prec"], j["flip"], j["kind"])
+            block0 += (J.n_items + 255) // 256
+        table = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).to(outs[0].device)
+        check(lib.md_pack_batch(_ptr(table), len(queue), block0, _stream()), "md_pack_batch")
+        table.record_stream(torch.cuda.current_stream(outs[0].device))
+    else:
+        for (owner, j), out in zip(queue, outs):
+            wp = C.c_void_p(j["w"].data_ptr() + j["w_off"])
+            if j["kind"] == _lib.PACK_WPK:
+                check(lib.md_pack_weights(wp, _ptr(out), j["rows"], j["kdim"], j["taps"], j["s_row"], j["s_k"], j["s_tap"], j["nt"],
+                                          j["kc"], j["prec"], _stream()), "md_pack_weights")
+            else:
+                check(lib.md_wino_pack_weights(wp, _ptr(out), j["rows"], j["kdim"], j["s_row"], j["s_k"], j["flip"], _stream()),
+                      "md_wino_pack_weights")
+    for (owner, j), out in zip(queue, outs):
+        owner._data = out
+        owner._src = None
+        owner._queued = False
+
+
+# Sites of the packed-weight caches (layers.HipLayer._cached) that were used since the last prewarm: a training step changes
+# every weight, so the forward of the next step would rebuild each cache entry at its first use -- one packing launch per
+# weight.  prewarm_packs() (start of a training forward) rebuilds the entries the previous step used, queues their packing
+# jobs and flushes them as ONE md_pack_batch launch.
+_PACK_SITES = {}
+
+
+def note_pack_use(layer, name, params, builder):
+    import weakref
+    key = (id(layer), name)
+    if key not in _PACK_SITES:
+        _PACK_SITES[key] = (weakref.ref(layer), name, list(params), builder)
+
+
+def prewarm_packs():
+    global _PACK_SITES
+    if not PACK_BATCH:
+        _PACK_SITES = {}
+        return 0
+    sites, _PACK_SITES = _PACK_SITES, {}
+    n = 0
+    for ref, name, params, builder in sites.values():
+        layer = ref()
+        if layer is None:
+            continue
+        obj = layer._cached(name, params, builder, mark=False)
+        if hasattr(obj, "request"):
+            obj.request()
+            n += 1
+    flush_packs()
+    return n
 
 
 def pack_s16b_from_matrix(w_kp, device):
@@ -246,9 +328,22 @@ class WinoWeight:
         nbytes = lib.md_wino_weight_bytes(self.rows, self.kdim)
         if nbytes <= 0:
             raise _lib.MeshDiffusionHipError("md_wino_weight_bytes: unsupported weight shape")
-        self.data = torch.empty(nbytes // 2, dtype=torch.bfloat16, device=device)
-        check(lib.md_wino_pack_weights(_ptr(w), _ptr(self.data), self.rows, self.kdim, s_row, s_k, flip, _stream()),
-              "md_wino_pack_weights")
+        self._data, self._queued = None, False
+        self._src = dict(kind=_lib.PACK_WINO, w=w, w_off=0, nbytes=nbytes, rows=self.rows, kdim=self.kdim, taps=9, s_row=s_row,
+                         s_k=s_k, s_tap=0, nt=0, kc=0, prec=PREC_BF16X3, flip=flip)
+
+    def request(self):
+        """Queue the packing job (see PackedWeight.request)."""
+        if self._data is None and not self._queued:
+            self._queued = True
+            _PACK_QUEUE.append((self, self._src))
+
+    @property
+    def data(self):
+        if self._data is None:
+            self.request()
+            flush_packs()
+        return self._data
 
 
 WINO_MIN_WGS = int(os.environ.get("MD_WINO_MIN_WGS", "256"))   # fewest workgroups the Winograd kernel is launched with

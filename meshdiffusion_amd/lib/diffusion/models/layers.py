@@ -81,13 +81,15 @@ class HipLayer(nn.Module):
     """Caches device-side packed weights; rebuilt when a parameter is modified in place,
     re-assigned or moved (key = data_ptr + version counter)."""
 
-    def _cached(self, name, params, builder):
+    def _cached(self, name, params, builder, mark=True):
         cache = self.__dict__.setdefault("_md_cache", {})
         key = (ops.PARAM_EPOCH,) + tuple((p.data_ptr(), p._version, str(p.device)) for p in params)
         hit = cache.get(name)
         if hit is None or hit[0] != key:
             hit = (key, builder())
             cache[name] = hit
+        if mark:
+            ops.note_pack_use(self, name, params, builder)     # hip_ops.prewarm_packs: rebuilt in one batch before the next training forward
         return hit[1]
 
 
@@ -333,14 +335,16 @@ class Downsample(HipLayer):
 
     def forward_blocked(self, x, Cc, B, P, tape=None):
         s_out = _spatial_edge(P) // 2
-        if tape is None and ops.conv3_s2_ok(self.Conv_0.weight.shape[0], Cc, s_out, B):
-            # inference: one kernel on the raw fp32 tensor (no split pass), GroupNorm sums of the output from its epilogue
+        if ops.conv3_s2_ok(self.Conv_0.weight.shape[0], Cc, s_out, B):
+            # one kernel on the raw fp32 tensor (inference: no split pass at all), GroupNorm sums of the output from its epilogue
             pw = self._cached("w/s2", [self.Conv_0.weight],
                               lambda: ops.PackedWeight(self.Conv_0.weight, "conv", ops.CFG_S2_PACK, self.Conv_0.weight.device))
             stats = torch.zeros((B, pw.rows, 2), dtype=torch.float64, device=x.device) if ops.FUSE_GN_STATS and pw.rows % 8 == 0 else None
             out = ops.conv3_s2(pw, x, B, s_out, bias=self.Conv_0.bias, stats=stats)
             if stats is not None:
                 out._md_sums = stats
+            if tape is not None:     # training: the weight gradient reads the split operand (md_to_pb16 <- S16B)
+                tape.append(dict(layer=self, act=ops.gn_apply([(x, Cc)], None, B, P, norm=False, silu=False), B=B, S_out=s_out))
             return out
         act = ops.gn_apply([(x, Cc)], None, B, P, norm=False, silu=False)
         pw = conv3_packed(self, "w", self.Conv_0, ops.conv_cfg_for(s_out, stride=2))

@@ -437,6 +437,36 @@ def test_generic_conv_fused_groupnorm_silu_operand(ops, case):
     assert e < TOL_MFMA and e2 < TOL_MFMA
 
 
+def test_pack_batch_bit_identical_to_single_launches(ops):
+    """md_pack_batch (csrc/pack_batch.hip: all queued weight packs of a training step in one launch) writes the same tiles,
+    bit for bit, as md_pack_weights / md_wino_pack_weights one weight at a time: conv / data-gradient / NIN / rows kinds,
+    several tile geometries, Winograd fragments forward and flipped, a partial row tile and a padded K."""
+    w1, w2, w3 = _rand((128, 64, 3, 3, 3), 80, 0.05).cuda(), _rand((136, 96, 3, 3, 3), 81, 0.05).cuda(), _rand((256, 128, 3, 3, 3), 82, 0.05).cuda()
+    m1, m2 = _rand((96, 128), 83).cuda(), _rand((40, 72), 84).cuda()
+
+    def make():
+        return [ops.PackedWeight(w1, "conv", ops.CFG_C3_128_FAST, "cuda"), ops.PackedWeight(w2, "conv_dgrad", ops.CFG_C3_LOW, "cuda"),
+                ops.PackedWeight(w2, "conv", ops.CFG_S2_PACK, "cuda"), ops.PackedWeight(m1, "nin", ops.CFG_G1_128, "cuda"),
+                ops.PackedWeight(m2, "rows", ops.CFG_G1_64_LOW, "cuda"), ops.WinoWeight(w3, "cuda"),
+                ops.WinoWeight(w3, "cuda", kind="conv_dgrad"), ops.WinoWeight(w1, "cuda")]
+
+    assert ops.PACK_BATCH
+    batch = make()
+    for o in batch:
+        o.request()
+    ops.flush_packs()
+    assert all(o._data is not None for o in batch)
+    ops.PACK_BATCH = False
+    try:
+        single = make()
+        for o in single:
+            _ = o.data
+    finally:
+        ops.PACK_BATCH = True
+    for a, b in zip(batch, single):
+        assert a.data.numel() == b.data.numel() and torch.equal(a.data.view(torch.int16), b.data.view(torch.int16))
+
+
 def test_gn_finalize_folded_affine(ops):
     B, Cc, S = 2, 64, 4
     x = _rand((B, Cc, S, S, S), 30) * 2.0 + 1.5
