@@ -284,10 +284,18 @@ int md_conv3_wino(const void* t_in, const void* wpk, float* out, const float* bi
 /*
  * md_pack_batch: several md_pack_weights / md_wino_pack_weights jobs in one launch (csrc/pack_batch.hip; a training step
  * re-packs every weight once: ~260 launches otherwise).  Bit-identical to the single-weight entry points.
- *   jobs_dev     : DEVICE array of n_jobs MdPackJob, sorted by block0; job j owns blocks [block0, block0 + ceil(n_items / 256))
- *   total_blocks : sum over jobs of ceil(n_items / 256)
- * kind MD_PACK_WPK : fields as the arguments of md_pack_weights (n_items = md_packed_weight_bytes / 16)
- * kind MD_PACK_WINO: rows = cout, kdim = cin, s_row, s_k, flip as md_wino_pack_weights (n_items = md_wino_weight_bytes / 16)
+ *   jobs_dev     : DEVICE array of n_jobs MdPackJob, sorted by block0; job j owns the blocks from block0 on
+ *   total_blocks : sum over jobs of their block counts
+ *   tiled = 0    : one 16-byte item per thread; a job has ceil(n_items / 256) blocks
+ *     kind MD_PACK_WPK : fields as the arguments of md_pack_weights (n_items = md_packed_weight_bytes / 16)
+ *     kind MD_PACK_WINO: rows = cout, kdim = cin, s_row, s_k, flip as md_wino_pack_weights (n_items = md_wino_weight_bytes / 16)
+ *   tiled = 1    : MD_PACK_WPK jobs only, taps > 1 with s_tap = +-1, 16 * kc * taps <= 13824 and nt % 16 == 0: a block stages 16
+ *                  rows x one K chunk x all taps through LDS (contiguous reads, 256-byte write runs); a job has
+ *                  ceil(rows / nt) * (nt / 16) * ceil(kdim / kc) blocks.  The form for the 3x3x3 weights, which hold most of the
+ *                  parameters.  tiled = taps * 100 + kc (2732, 2716, 932, 916): the same with that geometry compiled in
+ *                  (every job of the table must have it; float4 source reads).
+ *   tiled = 3    : MD_PACK_WINO jobs, block-cooperative (a block = 32 rows x 16 channels x 27 taps); a job has
+ *                  (cout / 32) * (cin / 16) blocks.
  */
 enum { MD_PACK_WPK = 0, MD_PACK_WINO = 1 };
 typedef struct MdPackJob {
@@ -296,7 +304,7 @@ typedef struct MdPackJob {
   int64_t s_row, s_k, s_tap, n_items, block0;
   int32_t rows, kdim, taps, nt, kc, prec, flip, kind;
 } MdPackJob;
-int md_pack_batch(const MdPackJob* jobs_dev, int32_t n_jobs, int64_t total_blocks, void* stream);
+int md_pack_batch(const MdPackJob* jobs_dev, int32_t n_jobs, int64_t total_blocks, int32_t tiled, void* stream);
 
 /*
  * md_conv3_s2: the stride-2 3x3x3 convolution of Downsample (layers.py:626-643: F.pad(x, (0, 1, 0, 1, 0, 1)) +

@@ -144,6 +144,7 @@ class PackedWeight:
 
 _PACK_QUEUE = []      # (owner, job) pairs waiting for flush_packs()
 PACK_BATCH = os.environ.get("MD_PACK_BATCH", "1") == "1"   # A/B switch: 0 = one md_pack_weights / md_wino_pack_weights launch per weight
+PACK_TILED = os.environ.get("MD_PACK_TILED", "1") == "1"   # A/B switch: 0 = the batch packs every weight one item per thread
 
 
 def flush_packs():
@@ -157,19 +158,37 @@ def flush_packs():
     for owner, j in queue:
         outs.append(torch.empty(j["nbytes"] // 2, dtype=torch.bfloat16, device=j["w"].device))
     if PACK_BATCH and len(queue) > 1 and len({j["w"].device for _, j in queue}) == 1:
-        jobs = (_lib.MdPackJob * len(queue))()
-        block0 = 0
-        for i, ((owner, j), out) in enumerate(zip(queue, outs)):
-            J = jobs[i]
-            J.w, J.out = j["w"].data_ptr() + j["w_off"], out.data_ptr()
-            J.s_row, J.s_k, J.s_tap = j["s_row"], j["s_k"], j["s_tap"]
-            J.n_items, J.block0 = j["nbytes"] // 16, block0
-            J.rows, J.kdim, J.taps, J.nt, J.kc, J.prec, J.flip, J.kind = (j["rows"], j["kdim"], j["taps"], j["nt"], j["kc"],
-                                                                         j["prec"], j["flip"], j["kind"])
-            block0 += (J.n_items + 255) // 256
-        table = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).to(outs[0].device)
-        check(lib.md_pack_batch(_ptr(table), len(queue), block0, _stream()), "md_pack_batch")
-        table.record_stream(torch.cuda.current_stream(outs[0].device))
+        def tiled(j):      # block-cooperative form (md_pack_tiled_kernel): the 3x3x3 weights -- most of the parameters
+            return (PACK_TILED and j["kind"] == _lib.PACK_WPK and j["taps"] > 1 and abs(j["s_tap"]) == 1
+                    and 16 * j["kc"] * j["taps"] <= 13824 and j["nt"] % 16 == 0)
+
+        def mode(j):       # md_pack_batch `tiled` argument for this job
+            if PACK_TILED and j["kind"] == _lib.PACK_WINO:
+                return 3
+            if not tiled(j):
+                return 0
+            m = j["taps"] * 100 + j["kc"]
+            return m if m in (2732, 2716, 932, 916) else 1
+
+        for md in sorted({mode(j) for _, j in queue}, reverse=True):
+            sel = [(j, out) for (owner, j), out in zip(queue, outs) if mode(j) == md]
+            jobs = (_lib.MdPackJob * len(sel))()
+            block0 = 0
+            for i, (j, out) in enumerate(sel):
+                J = jobs[i]
+                J.w, J.out = j["w"].data_ptr() + j["w_off"], out.data_ptr()
+                J.s_row, J.s_k, J.s_tap = j["s_row"], j["s_k"], j["s_tap"]
+                J.n_items, J.block0 = j["nbytes"] // 16, block0
+                J.rows, J.kdim, J.taps, J.nt, J.kc, J.prec, J.flip, J.kind = (j["rows"], j["kdim"], j["taps"], j["nt"], j["kc"],
+                                                                             j["prec"], j["flip"], j["kind"])
+                if md == 3:
+                    block0 += (j["rows"] // 32) * (j["kdim"] // 16)
+                elif md:
+                    block0 += -(-j["rows"] // j["nt"]) * (j["nt"] // 16) * -(-j["kdim"] // j["kc"])
+                else:
+                    block0 += (J.n_items + 255) // 256
+            table = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).to(outs[0].device)
+            check(lib.md_pack_batch(_ptr(table), len(sel), block0, md, _stream()), "md_pack_batch")
     else:
         for (owner, j), out in zip(queue, outs):
             wp = C.c_void_p(j["w"].data_ptr() + j["w_off"])
