@@ -603,6 +603,43 @@ FUSE_GN_APPLY = os.environ.get("MD_FUSE_GN_APPLY", "1") == "1"   # GroupNorm aff
 FUSE_GN_STATS = True     # take GroupNorm sums from the producing conv's epilogue when it recorded them (A/B switch)
 
 
+# GroupNorm sum buffers ([B][C][2] float64, zero before the producing conv's epilogue / md_gn_stats adds into them) come
+# out of one arena per device that the U-Net zeroes ONCE at the start of a forward (stats_arena_reset): ~90 fill launches
+# per sampling step otherwise (torch.zeros per conv, md_zero per GroupNorm).  Without a reset nothing is ever handed out
+# twice: an exhausted arena is replaced by a fresh zeroed one.
+STATS_ARENA = os.environ.get("MD_STATS_ARENA", "1") == "1"
+_STATS_ARENAS = {}
+_STATS_ARENA_DOUBLES = 1 << 20
+
+
+def stats_arena_reset(device):
+    """Start of a forward: everything handed out before is dead (consumed by the GroupNorms of the previous forward)."""
+    if not STATS_ARENA:
+        return
+    a = _STATS_ARENAS.get(device)
+    if a is None:
+        return
+    if a["off"] > 0:
+        a["buf"][:a["off"]].zero_()
+    a["off"] = 0
+
+
+def stats_zeros(B, rows, device):
+    """Zeroed float64 [B][rows][2]."""
+    n = B * rows * 2
+    if not STATS_ARENA or n > _STATS_ARENA_DOUBLES // 4:
+        return torch.zeros((B, rows, 2), dtype=torch.float64, device=device)
+    device = torch.device(device)
+    if device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    a = _STATS_ARENAS.get(device)
+    if a is None or a["off"] + n > _STATS_ARENA_DOUBLES:
+        a = _STATS_ARENAS[device] = dict(buf=torch.zeros(_STATS_ARENA_DOUBLES, dtype=torch.float64, device=device), off=0)
+    out = a["buf"][a["off"]:a["off"] + n].view(B, rows, 2)
+    a["off"] += (n + 15) & ~15
+    return out
+
+
 def gn_params(parts, gamma, beta, B, P, eps=1e-6, groups=32, want_ac=False):
     """parts: list of (F32B tensor, C).  Returns the float4 params tensor [B][Ctot][4] (want_ac: and the folded affine
     [B][Ctot][2] = (rstd*gamma, beta - mean*rstd*gamma) that md_gemm_conv's fused operand loader applies).
@@ -614,9 +651,7 @@ def gn_params(parts, gamma, beta, B, P, eps=1e-6, groups=32, want_ac=False):
     if len(parts) == 1 and cached[0] is not None:
         sums = cached[0]           # the producing conv already accumulated them in its epilogue
     else:
-        sums = torch.empty((B, ctot, 2), dtype=torch.float64, device=dev)
-        if any(c is None for c in cached):
-            check(lib.md_zero(_ptr(sums), sums.numel() * 8, _stream()), "md_zero")
+        sums = stats_zeros(B, ctot, dev) if any(c is None for c in cached) else torch.empty((B, ctot, 2), dtype=torch.float64, device=dev)
         off = 0
         for (t, c), cs in zip(parts, cached):
             if cs is not None:

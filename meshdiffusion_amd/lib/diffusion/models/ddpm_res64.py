@@ -158,6 +158,7 @@ class DDPMUNet3D(layers.HipLayer):
             raise NotImplementedError("training with model.scale_by_sigma=True is not implemented on the HIP path")
         assert tuple(x.shape[1:]) == (self.out_channels, self.img_size, self.img_size, self.img_size)
         ops.set_precision("bf16x3")
+        ops.stats_arena_reset(x.device)
         ops.prewarm_packs()      # every weight changed since the last step: re-pack what that step used in one launch
         mods = self.all_modules
         B, R = x.shape[0], self.img_size
@@ -410,6 +411,7 @@ class DDPMUNet3D(layers.HipLayer):
         B, R = x.shape[0], self.img_size
         P = R ** 3
         assert tuple(x.shape[1:]) == (self.out_channels, R, R, R)
+        ops.stats_arena_reset(x.device)      # one fill for every GroupNorm sum buffer of this evaluation
         i = 0
         temb = layers.get_timestep_embedding(labels, self.nf)
         temb = ops.linear(temb, mods[i].weight, mods[i].bias); i += 1

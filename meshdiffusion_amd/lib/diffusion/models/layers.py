@@ -144,7 +144,7 @@ def run_conv3(pw, act_s16, B, S_out, *, bias=None, bias_bstride=0, residual=None
         res_bstride = rows_alloc * P
     if (b_f32 is not None and wino is not None and out_mode == ops.OUT_F32B and rows_alloc == pw.rows
             and pw.prec == ops.PREC_BF16X3 and ops.wino_ok(pw.rows, pw.kdim, S_out, B)):
-        stats = torch.zeros((B, rows_alloc, 2), dtype=torch.float64, device=dev) if want_stats and ops.FUSE_GN_STATS else None
+        stats = ops.stats_zeros(B, rows_alloc, dev) if want_stats and ops.FUSE_GN_STATS else None
         t = ops.wino_prep(b_f32["parts"], b_f32.get("ac"), b_f32.get("silu"), ups, B, S_out, drop=b_f32.get("drop"),
                           keep=bool(b_f32.get("keep")))
         if b_f32.get("keep"):
@@ -162,7 +162,7 @@ def run_conv3(pw, act_s16, B, S_out, *, bias=None, bias_bstride=0, residual=None
     stats = None
     if (want_stats and ops.FUSE_GN_STATS and pw.cfg == ops.CFG_C3_128_FAST and ksplit == 1
             and out_mode == ops.OUT_F32B and rows_alloc == pw.rows):
-        stats = torch.zeros((B, rows_alloc, 2), dtype=torch.float64, device=dev)
+        stats = ops.stats_zeros(B, rows_alloc, dev)
     ops.gemm_conv(cfg=pw.cfg, a=pw.data, b=act_s16, out=out, batch=B, rows=pw.rows,
                   rows_alloc=rows_alloc, kdim=pw.kdim, dims=(S_out, S_out, S_out), bias=bias,
                   bias_bstride=bias_bstride, residual=residual, res_bstride=res_bstride or 0, ups=ups,
@@ -339,7 +339,7 @@ class Downsample(HipLayer):
             # one kernel on the raw fp32 tensor (inference: no split pass at all), GroupNorm sums of the output from its epilogue
             pw = self._cached("w/s2", [self.Conv_0.weight],
                               lambda: ops.PackedWeight(self.Conv_0.weight, "conv", ops.CFG_S2_PACK, self.Conv_0.weight.device))
-            stats = torch.zeros((B, pw.rows, 2), dtype=torch.float64, device=x.device) if ops.FUSE_GN_STATS and pw.rows % 8 == 0 else None
+            stats = ops.stats_zeros(B, pw.rows, x.device) if ops.FUSE_GN_STATS and pw.rows % 8 == 0 else None
             out = ops.conv3_s2(pw, x, B, s_out, bias=self.Conv_0.bias, stats=stats)
             if stats is not None:
                 out._md_sums = stats
