@@ -282,6 +282,17 @@ int md_conv3_wino(const void* t_in, const void* wpk, float* out, const float* bi
                   int32_t D, int32_t H, int32_t W, int32_t variant, void* stream);
 
 /*
+ * md_conv3_head: GroupNorm + SiLU + the dx-folded 3x3x3 output head in one kernel for inference (csrc/conv3_head.hip;
+ * ddpm_res64.py:120-121 applied :186-189): replaces md_gn_apply + md_gemm_conv(MD_CFG_C3X_32); md_fold_dx finishes the conv.
+ *   x   : F32B [B][cin/8][P][8] (the un-normalised tensor);  ac: [B][cin][2] folded GroupNorm affine of md_gn_finalize
+ *   wpk : md_pack_weights(W2, rows = co * 3, kdim = cin, taps = 9, nt = 32, kc = 16), W2[(co, kw)][ci][kd][kh] (see md_fold_dx)
+ *   y   : F32B [B][rows_alloc/8][P][8], rows (co, kw); no bias
+ * Supported: cin % 32 == 0, rows_alloc in {8, 16, 24, 32}, D % 4 == 0, H % 8 == 0, W % 8 == 0, D*H*W < 2^30.
+ */
+int md_conv3_head(const float* x, const float* ac, const void* wpk, float* y, int32_t batch, int32_t cin, int32_t rows_alloc,
+                  int32_t D, int32_t H, int32_t W, void* stream);
+
+/*
  * md_pack_batch: several md_pack_weights / md_wino_pack_weights jobs in one launch (csrc/pack_batch.hip; a training step
  * re-packs every weight once: ~260 launches otherwise).  Bit-identical to the single-weight entry points.
  *   jobs_dev     : DEVICE array of n_jobs MdPackJob, sorted by block0; job j owns the blocks from block0 on

@@ -524,6 +524,28 @@ def conv3_s2(pw, x, B, S_out, *, bias=None, bias_bstride=0, stats=None, out=None
     return out
 
 
+# GroupNorm + SiLU + dx-folded 3x3x3 head in one kernel (csrc/conv3_head.hip): no md_gn_apply pass, no generic tile
+CONV3_HEAD = os.environ.get("MD_CONV3_HEAD", "1") == "1"   # A/B switch: 0 = md_gn_apply + md_gemm_conv(CFG_C3X_32)
+CFG_HEAD_PACK = CFG_C5X_32_K16                             # tile geometry of its packed weights: nt = 32, kc = 16
+
+
+def conv3_head_ok(rows, cin, S):
+    return CONV3_HEAD and FUSE_GN_APPLY and PRECISION == "bf16x3" and rows <= 32 and cin % 32 == 0 and S % 8 == 0
+
+
+def conv3_head(pw, x, ac, B, S, rows_alloc):
+    """y F32B [B][rows_alloc][S^3] (rows = (co, kw)) of the dx-folded head on the un-normalised F32B tensor x with the folded
+    GroupNorm affine `ac`; SiLU inside -- md_conv3_head."""
+    lib = _lib.load()
+    P = S ** 3
+    y = f32b_empty(B, rows_alloc, P, x.device)
+    ev = _prof_begin()
+    check(lib.md_conv3_head(_ptr(x), _ptr(ac), _ptr(pw.data), _ptr(y), B, pw.kdim, rows_alloc, S, S, S, _stream()), "md_conv3_head")
+    _prof_end(ev, "head", 2.0 * B * pw.rows * pw.kdim * 9 * P, 4.0 * (B * pw.kdim * P + pw.rows * pw.kdim * 9 + B * rows_alloc * P),
+              f"{pw.kdim}->{pw.rows}@{S}x{S}x{S}")
+    return y
+
+
 # ---- EXPERIMENTAL: Winograd F(4,3) along w (csrc/experimental/conv3_wino43.hip, MD_BUILD_EXPERIMENTAL=1 builds only);
 # ---- tools/bench_wino.py --f43, tests/test_gpu_wino.py.  Nothing on the product path uses it.
 def _need_experimental():

@@ -381,6 +381,19 @@ class DDPMUNet3D(layers.HipLayer):
         xf = ops.ncdhw_to_s16b_xfold(xin, k, c_pad)
         return layers.run_conv3(pw, xf, B, R, bias=stem.bias, residual=self._stem_const(), res_bstride=0)
 
+    def _head_forward_fused(self, head, h, ac, B, R):
+        """_head_forward on the un-normalised tensor `h` (F32B) with the folded GroupNorm affine `ac`: md_conv3_head."""
+        k, co = self.KSIZE, self.out_channels
+
+        def build():
+            w = head.weight.detach()                                   # [co][ci][kz][ky][kx]
+            w2 = w.permute(0, 4, 1, 2, 3).reshape(co * k, w.shape[1], k, k, 1).contiguous()
+            return ops.PackedWeight(w2, "conv", ops.CFG_HEAD_PACK, w.device)
+        pw = self._cached("head_fold_fused", [head.weight], build)
+        rows_alloc = ((co * k + 7) // 8) * 8
+        y = ops.conv3_head(pw, h, ac, B, R, rows_alloc)
+        return ops.fold_dx(y, head.bias, B, co, k, rows_alloc, R)
+
     def _head_forward(self, head, a, B, R):
         """The k^3 head conv to 4 channels, dx-folded: a k x k x 1 conv whose rows are the (co, dx) pairs (12 or 20 of the
         32 rows of an MFMA tile instead of 4, with k times fewer taps), then `md_fold_dx` adds the k x-shifted columns
@@ -457,11 +470,16 @@ class DDPMUNet3D(layers.HipLayer):
         assert not hs
 
         gn = mods[i]; i += 1
-        prm = ops.gn_params([(h, c)], gn.weight, gn.bias, B, p, eps=gn.eps, groups=gn.num_groups)
-        a = ops.gn_apply([(h, c)], prm, B, p, norm=True, silu=True)
         head = mods[i]; i += 1
         assert i == len(mods)
-        out = self._head_forward(head, a, B, R)
+        if self.KSIZE == 3 and ops.conv3_head_ok(self.out_channels * 3, c, R):
+            # GroupNorm affine + SiLU + split inside the head kernel's loader: no GroupNorm-apply pass over the 64^3 tensor
+            _, ac = ops.gn_params([(h, c)], gn.weight, gn.bias, B, p, eps=gn.eps, groups=gn.num_groups, want_ac=True)
+            out = self._head_forward_fused(head, h, ac, B, R)
+        else:
+            prm = ops.gn_params([(h, c)], gn.weight, gn.bias, B, p, eps=gn.eps, groups=gn.num_groups)
+            a = ops.gn_apply([(h, c)], prm, B, p, norm=True, silu=True)
+            out = self._head_forward(head, a, B, R)
 
         if self.scale_by_sigma:
             out = out / self.sigmas[labels.long(), None, None, None, None].to(out.dtype)

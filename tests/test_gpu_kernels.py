@@ -437,6 +437,35 @@ def test_generic_conv_fused_groupnorm_silu_operand(ops, case):
     assert e < TOL_MFMA and e2 < TOL_MFMA
 
 
+@pytest.mark.parametrize("B,cin,S", [(2, 64, 8), (1, 128, 16)])
+def test_conv3_head_fused_kernel(ops, B, cin, S):
+    """md_conv3_head (csrc/conv3_head.hip: GroupNorm affine + SiLU + split in the loader of the dx-folded 3x3x3 head, then
+    md_fold_dx) against torch fp32 GroupNorm -> SiLU -> conv3d, and against the two-pass path it replaces (md_gn_apply +
+    MD_CFG_C3X_32 + md_fold_dx); bit-identical between launches."""
+    co = 4
+    x = _rand((B, cin, S, S, S), 90) * 1.5 + 0.2
+    gamma, beta = 1.0 + 0.2 * _rand((cin,), 91), 0.5 * _rand((cin,), 92)
+    w = _rand((co, cin, 3, 3, 3), 93, 0.05); bias = _rand((co,), 94)
+    P = S ** 3
+    parts = [(ops.ncdhw_to_f32b(x.cuda()), cin)]
+    prm, ac = ops.gn_params(parts, gamma.cuda(), beta.cuda(), B, P, want_ac=True)
+    w2 = w.permute(0, 4, 1, 2, 3).reshape(co * 3, cin, 3, 3, 1).contiguous().cuda()
+    assert ops.conv3_head_ok(co * 3, cin, S)
+    pw = ops.PackedWeight(w2, "conv", ops.CFG_HEAD_PACK, "cuda")
+    y = ops.conv3_head(pw, parts[0][0], ac, B, S, 16)
+    out = ops.fold_dx(y, bias.cuda(), B, co, 3, 16, S)
+    ref = F.conv3d(F.silu(F.group_norm(x, 32, gamma, beta, eps=1e-6)), w, bias, padding=1)
+    e = rel_l2(out.cpu(), ref)
+    a16 = ops.gn_apply(parts, prm, B, P, norm=True, silu=True)
+    pw_old = ops.PackedWeight(w2, "conv", ops.CFG_C3X_32, "cuda")
+    y_old = ops.f32b_empty(B, 16, P, "cuda")
+    ops.gemm_conv(cfg=ops.CFG_C3X_32, a=pw_old.data, b=a16, out=y_old, batch=B, rows=12, rows_alloc=16, kdim=cin, dims=(S, S, S))
+    e2 = rel_l2(out.cpu(), ops.fold_dx(y_old, bias.cuda(), B, co, 3, 16, S).cpu())
+    print(f"conv3_head {cin}->4 @ {S}^3: vs torch fp32 {e:.2e}, vs the two-pass path {e2:.2e}")
+    assert e < TOL_MFMA and e2 < TOL_MFMA
+    assert torch.equal(y, ops.conv3_head(pw, parts[0][0], ac, B, S, 16))
+
+
 def test_pack_batch_bit_identical_to_single_launches(ops):
     """md_pack_batch (csrc/pack_batch.hip: all queued weight packs of a training step in one launch) writes the same tiles,
     bit for bit, as md_pack_weights / md_wino_pack_weights one weight at a time: conv / data-gradient / NIN / rows kinds,
