@@ -513,7 +513,7 @@ int md_launch_conv3_main(const MdGemmConvArgs& a, hipStream_t stream) {
     if (a.prec != MD_PREC_BF16X3 || (a.b_split & 7) || a.b_split <= 0 || (a.b_split < a.kdim && a.b2 == nullptr)) return MD_ERR_BAD_ARG;
     if (a.b_silu && a.b_ac == nullptr) return MD_ERR_BAD_ARG;   // SiLU is applied together with the folded GroupNorm affine only
   }
-  if (a.stats != nullptr && a.ksplit > 1) return MD_ERR_UNSUPPORTED;
+  // (with split-K the statistics come from the finish kernel: md_splitk_reduce_stats_kernel)
   const int tiles = (a.D / TZ) * (a.H / TY) * (a.W / TX);
   const int ks = a.ksplit > 1 ? a.ksplit : 1;
   if (ks > 1 && (a.partial == nullptr || ks > a.kdim / KC)) return MD_ERR_BAD_ARG;

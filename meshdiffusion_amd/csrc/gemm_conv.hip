@@ -583,8 +583,65 @@ __global__ void md_splitk_reduce_kernel(const MdGemmConvArgs A, int64_t P) {
   }
 }
 
+// The same finish with the GroupNorm sums of the result (MdGemmConvArgs.stats) for the small grids that run split-K (8^3 / 4^3
+// levels): one block per (sample, 8-channel group) walks that slab's P positions; a thread keeps one channel quad (its float4
+// index parity is constant over the block stride), so the sums are per-thread adds, one wave reduction, 16 plain adds to stats
+// -- instead of a md_gn_stats launch over the tensor just written.
+__global__ __launch_bounds__(256) void md_splitk_reduce_stats_kernel(const MdGemmConvArgs A, int64_t P) {
+  __shared__ float red[4][16];
+  const int rga = A.rows_alloc / 8;
+  const int cg = blockIdx.x % rga, b = blockIdx.x / rga;
+  const int64_t slab = ((int64_t)b * rga + cg) * P * 8;                // first float of this (sample, channel group)
+  const int64_t slice = (int64_t)A.batch * rga * P * 8;
+  const int row = cg * 8 + (threadIdx.x & 1) * 4;
+  f32x4 bias = {0.f, 0.f, 0.f, 0.f};
+  if (A.bias != nullptr) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) if (row + e < A.rows) bias[e] = A.bias[(int64_t)b * A.bias_bstride + row + e];
+  }
+  f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1;
+  for (int64_t i = threadIdx.x; i < P * 2; i += 256) {                 // float4 items of the slab: (position, channel half)
+    const int64_t e0 = slab + i * 4;
+    f32x4 s = *(const f32x4*)(A.partial + e0);
+    for (int z = 1; z < A.ksplit; ++z) {
+      const f32x4 v = *(const f32x4*)(A.partial + (int64_t)z * slice + e0);
+      s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
+    }
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = A.alpha * s[e] + bias[e];       // same association as md_splitk_reduce_kernel
+    if (A.residual != nullptr) {
+      const f32x4 rv = *(const f32x4*)(A.residual + (int64_t)b * A.res_bstride + (int64_t)cg * P * 8 + i * 4);
+      o[0] += rv[0]; o[1] += rv[1]; o[2] += rv[2]; o[3] += rv[3];
+    }
+    *(f32x4*)((float*)A.out + e0) = o;
+    s1 += o; s2 += o * o;
+  }
+  // lanes of equal parity hold the same channel quad: xor-reduce over lane bits 1..5, then over the 4 waves through LDS
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+#pragma unroll
+    for (int o = 2; o < 64; o <<= 1) { s1[e] += __shfl_xor(s1[e], o, 64); s2[e] += __shfl_xor(s2[e], o, 64); }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane < 2) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { red[wv][(lane * 4 + e) * 2] = s1[e]; red[wv][(lane * 4 + e) * 2 + 1] = s2[e]; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 16) {
+    const float t = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    A.stats[((int64_t)b * A.rows_alloc + cg * 8) * 2 + threadIdx.x] += (double)t;     // this block owns the 8 channels
+  }
+}
+
 int md_launch_splitk_reduce(const MdGemmConvArgs& a, hipStream_t stream) {
   const int64_t P = (int64_t)a.D * a.H * a.W;
+  if (a.stats != nullptr) {
+    MD_HIP_CLEAR_ERROR();
+    hipLaunchKernelGGL(md_splitk_reduce_stats_kernel, dim3((unsigned)(a.batch * (a.rows_alloc / 8))), dim3(256), 0, stream, a, P);
+    MD_HIP_CHECK_LAUNCH();
+    return MD_OK;
+  }
   const int64_t n4 = (int64_t)a.batch * (a.rows_alloc / 8) * P * 2;
   int blocks = (int)((n4 + 255) / 256);
   if (blocks > 2048) blocks = 2048;
@@ -693,7 +750,8 @@ extern "C" int md_gemm_conv(const MdGemmConvArgs* args, void* stream) {
   int rc = MD_OK;
   hipStream_t st = (hipStream_t)stream;
   if (args->cfg == MD_CFG_C3_128_FAST || (args->cfg >= 111 && args->cfg <= 127)) return md_launch_conv3_main(*args, st);
-  if (args->stats != nullptr) return MD_ERR_UNSUPPORTED;   // epilogue statistics: dedicated 3x3x3 kernel only
+  if (args->stats != nullptr && !(args->ksplit > 1 && args->out_mode == MD_OUT_F32B))
+    return MD_ERR_UNSUPPORTED;   // statistics: the dedicated 3x3x3 kernel's epilogue, or the split-K finish (md_splitk_reduce_stats_kernel)
   MD_CFG_SWITCH_LAUNCH(args->cfg, rc = launch_cfg, *args, st);
   return rc;
 }

@@ -623,6 +623,7 @@ def _prof_end(e0, cfg, flops, abytes, tag):
 # ---------------------------------------------------------------------------------------------
 FUSE_GN_APPLY = os.environ.get("MD_FUSE_GN_APPLY", "1") == "1"   # GroupNorm affine + SiLU + split inside the conv's halo loader (inference)
 FUSE_GN_STATS = True     # take GroupNorm sums from the producing conv's epilogue when it recorded them (A/B switch)
+SPLITK_STATS = os.environ.get("MD_SPLITK_STATS", "1") == "1"   # ... and from the split-K finish kernel (8^3 / 4^3 levels)
 
 
 # GroupNorm sum buffers ([B][C][2] float64, zero before the producing conv's epilogue / md_gn_stats adds into them) come

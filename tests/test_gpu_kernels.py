@@ -359,6 +359,27 @@ def test_conv_epilogue_groupnorm_statistics(hip_lib):
     assert rel_l2(p_cat.cpu(), p_cat_plain.cpu()) < 1e-6
 
 
+@pytest.mark.parametrize("cfg_name,S,ks", [("CFG_C3_128_FAST", 8, 4), ("CFG_C3_LOW", 4, 2)])
+def test_splitk_finish_groupnorm_statistics(ops, cfg_name, S, ks):
+    """With split-K the GroupNorm sums come from the finish kernel (md_splitk_reduce_stats_kernel): same output bits as the
+    plain finish, sums equal to float64 sums of what was written (bias + residual included)."""
+    cfg = getattr(ops, cfg_name)
+    B, cin, cout = 3, 128, 136
+    x = _rand((B, cin, S, S, S), 50); w = _rand((cout, cin, 3, 3, 3), 51, 0.05); bias = _rand((cout,), 52)
+    res = ops.ncdhw_to_f32b(_rand((B, cout, S, S, S), 53).cuda())
+    s16, _, _ = _to_s16(ops, x)
+    pw = ops.PackedWeight(w.cuda(), "conv", cfg, "cuda")
+    kw = dict(cfg=cfg, a=pw.data, b=s16, batch=B, rows=cout, rows_alloc=cout, kdim=cin, dims=(S, S, S), bias=bias.cuda(),
+              residual=res, res_bstride=cout * S ** 3, ksplit=ks)
+    plain = ops.gemm_conv(out=ops.f32b_empty(B, cout, S ** 3, "cuda"), **kw)
+    stats = torch.zeros((B, cout, 2), dtype=torch.float64, device="cuda")
+    out = ops.gemm_conv(out=ops.f32b_empty(B, cout, S ** 3, "cuda"), stats=stats, **kw)
+    assert torch.equal(out, plain)
+    y = ops.f32b_to_ncdhw(out, (S, S, S)).double()
+    ref = torch.stack([y.sum(dim=(2, 3, 4)), (y * y).sum(dim=(2, 3, 4))], dim=-1)
+    assert torch.allclose(stats, ref, rtol=1e-5, atol=1e-3)
+
+
 @pytest.mark.parametrize("case", ["one_part_gn_silu", "two_parts_gn_silu", "ups_split_only", "gn_no_silu"])
 def test_conv3_fused_groupnorm_silu_operand(ops, case):
     """MD_B_F32B_GN: the dedicated conv reads fp32 F32B parts (one tensor or a channel concat of two) and applies the
