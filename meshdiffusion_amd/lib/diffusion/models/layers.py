@@ -161,7 +161,9 @@ def run_conv3(pw, act_s16, B, S_out, *, bias=None, bias_bstride=0, residual=None
     ksplit = ops.ksplit_for(pw.cfg, B, pw.rows, pw.kdim, S_out) if out_mode == ops.OUT_F32B else 1
     stats = None
     # statistics of the output: the dedicated kernel's epilogue, or (8^3 / 4^3 levels) the split-K finish kernel
-    if (want_stats and ops.FUSE_GN_STATS and ((pw.cfg == ops.CFG_C3_128_FAST and ksplit == 1) or (ksplit > 1 and ops.SPLITK_STATS))
+    # (one block per (sample, 8-channel group) there: only where that fills the chip -- at B = 1 the 32^3 level would run on 16 blocks)
+    if (want_stats and ops.FUSE_GN_STATS and ((pw.cfg == ops.CFG_C3_128_FAST and ksplit == 1)
+                                              or (ksplit > 1 and ops.SPLITK_STATS and P <= 512 and B * rows_alloc >= 2048))
             and out_mode == ops.OUT_F32B and rows_alloc == pw.rows):
         stats = ops.stats_zeros(B, rows_alloc, dev)
     ops.gemm_conv(cfg=pw.cfg, a=pw.data, b=act_s16, out=out, batch=B, rows=pw.rows,
