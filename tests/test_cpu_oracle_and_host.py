@@ -155,6 +155,36 @@ def test_bad_arguments_are_rejected_without_a_gpu(hip_lib):
     assert hip_lib.md_wgrad_wino(p, p, p, p, big, 1, 128, 256, 64, 64, 64, 64, 27 * 256, 27, 1, None) == -1    # ksplit > B (D - 1)
 
 
+def test_round3_entry_points_reject_bad_arguments_without_a_gpu(hip_lib):
+    """md_conv3_s2 / md_conv3_head / md_pack_batch check their arguments before any launch; MdPackJob matches the header; the
+    host-side shape predicates of the new kernels."""
+    from meshdiffusion_amd import _lib, hip_ops
+    buf = ctypes.create_string_buffer(64)
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    s2 = hip_lib.md_conv3_s2
+    assert s2(None, p, p, None, 0, None, 1, 32, 64, 64, 8, 8, 8, None) == -1          # no input
+    assert s2(p, p, p, None, 0, None, 1, 48, 64, 64, 8, 8, 8, None) == -2             # cin % 32
+    assert s2(p, p, p, None, 0, None, 1, 32, 64, 64, 6, 8, 8, None) == -2             # D % 4
+    assert s2(p, p, p, None, 0, None, 1, 32, 64, 60, 8, 8, 8, None) == -1             # rows_alloc < rows
+    hd = hip_lib.md_conv3_head
+    assert hd(p, None, p, p, 1, 64, 16, 8, 8, 8, None) == -1                          # the folded affine is required
+    assert hd(p, p, p, p, 1, 48, 16, 8, 8, 8, None) == -2 and hd(p, p, p, p, 1, 64, 40, 8, 8, 8, None) == -2
+    assert hd(p, p, p, p, 1, 64, 16, 8, 8, 12, None) == -2
+    pb = hip_lib.md_pack_batch
+    assert pb(None, 1, 1, 0, None) == -1 and pb(p, 0, 1, 0, None) == -1 and pb(p, 1, 0, 0, None) == -1
+    assert ctypes.sizeof(_lib.MdPackJob) == 2 * 8 + 5 * 8 + 8 * 4 and _lib.MdPackJob.rows.offset == 56
+    header = open(os.path.join(ROOT, "include", "meshdiffusion_hip.h")).read()
+    body = header[header.index("typedef struct MdPackJob {"):header.index("} MdPackJob;")]
+    assert [f.strip(" ;") for f in body.split("\n")[1:] if f.strip()] == [
+        "const float* w", "void* out", "int64_t s_row, s_k, s_tap, n_items, block0", "int32_t rows, kdim, taps, nt, kc, prec, flip, kind"]
+    # shape predicates (pure host logic)
+    assert hip_ops.conv3_s2_ok(128, 128, 32, 8) and hip_ops.conv3_s2_ok(128, 128, 16, 8)
+    assert not hip_ops.conv3_s2_ok(256, 256, 8, 8)          # 32 workgroups: the split-K generic tile is faster
+    assert not hip_ops.conv3_s2_ok(128, 128, 4, 8) and not hip_ops.conv3_s2_ok(128, 48, 32, 8)
+    assert hip_ops.conv3_s2_ok(128, 128, 32, 1) and not hip_ops.conv3_s2_ok(128, 128, 16, 1)
+    assert hip_ops.conv3_head_ok(12, 128, 64) and not hip_ops.conv3_head_ok(20, 64, 12) and not hip_ops.conv3_head_ok(36, 128, 64)
+
+
 def test_hip_path_refuses_cpu_tensors():
     from meshdiffusion_amd import _lib, hip_ops
     with pytest.raises(_lib.MeshDiffusionHipError):
