@@ -282,6 +282,20 @@ int md_conv3_wino(const void* t_in, const void* wpk, float* out, const float* bi
                   int32_t D, int32_t H, int32_t W, int32_t variant, void* stream);
 
 /*
+ * md_conv3_stem: the dx-folded 3x3x3 input convolution from 4 channels (csrc/conv3_stem.hip; ddpm_res64.py:87-92 applied
+ * :138-146: conv3x3(channels, nf)(x) + pos_layer(coords) + mask_layer(mask)) with the GroupNorm sums of its output: replaces
+ * md_gemm_conv(MD_CFG_C3X_128_K16) + md_gn_stats.
+ *   x16      : S16B [B][2][2][P][8]: the operand of md_ncdhw_to_s16b_xfold(kx = 3, c_pad = 16)
+ *   wpk      : md_pack_weights(W2, rows = cout, kdim = 12 (padded to 16), taps = 9, nt = 128, kc = 16), W2[co][(ci, kx)][kd][kh]
+ *   out      : F32B [B][cout/8][P][8] = conv + bias[co] + residual[co][p]
+ *   residual : F32B [cout/8][P][8] shared by the batch (the input-independent terms), or NULL;  bias: [cout] or NULL
+ *   stats    : optional zeroed double [B][cout][2] += per-(sample, channel) (sum, sum of squares) of out
+ * Supported: cout % 8 == 0, D % 4 == 0, H % 8 == 0, W % 8 == 0; else MD_ERR_UNSUPPORTED.
+ */
+int md_conv3_stem(const void* x16, const void* wpk, float* out, const float* bias, const float* residual, double* stats,
+                  int32_t batch, int32_t cout, int32_t D, int32_t H, int32_t W, void* stream);
+
+/*
  * md_conv3_head: GroupNorm + SiLU + the dx-folded 3x3x3 output head in one kernel for inference (csrc/conv3_head.hip;
  * ddpm_res64.py:120-121 applied :186-189): replaces md_gn_apply + md_gemm_conv(MD_CFG_C3X_32); md_fold_dx finishes the conv.
  *   x   : F32B [B][cin/8][P][8] (the un-normalised tensor);  ac: [B][cin][2] folded GroupNorm affine of md_gn_finalize

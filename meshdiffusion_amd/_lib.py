@@ -81,6 +81,7 @@ SIGNATURES = {
     "md_wino_weight_bytes": (_I64, [_I32, _I32]),
     "md_wino_pack_weights": (C.c_int, [_P, _P, _I32, _I32, _I64, _I64, _I32, _P]),
     "md_conv3_wino": (C.c_int, [_P, _P, _P, _P, _I64, _P, _I64, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P]),
+    "md_conv3_stem": (C.c_int, [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P]),
     "md_conv3_head": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _P]),
     "md_pack_batch": (C.c_int, [_P, _I32, _I64, _I32, _P]),
     "md_conv3_s2": (C.c_int, [_P, _P, _P, _P, _I64, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P]),

@@ -524,6 +524,27 @@ def conv3_s2(pw, x, B, S_out, *, bias=None, bias_bstride=0, stats=None, out=None
     return out
 
 
+# The dx-folded 3x3x3 stem in its own kernel (csrc/conv3_stem.hip), with the GroupNorm sums of its output
+CONV3_STEM = os.environ.get("MD_CONV3_STEM", "1") == "1"   # A/B switch: 0 = md_gemm_conv(CFG_C3X_128_K16) + md_gn_stats
+
+
+def conv3_stem_ok(rows, kdim, S):
+    return CONV3_STEM and PRECISION == "bf16x3" and kdim == 16 and rows % 8 == 0 and S % 8 == 0
+
+
+def conv3_stem(pw, x16, B, S, *, bias=None, residual=None, stats=None):
+    """out F32B [B][rows][S^3] of the dx-folded stem on the x-folded S16B operand (md_ncdhw_to_s16b_xfold) -- md_conv3_stem."""
+    lib = _lib.load()
+    P = S ** 3
+    out = f32b_empty(B, pw.rows, P, x16.device)
+    ev = _prof_begin()
+    check(lib.md_conv3_stem(_ptr(x16), _ptr(pw.data), _ptr(out), _ptr(bias), _ptr(residual), _ptr(stats), B, pw.rows, S, S, S,
+                            _stream()), "md_conv3_stem")
+    _prof_end(ev, "stem", 2.0 * B * pw.rows * pw.kdim * 9 * P, 4.0 * (B * pw.kdim * P + pw.rows * pw.kdim * 9 + B * pw.rows * P),
+              f"{pw.kdim}->{pw.rows}@{S}x{S}x{S}" + ("/res" if residual is not None else "") + ("/stats" if stats is not None else ""))
+    return out
+
+
 # GroupNorm + SiLU + dx-folded 3x3x3 head in one kernel (csrc/conv3_head.hip): no md_gn_apply pass, no generic tile
 CONV3_HEAD = os.environ.get("MD_CONV3_HEAD", "1") == "1"   # A/B switch: 0 = md_gn_apply + md_gemm_conv(CFG_C3X_32)
 CFG_HEAD_PACK = CFG_C5X_32_K16                             # tile geometry of its packed weights: nt = 32, kc = 16

@@ -379,6 +379,13 @@ class DDPMUNet3D(layers.HipLayer):
             return ops.PackedWeight(w2, "conv", cfg, w.device)
         pw = self._cached(f"stem_fold{cfg}", [stem.weight], build)
         xf = ops.ncdhw_to_s16b_xfold(xin, k, c_pad)
+        if k == 3 and ops.conv3_stem_ok(pw.rows, pw.kdim, R):
+            # dedicated kernel; the GroupNorm sums of h0 (first ResnetBlock) come from its epilogue
+            stats = ops.stats_zeros(B, pw.rows, xin.device) if ops.FUSE_GN_STATS else None
+            out = ops.conv3_stem(pw, xf, B, R, bias=stem.bias, residual=self._stem_const(), stats=stats)
+            if stats is not None:
+                out._md_sums = stats
+            return out
         return layers.run_conv3(pw, xf, B, R, bias=stem.bias, residual=self._stem_const(), res_bstride=0)
 
     def _head_forward_fused(self, head, h, ac, B, R):

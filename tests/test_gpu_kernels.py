@@ -458,6 +458,33 @@ def test_generic_conv_fused_groupnorm_silu_operand(ops, case):
     assert e < TOL_MFMA and e2 < TOL_MFMA
 
 
+@pytest.mark.parametrize("B,cout,S", [(2, 128, 8), (3, 136, 16)])
+def test_conv3_stem_kernel(ops, B, cout, S):
+    """md_conv3_stem (csrc/conv3_stem.hip: the dx-folded 3x3x3 conv from 4 channels with a batch-shared residual and the
+    GroupNorm sums of its output) against torch fp32, against the generic tile it replaces (bit-identical: same products,
+    same order) and float64 sums of what it wrote.  Second case: several tiles per axis, a partial second row tile."""
+    x = _rand((B, 4, S, S, S), 60); w = _rand((cout, 4, 3, 3, 3), 61, 0.1); bias = _rand((cout,), 62)
+    res = _rand((1, cout, S, S, S), 63)
+    res_f = ops.ncdhw_to_f32b(res.cuda())
+    w2 = w.permute(0, 1, 4, 2, 3).reshape(cout, 12, 3, 3, 1).contiguous().cuda()
+    pw = ops.PackedWeight(w2, "conv", ops.CFG_C3X_128_K16, "cuda")
+    xf = ops.ncdhw_to_s16b_xfold(x.cuda(), 3, 16)
+    assert ops.conv3_stem_ok(pw.rows, pw.kdim, S)
+    stats = torch.zeros((B, cout, 2), dtype=torch.float64, device="cuda")
+    out = ops.conv3_stem(pw, xf, B, S, bias=bias.cuda(), residual=res_f, stats=stats)
+    got = ops.f32b_to_ncdhw(out, (S, S, S)).cpu()
+    ref = F.conv3d(x, w, bias, padding=1) + res
+    e = rel_l2(got, ref)
+    print(f"conv3_stem 4->{cout} @ {S}^3: vs torch fp32 {e:.2e}")
+    assert e < TOL_MFMA
+    g64 = got.double()
+    assert torch.allclose(stats.cpu(), torch.stack([g64.sum(dim=(2, 3, 4)), (g64 * g64).sum(dim=(2, 3, 4))], dim=-1), rtol=1e-5, atol=1e-3)
+    old = ops.f32b_empty(B, cout, S ** 3, "cuda")
+    ops.gemm_conv(cfg=ops.CFG_C3X_128_K16, a=pw.data, b=xf, out=old, batch=B, rows=cout, rows_alloc=cout, kdim=16, dims=(S, S, S),
+                  bias=bias.cuda(), residual=res_f, res_bstride=0)
+    assert torch.equal(out, old)
+
+
 @pytest.mark.parametrize("B,cin,S", [(2, 64, 8), (1, 128, 16)])
 def test_conv3_head_fused_kernel(ops, B, cin, S):
     """md_conv3_head (csrc/conv3_head.hip: GroupNorm affine + SiLU + split in the loader of the dx-folded 3x3x3 head, then
