@@ -207,32 +207,35 @@ def flush_packs():
 # Sites of the packed-weight caches (layers.HipLayer._cached) that were used since the last prewarm: a training step changes
 # every weight, so the forward of the next step would rebuild each cache entry at its first use -- one packing launch per
 # weight.  prewarm_packs() (start of a training forward) rebuilds the entries the previous step used, queues their packing
-# jobs and flushes them as ONE md_pack_batch launch.
-_PACK_SITES = {}
+# jobs and flushes them as md_pack_batch launches.  The (params, builder) pairs live on the layers themselves (they reference
+# the layer: a global table would keep every model ever built alive); here only a weak set of the layers that have some.
+import weakref  # noqa: E402
+
+_PACK_LAYERS = weakref.WeakSet()
 
 
 def note_pack_use(layer, name, params, builder):
-    import weakref
-    key = (id(layer), name)
-    if key not in _PACK_SITES:
-        _PACK_SITES[key] = (weakref.ref(layer), name, list(params), builder)
+    used = layer.__dict__.get("_md_used")
+    if used is None:
+        used = layer.__dict__["_md_used"] = {}
+        _PACK_LAYERS.add(layer)
+    if name not in used:
+        used[name] = (list(params), builder)
 
 
 def prewarm_packs():
-    global _PACK_SITES
-    if not PACK_BATCH:
-        _PACK_SITES = {}
-        return 0
-    sites, _PACK_SITES = _PACK_SITES, {}
+    layers = list(_PACK_LAYERS)
+    _PACK_LAYERS.clear()
     n = 0
-    for ref, name, params, builder in sites.values():
-        layer = ref()
-        if layer is None:
+    for layer in layers:
+        used = layer.__dict__.pop("_md_used", None) or {}
+        if not PACK_BATCH:
             continue
-        obj = layer._cached(name, params, builder, mark=False)
-        if hasattr(obj, "request"):
-            obj.request()
-            n += 1
+        for name, (params, builder) in used.items():
+            obj = layer._cached(name, params, builder, mark=False)
+            if hasattr(obj, "request"):
+                obj.request()
+                n += 1
     flush_packs()
     return n
 

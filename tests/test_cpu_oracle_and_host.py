@@ -185,6 +185,39 @@ def test_round3_entry_points_reject_bad_arguments_without_a_gpu(hip_lib):
     assert hip_ops.conv3_head_ok(12, 128, 64) and not hip_ops.conv3_head_ok(20, 64, 12) and not hip_ops.conv3_head_ok(36, 128, 64)
 
 
+def test_pack_site_registry_rebuilds_stale_entries_and_does_not_keep_layers_alive():
+    """hip_ops.prewarm_packs (start of a training forward): the cache entries used since the last prewarm are rebuilt once
+    when the parameters changed (PARAM_EPOCH), entries are re-registered by their next use, and the registry holds the layers
+    weakly (the builders reference their layer: a strong table would keep every model ever built alive)."""
+    import gc
+    import torch
+    from meshdiffusion_amd import hip_ops as ops
+    from meshdiffusion_amd.lib.diffusion.models import layers
+
+    class L(layers.HipLayer):
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.zeros(3))
+
+    ops.prewarm_packs()                       # start from an empty registry
+    calls = []
+    lay = L()
+    build = lambda: calls.append(1) or "obj"  # noqa: E731
+    assert lay._cached("a", [lay.w], build) == "obj" and len(calls) == 1
+    assert lay._cached("a", [lay.w], build) == "obj" and len(calls) == 1          # cache hit
+    ops.prewarm_packs()
+    assert len(calls) == 1                    # nothing changed: nothing rebuilt
+    lay._cached("a", [lay.w], build)
+    ops.bump_param_epoch()                    # what the fused optimizer does after its raw-pointer update
+    ops.prewarm_packs()
+    assert len(calls) == 2 and len(ops._PACK_LAYERS) == 0
+    lay._cached("a", [lay.w], build)          # already rebuilt: a hit, and registered again
+    assert len(calls) == 2 and len(ops._PACK_LAYERS) == 1
+    del lay
+    gc.collect()
+    assert len(ops._PACK_LAYERS) == 0
+
+
 def test_hip_path_refuses_cpu_tensors():
     from meshdiffusion_amd import _lib, hip_ops
     with pytest.raises(_lib.MeshDiffusionHipError):
