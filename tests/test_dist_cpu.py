@@ -12,6 +12,24 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _wire(o):
+    """Results travel through the multiprocessing queue BY VALUE (numpy): a torch tensor is sent as a shared-memory handle that
+    dies with the worker -- a parent that reads the queue after the worker has exited gets FileNotFoundError (seen 1 run in 5)."""
+    if isinstance(o, torch.Tensor):
+        return ("__t__", o.detach().cpu().numpy().copy())
+    if isinstance(o, (list, tuple)):
+        return type(o)(_wire(v) for v in o)
+    return o
+
+
+def _unwire(o):
+    if isinstance(o, tuple) and len(o) == 2 and isinstance(o[0], str) and o[0] == "__t__":
+        return torch.from_numpy(o[1])
+    if isinstance(o, (list, tuple)):
+        return type(o)(_unwire(v) for v in o)
+    return o
+
+
 def retry_rendezvous(fn):
     """The multi-process tests rendezvous over 127.0.0.1 on a port that was free a moment ago; on a busy host another
     process can grab it first (seen right after large file transfers).  One retry with a fresh port."""
@@ -54,7 +72,7 @@ def _worker(rank, world, port, total, q):
     assert (r, w) == (rank, world)
     out = parallel.sharded_sample(_stub_sampler, total, seed=100)
     local = parallel.sharded_sample(_stub_sampler, total, seed=100, gather=False)
-    q.put((rank, None if out is None else out.clone(), local.clone()))
+    q.put(_wire((rank, None if out is None else out.clone(), local.clone())))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -72,7 +90,7 @@ def test_sharded_sampling_two_ranks_gloo(total):
         p.start()
     res = {}
     for _ in range(2):
-        rank, out, local = q.get(timeout=120)
+        rank, out, local = _unwire(q.get(timeout=120))
         res[rank] = (out, local)
     for p in procs:
         p.join(timeout=60)
@@ -98,7 +116,7 @@ def _grad_worker(rank, world, port, q):
     shard = data[rank * 4:(rank + 1) * 4]
     flat = shard.mean(dim=0).clone()
     parallel.allreduce_grads_(flat)
-    q.put((rank, flat.clone()))
+    q.put(_wire((rank, flat.clone())))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -111,7 +129,7 @@ def test_grad_allreduce_equals_large_batch_gradient_gloo():
     procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = dict(q.get(timeout=120) for _ in range(2))
+    res = dict(_unwire(q.get(timeout=120)) for _ in range(2))
     for p in procs:
         p.join(timeout=60)
     codes = [p.exitcode for p in procs]
@@ -170,7 +188,7 @@ def _replica_worker(rank, world, port, q):
     assert red.stats["buckets"] == 2 and red.stats["bytes"] == 4 * fg.n
     for p, g in zip(net.parameters(), reduced):
         assert torch.allclose(p.grad, g, atol=1e-7)
-    q.put((rank, start, reduced))
+    q.put(_wire((rank, start, reduced)))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -187,7 +205,7 @@ def test_replica_broadcast_and_bucketed_grad_allreduce_gloo():
         p.start()
     res = {}
     for _ in range(2):
-        rank, start, grads = q.get(timeout=120)
+        rank, start, grads = _unwire(q.get(timeout=120))
         res[rank] = (start, grads)
     for p in procs:
         p.join(timeout=60)
@@ -338,7 +356,7 @@ def _accum_worker(rank, world, port, q):
         launched.append(len(red.pending))
     red.finish(params)
     assert launched[0] >= 1 and red.stats["buckets"] >= 3 and red.stats["bytes"] == 4 * fg.n
-    q.put((rank, [m for m in micro], fg.flat.clone()))
+    q.put(_wire((rank, [m for m in micro], fg.flat.clone())))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -355,7 +373,7 @@ def test_gradient_accumulation_two_micro_steps_flat_reducer_gloo():
         p.start()
     res = {}
     for _ in range(2):
-        rank, micro, flat = q.get(timeout=120)
+        rank, micro, flat = _unwire(q.get(timeout=120))
         res[rank] = (micro, flat)
     for p in procs:
         p.join(timeout=60)
