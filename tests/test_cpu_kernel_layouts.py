@@ -1,0 +1,104 @@
+"""Index arithmetic of the round-3 kernels restated in numpy (no GPU): the LDS images and lane mappings the HIP sources rely on
+are bijective, agree between the writing and the reading side, and keep the 16 lanes of a `ds_read_b128` group on 16 different
+16-byte bank groups (gfx950: 64 banks x 4 B = 16 groups of 16 B).  The formulas are copied from the kernels' comments; the
+GPU tests check the kernels themselves."""
+import numpy as np
+
+
+def _bank_groups_distinct(slots16):
+    """slots16: 16-byte slot indices read by the 16 lanes of one ds_read_b128 group."""
+    return len({int(s) % 16 for s in slots16}) == len(slots16)
+
+
+def test_winograd_epilogue_read_side_mapping():
+    """csrc/conv3_wino.hip epilogue: write side = MFMA layout (lane (j, h): column j, rows 8 q + 4 h + e), exchange row stride
+    36 floats; read side = lane (cq, yr) takes rows 4 cq .. 4 cq + 3 of the columns 4 yr + pr (pr < 4)."""
+    lanes = np.arange(64)
+    cq = (lanes & 3) | ((lanes >> 5) << 2)
+    yr = (lanes >> 2) & 7
+    # every (4-row group, column) of the 32 x 32 tile is read exactly once per wave and frequency
+    seen = {(int(c), int(4 * y + pr)) for c, y in zip(cq, yr) for pr in range(4)}
+    assert len(seen) == 8 * 32
+    # and the write side covers the same (row, column) set: rows 8 q + 4 h + e  ==  4 * (2 q + h) + e
+    j, h = lanes & 31, lanes >> 5
+    wrote = {(int(2 * q + hh), int(jj)) for jj, hh in zip(j, h) for q in range(4)}
+    assert wrote == seen
+    # bank groups: 16-byte slot of a read = (column * 36 + 4 cq) / 4 = 9 column + cq
+    for pr in range(4):
+        for g in range(4):
+            grp = lanes[16 * g:16 * g + 16]
+            assert _bank_groups_distinct(9 * (4 * yr[grp] + pr) + cq[grp])
+    # the write side (round-2 layout, unchanged): slot = 9 j + 2 q + h for the 16 lanes of a group (h fixed inside a group)
+    for q in range(4):
+        for g in range(4):
+            grp = lanes[16 * g:16 * g + 16]
+            assert _bank_groups_distinct(9 * j[grp] + 2 * q + h[grp])
+    # statistics: the four lanes that share a channel quad inside a DPP row are lane ^ 4, ^ 8, ^ 12 (row_ror 8 then row_ror 4)
+    for ln in range(64):
+        row = ln & ~15
+        mates = {row | ((ln + r) & 15) for r in (0, 4, 8, 12)}
+        assert {int(cq[m]) for m in mates} == {int(cq[ln])} and len({int(yr[m]) for m in mates}) == 4
+
+
+def test_stride2_slab_image_and_fragment_reads():
+    """csrc/conv3_s2.hip: slab row image = 9 even-x slots, 8 odd-x slots, 3 pad (20 slots); a fragment read of tap kw by the
+    output at x (8 per tile row) must find the input position 2 x + kw, and 16 lanes (8 x by 2 output rows) must not conflict."""
+    YH, ROW = 17, 20
+
+    def commit_slot(zl, hy, hx):
+        return (zl * YH + hy) * ROW + (hx & 1) * 9 + (hx >> 1)
+
+    def read_slot(wc, cm, j, kh, kw):
+        return (wc * YH + 2 * (cm * 4 + (j >> 3)) + kh) * ROW + (kw & 1) * 9 + (kw >> 1) + (j & 7)
+
+    slots = {commit_slot(zl, hy, hx) for zl in range(4) for hy in range(17) for hx in range(17)}
+    assert len(slots) == 4 * 17 * 17 and max(slots) < 4 * YH * ROW
+    pads = {(zl * YH + hy) * ROW + p for zl in range(4) for hy in range(17) for p in (17, 18, 19)}
+    assert not (slots & pads)                         # items beyond the slab are parked in pad slots
+    for wc in range(4):
+        for cm in range(2):
+            for kh in range(3):
+                for kw in range(3):
+                    for j in range(32):
+                        y, x = cm * 4 + (j >> 3), j & 7
+                        assert read_slot(wc, cm, j, kh, kw) == commit_slot(wc, 2 * y + kh, 2 * x + kw)
+                    for g in range(2):
+                        assert _bank_groups_distinct([read_slot(wc, cm, j, kh, kw) for j in range(16 * g, 16 * g + 16)])
+
+
+def test_head_and_stem_halo_images():
+    """csrc/conv3_head.hip / conv3_stem.hip: halo position p = hz * 80 + hy * 8 + hx of a 6 x 10 x 8 halo (no x halo: the taps
+    along x are folded into rows / channels); the fragment of tap (kd, kh) for output (z, y, x) reads halo (z + kd, y + kh, x)."""
+    for j in range(32):
+        for wc in range(4):
+            for half in range(2):                     # head: y half per wave; stem: column tile cm
+                for kd in range(3):
+                    for kh in range(3):
+                        y, x = half * 4 + (j >> 3), j & 7
+                        slot = ((wc * 10 + half * 4 + (j >> 3)) * 8 + (j & 7)) + (kd * 80 + kh * 8)
+                        assert slot == (wc + kd) * 80 + (y + kh) * 8 + x
+    for kd in range(3):
+        for kh in range(3):
+            for g in range(2):
+                assert _bank_groups_distinct([(j >> 3) * 8 + (j & 7) + kd * 80 + kh * 8 for j in range(16 * g, 16 * g + 16)])
+
+
+def test_tiled_weight_packer_covers_every_item_once():
+    """csrc/pack_batch.hip md_pack_tiled_kernel: blocks (16-row block rb, chunk cc) x tasks (tap, channel group g, row rr) write
+    items base and base + nt of the WPK layout [rt][cc][tap][kg][part 2][nt][8]: every item exactly once."""
+    rows, kdim, taps, nt, kc = 136, 96, 27, 128, 32
+    kg, ncc = kc // 8, -(-kdim // kc)
+    nrb = -(-rows // nt) * (nt // 16)
+    n_items = -(-rows // nt) * ncc * taps * kg * 2 * nt
+    hit = np.zeros(n_items, dtype=np.int32)
+    for lb in range(nrb * ncc):
+        rb, cc = lb % nrb, lb // nrb
+        for task in range(taps * kg * 16):
+            rr, tg = task % 16, task // 16
+            g, tap = tg % kg, tg // kg
+            row = rb * 16 + rr
+            rt, rin = row // nt, row % nt
+            base = ((((rt * ncc + cc) * taps + tap) * kg + g) * 2) * nt + rin
+            hit[base] += 1
+            hit[base + nt] += 1
+    assert hit.min() == 1 and hit.max() == 1
