@@ -14,6 +14,16 @@ int main(void) {
   if (md_pb16_bytes(8, 128, 64, 64, 64, 0, 1) != (int64_t)66 * 66 * 66 * 2 * 128 * 8 * 2) { printf("pb16 bytes\n"); ++fails; }
   if (md_gemm_conv(NULL, NULL) != MD_ERR_BAD_ARG) { printf("null args\n"); ++fails; }
   if (md_gn_stats(NULL, NULL, 1, 8, 1, 8, 0, NULL) != MD_ERR_BAD_ARG) { printf("gn_stats null\n"); ++fails; }
+  /* round-3 entry points: argument validation and the job record of md_pack_batch */
+  {
+    MdPackJob j;
+    char buf[64];
+    if (sizeof j != 88 || offsetof(MdPackJob, block0) != 48 || offsetof(MdPackJob, kind) != 84) { printf("MdPackJob layout\n"); ++fails; }
+    if (md_pack_batch(NULL, 1, 1, 0, NULL) != MD_ERR_BAD_ARG) { printf("pack_batch null\n"); ++fails; }
+    if (md_conv3_s2((const float*)buf, buf, (float*)buf, NULL, 0, NULL, 1, 48, 64, 64, 8, 8, 8, NULL) != MD_ERR_UNSUPPORTED) { printf("s2 cin\n"); ++fails; }
+    if (md_conv3_head((const float*)buf, NULL, buf, (float*)buf, 1, 64, 16, 8, 8, 8, NULL) != MD_ERR_BAD_ARG) { printf("head ac\n"); ++fails; }
+    if (md_conv3_stem(buf, buf, (float*)buf, NULL, NULL, NULL, 1, 12, 8, 8, 8, NULL) != MD_ERR_UNSUPPORTED) { printf("stem cout\n"); ++fails; }
+  }
   printf("sizeof(MdGemmConvArgs)=%zu stats@%zu %s\n", sizeof a, offsetof(MdGemmConvArgs, stats), fails ? "FAIL" : "ok");
   return fails;
 }
