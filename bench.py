@@ -7,6 +7,7 @@ data.  Sampling shards over GPUs as independent sample batches: no data-path col
 ("scaling": "weak", batch per GPU fixed).
 
     python bench.py --gpus 1 --steps 5 --warmup 2
+    python bench.py --gpus 8 --steps 20 --warmup 3      # no launcher around it: starts the 8 ranks itself (self_launch)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -67,13 +68,39 @@ def parse():
     return ap.parse_args()
 
 
+def self_launch(a):
+    """`python bench.py --gpus N` without a launcher around it: re-execute this command line under
+    torch.distributed.run with N ranks on this node (one process per GPU, RCCL; gloo for --dry-run) and pass its exit
+    code on.  Fails loudly when the node has fewer than N devices: a 1-rank line must never stand in for an N-GPU record."""
+    import socket
+    import subprocess
+    if not a.dry_run:
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < a.gpus:
+            raise SystemExit(f"bench.py --gpus {a.gpus}: this node has {have} visible GPU(s); refusing to run fewer ranks")
+    with socket.socket() as so:          # a free rendezvous port on the loopback interface
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this driver (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "8")
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
+
+
 def main():
     a = parse()
+    if a.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(a)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != a.gpus and world > 1:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {a.gpus} "
+                         "(or leave WORLD_SIZE unset and bench.py starts the ranks itself)")
     if a.dry_run:
         return dry_run(a, rank, world)
     if not torch.cuda.is_available():
@@ -85,6 +112,10 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if dist.get_world_size() != a.gpus:
+            raise SystemExit(f"--gpus {a.gpus} but the process group has {dist.get_world_size()} ranks")
+        if torch.cuda.device_count() < world:
+            raise SystemExit(f"{world} ranks but {torch.cuda.device_count()} visible GPU(s): one process per GPU")
 
     from meshdiffusion_amd import hip_ops, synth
     from meshdiffusion_amd.config import get_config_res64
@@ -261,7 +292,8 @@ def main():
             cpu = cpu_baseline(sd_cpu, cfg, synth)
         line = {
             "metric": "denoise steps/sec on 64^3x4 DMTet grids (sample-steps/s = n_gpus*batch*steps/wall)",
-            "value": round(value, 3), "unit": "sample-steps/s", "n_gpus": world, "steps": a.steps,
+            "value": round(value, 3), "unit": "sample-steps/s",
+            "n_gpus": dist.get_world_size() if dist is not None else 1, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": ("bf16x3 (split-bf16 MFMA operands, fp32 accumulate/IO)" if a.precision == "bf16x3" else
                                            "fp16x2 (weights split fp16, activations fp16, fp32 accumulate/IO)"),
@@ -395,6 +427,15 @@ def train_step_bench(a, cfg, model, rank, world, dev, dist, barrier):
         dist.all_reduce(wt, op=dist.ReduceOp.MAX)
     s_per_step = float(wt) / a.train_steps
     ex = state.get("exchange") or {}
+    # every rank's own exchange record (buckets, bytes, exposed wait of the instrumented step): rank 0 prints them all
+    mine = torch.tensor([float(ex.get("buckets", 0)), float(ex.get("bytes", 0)), float(split.get("exchange_exposed", 0.0)),
+                         float(split.get("bwd", 0.0))], dtype=torch.float64, device=dev)
+    per_rank = [mine]
+    if dist is not None:
+        per_rank = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(per_rank, mine)
+    per_rank = [{"rank": r, "buckets": int(v[0]), "bytes": int(v[1]), "exchange_exposed_ms": round(float(v[2]), 2),
+                 "backward_ms": round(float(v[3]), 2)} for r, v in enumerate(per_rank)]
     return {"workload": "BASELINE configs[2] per GPU: res64 training step (fwd + loss + bwd + grad exchange + clip + Adam + EMA), "
                         f"batch {B} per GPU, dropout {cfg.model.dropout}",
             "value": round(world * B / s_per_step, 3), "unit": "samples/s", "n_gpus": world, "steps": a.train_steps,
@@ -404,7 +445,7 @@ def train_step_bench(a, cfg, model, rank, world, dev, dist, barrier):
             "exchange": {"collective": "RCCL all-reduce (AVG) of fp32 gradients, in place on the flat gradient buffer"
                                        if world > 1 else "none (single rank)",
                          "buckets": ex.get("buckets", 0), "bytes": ex.get("bytes", 0), "bucket_cap_bytes": 128 << 20,
-                         "exposed_ms": round(split.get("exchange_exposed", 0.0), 2)},
+                         "exposed_ms": round(split.get("exchange_exposed", 0.0), 2), "per_rank": per_rank},
             "loss": [round(float(v.detach()), 5) for v in losses_seen],
             "peak_hbm_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1), "optimizer": "reference objects (torch.optim.Adam state, EMA shadow params, optimization_manager hyper-parameters) executed by "
                          "md_grad_sqnorm + md_adam_ema_step over flat buffers (MD_FUSED_OPT=0: torch kernels)"}
@@ -485,12 +526,16 @@ def dry_run(a, rank, world):
         dist.init_process_group("gloo", rank=rank, world_size=world)
         dist.barrier()
     wall_t = torch.tensor([0.1 * (rank + 1)], dtype=torch.float64)
+    ranks = 1
     if world > 1:
         dist.all_reduce(wall_t, op=dist.ReduceOp.MAX)
         dist.barrier()
+        ranks = dist.get_world_size()        # what the line reports is what the process group holds, not the flag
+        if ranks != a.gpus:
+            raise SystemExit(f"--gpus {a.gpus} but the process group has {ranks} ranks")
     if rank == 0:
         wall = float(wall_t.item())
-        print(json.dumps({"metric": "dry-run", "value": world * a.batch * a.steps / wall, "n_gpus": world,
+        print(json.dumps({"metric": "dry-run", "value": ranks * a.batch * a.steps / wall, "n_gpus": ranks,
                           "steps": a.steps, "warmup": a.warmup, "max_wall": wall}), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -240,6 +240,38 @@ def test_bench_multi_process_control_flow_dry_run():
     assert d["n_gpus"] == 2 and abs(d["max_wall"] - 0.2) < 1e-9 and d["value"] == 2 * 8 * 3 / 0.2
 
 
+@retry_rendezvous
+def test_bench_gpus_flag_starts_its_own_ranks():
+    """plain `python bench.py --gpus 2` (no torchrun around it, WORLD_SIZE unset) must come up with two
+    ranks -- it re-executes itself under torch.distributed.run -- and report n_gpus from the process group."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                          "--dry-run"], capture_output=True, text=True, timeout=240, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and abs(d["max_wall"] - 0.2) < 1e-9 and d["value"] == 2 * 8 * 3 / 0.2
+
+
+def test_bench_refuses_fewer_ranks_than_gpus_flag():
+    """A 1-rank run must never print a line for --gpus N: a WORLD_SIZE that disagrees with the flag (also WORLD_SIZE=1),
+    or fewer devices than ranks on the real path, exits non-zero without a JSON line."""
+    import subprocess
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dry-run"], capture_output=True,
+                         text=True, timeout=120, cwd=ROOT, env=env)
+    assert out.returncode != 0 and "WORLD_SIZE=1" in out.stderr and "{" not in out.stdout
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], capture_output=True,
+                         text=True, timeout=120, cwd=ROOT, env=env)     # no --dry-run: this container has no GPU at all
+    import torch
+    if torch.cuda.device_count() < 2:
+        assert out.returncode != 0 and "refusing to run fewer ranks" in out.stderr and "{" not in out.stdout
+
+
 def _evaler_worker(rank, world, port, tmp, total):
     """One rank of `main_diffusion.py --mode=uncond_gen` / cond_gen under torchrun; the sampler is a stub (the HIP path
     needs a GPU; tests/test_gpu_dist.py runs the same flow through the real kernels)."""
