@@ -139,6 +139,8 @@ class PackedWeight:
         if self._data is None:
             self.request()
             flush_packs()
+            if self._data is None:
+                raise _lib.MeshDiffusionHipError("packed weight requested but not produced by flush_packs()")
         return self._data
 
 
@@ -153,6 +155,18 @@ def flush_packs():
     if not _PACK_QUEUE:
         return
     queue, _PACK_QUEUE = _PACK_QUEUE, []
+    try:
+        _flush(queue)
+    except BaseException:
+        # an allocation or a launch failed midway: no owner may stay "queued" without a job behind it (request() would be a
+        # no-op and .data would hand out None from then on) -- they go back to "not packed" and the next access retries
+        for owner, _ in queue:
+            if owner._data is None:
+                owner._queued = False
+        raise
+
+
+def _flush(queue):
     lib = _lib.load()
     outs = []
     for owner, j in queue:
@@ -231,9 +245,14 @@ def prewarm_packs():
         used = layer.__dict__.pop("_md_used", None) or {}
         if not PACK_BATCH:
             continue
+        cache = layer.__dict__.get("_md_cache") or {}
         for name, (params, builder) in used.items():
+            old = cache.get(name)
+            # only what the previous step CONSUMED: a layer on the Winograd path looks its direct-tile entry up for
+            # rows / kdim but never reads `.data` -- packing those tiles every step would cost ~4 B per parameter for nothing
+            consumed = old is not None and getattr(old[1], "_data", None) is not None
             obj = layer._cached(name, params, builder, mark=False)
-            if hasattr(obj, "request"):
+            if consumed and hasattr(obj, "request"):
                 obj.request()
                 n += 1
     flush_packs()
@@ -365,6 +384,8 @@ class WinoWeight:
         if self._data is None:
             self.request()
             flush_packs()
+            if self._data is None:
+                raise _lib.MeshDiffusionHipError("packed weight requested but not produced by flush_packs()")
         return self._data
 
 

@@ -117,10 +117,13 @@ def conv3_wino_packed(layer, name, conv):
     return lambda: layer._cached(f"{name}/wino", [conv.weight], lambda: ops.WinoWeight(conv.weight, conv.weight.device))
 
 
-def fused_operand_ok(pw):
+def fused_operand_ok(pw, ups=0):
     """True when a conv on packed weights `pw` can take its input as fp32 F32B parts and apply GroupNorm + SiLU + the
-    bf16 split itself (MD_B_F32B_GN: the dedicated kernel, or the 4^3-level tile of the generic kernel; bf16x3 arithmetic)."""
-    return ops.FUSE_GN_APPLY and pw.cfg in (ops.CFG_C3_128_FAST, ops.CFG_C3_LOW) and pw.prec == ops.PREC_BF16X3
+    bf16 split itself (MD_B_F32B_GN: the dedicated kernel, or the 4^3-level tile of the generic kernel; bf16x3 arithmetic).
+    The generic tile's fused loader has no nearest-x2 fold (launch_cfg: MD_ERR_UNSUPPORTED for BF && ups), so an Upsample
+    onto a 4^3 grid stays on the split path."""
+    cfgs = (ops.CFG_C3_128_FAST,) if ups else (ops.CFG_C3_128_FAST, ops.CFG_C3_LOW)
+    return ops.FUSE_GN_APPLY and pw.cfg in cfgs and pw.prec == ops.PREC_BF16X3
 
 
 def run_conv3(pw, act_s16, B, S_out, *, bias=None, bias_bstride=0, residual=None, res_bstride=None, ups=0,
@@ -302,7 +305,7 @@ class Upsample(HipLayer):
     def forward_blocked(self, x, Cc, B, P, tape=None):
         s_out = 2 * _spatial_edge(P)
         pw = conv3_packed(self, "w", self.Conv_0, ops.conv_cfg_for(s_out))
-        if tape is None and fused_operand_ok(pw) and pw.kdim == Cc:   # the conv splits the raw fp32 input while loading it
+        if tape is None and fused_operand_ok(pw, ups=1) and pw.kdim == Cc:   # the conv splits the raw fp32 input while loading it
             return run_conv3(pw, None, B, s_out, bias=self.Conv_0.bias, ups=1, want_stats=True,
                              b_f32=dict(parts=[(x, Cc)], ac=None, silu=False), wino=conv3_wino_packed(self, "w", self.Conv_0))
         fw = None

@@ -64,19 +64,27 @@ def sharded_sample(sample_fn, total_batch, seed, gather=True):
         return local
     # all ranks must contribute equal-shaped buffers: pad the shard to the largest size
     ref = local if local is not None else None
+    # slot 0: rank count of dims, 1..6: shape, 7: dtype code -- the gather keeps the shard's OWN dtype (the DDIM sampler
+    # returns float64 state like the reference: a world-size-dependent cast would change the written .npy)
+    codes = {torch.float32: 1, torch.float64: 2, torch.float16: 3, torch.bfloat16: 4}
     shape_t = torch.zeros(8, dtype=torch.int64)
     if ref is not None:
+        assert ref.dim() <= 6 and ref.dtype in codes, (ref.shape, ref.dtype)
         shape_t[0] = ref.dim()
         shape_t[1:1 + ref.dim()] = torch.tensor(ref.shape)
+        shape_t[7] = codes[ref.dtype]
     # RCCL moves device buffers; gloo gathers through host memory (also when the shards live on a GPU)
     dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
     shape_t = shape_t.to(dev)
     dist.all_reduce(shape_t, op=dist.ReduceOp.MAX)
     nd = int(shape_t[0])
     full = [int(v) for v in shape_t[1:1 + nd]]
-    buf = torch.zeros([max(sizes)] + full[1:], dtype=torch.float32, device=dev)
+    dtype = {v: k for k, v in codes.items()}[int(shape_t[7])]
+    if local is not None and local.dtype != dtype:
+        raise RuntimeError(f"sharded_sample: rank {rank} sampled {local.dtype}, another rank {dtype}")
+    buf = torch.zeros([max(sizes)] + full[1:], dtype=dtype, device=dev)
     if local is not None:
-        buf[:sizes[rank]] = local.to(dev, torch.float32)
+        buf[:sizes[rank]] = local.to(dev)
     out = [torch.empty_like(buf) for _ in range(world)] if rank == 0 else None
     dist.gather(buf, out, dst=0)
     if rank != 0:

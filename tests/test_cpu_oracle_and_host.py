@@ -218,6 +218,82 @@ def test_pack_site_registry_rebuilds_stale_entries_and_does_not_keep_layers_aliv
     assert len(ops._PACK_LAYERS) == 0
 
 
+def test_prewarm_requests_only_consumed_packs_and_failed_flush_resets_owners(monkeypatch):
+    """(a) prewarm_packs re-queues only cache entries whose tiles were read in the previous step (a layer on
+    the Winograd path looks its direct-tile entry up for rows / kdim only); (b) a flush that raises midway leaves no owner
+    marked queued-without-a-job, and `.data` raises instead of handing out None."""
+    import torch
+    from meshdiffusion_amd import _lib, hip_ops as ops
+    from meshdiffusion_amd.lib.diffusion.models import layers
+
+    class Pack:                                # the protocol of PackedWeight / WinoWeight without a device
+        made = []
+
+        def __init__(self):
+            self._data, self._queued, self.requests = None, False, 0
+            Pack.made.append(self)
+
+        def request(self):
+            if self._data is None and not self._queued:
+                self._queued = True
+                self.requests += 1
+                ops._PACK_QUEUE.append((self, dict(nbytes=32, w=torch.zeros(1))))
+
+    class L(layers.HipLayer):
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.zeros(3))
+
+    ops.prewarm_packs()
+    ops._PACK_QUEUE.clear()
+    done = []
+    monkeypatch.setattr(ops, "_flush", lambda queue: done.extend(queue) or [setattr(o, "_data", "tiles") or setattr(o, "_queued", False)
+                                                                            for o, _ in queue])
+    lay = L()
+    looked_up = lay._cached("direct", [lay.w], Pack)      # consulted for its shape only: never read
+    read = lay._cached("wino", [lay.w], Pack)
+    read.request(); ops.flush_packs()
+    assert read._data == "tiles" and looked_up._data is None
+    ops.bump_param_epoch()
+    ops.prewarm_packs()
+    new_direct, new_wino = lay._cached("direct", [lay.w], Pack), lay._cached("wino", [lay.w], Pack)
+    assert new_direct is not looked_up and new_wino is not read          # both rebuilt for the new weights ...
+    assert new_wino._data == "tiles" and new_direct.requests == 0 and new_direct._data is None   # ... only the consumed one packed
+
+    def boom(queue):
+        raise RuntimeError("out of memory")
+    monkeypatch.setattr(ops, "_flush", boom)
+    ops._PACK_QUEUE.clear()
+    a, b = Pack(), Pack()
+    a.request(); b.request()
+    with pytest.raises(RuntimeError):
+        ops.flush_packs()
+    assert not a._queued and not b._queued and ops._PACK_QUEUE == []    # the next access retries instead of returning None
+    a.request()
+    assert a._queued and len(ops._PACK_QUEUE) == 1
+    ops._PACK_QUEUE.clear()
+    # the real classes raise when a flush produced nothing
+    pw = ops.PackedWeight.__new__(ops.PackedWeight)
+    pw._data, pw._queued = None, True
+    monkeypatch.setattr(ops, "flush_packs", lambda: None)
+    with pytest.raises(_lib.MeshDiffusionHipError):
+        pw.data
+
+
+def test_upsample_onto_4cube_grid_stays_off_the_fused_generic_loader():
+    """the generic tile's fused fp32 loader has no nearest-x2 fold; fused_operand_ok(pw, ups=1) must say no for
+    CFG_C3_LOW (a model deep enough to upsample 2^3 -> 4^3) while the plain conv on a 4^3 grid keeps the fused loader."""
+    from types import SimpleNamespace
+    from meshdiffusion_amd import hip_ops as ops
+    from meshdiffusion_amd.lib.diffusion.models import layers
+    low = SimpleNamespace(cfg=ops.CFG_C3_LOW, prec=ops.PREC_BF16X3)
+    fast = SimpleNamespace(cfg=ops.CFG_C3_128_FAST, prec=ops.PREC_BF16X3)
+    assert ops.conv_cfg_for(4) == ops.CFG_C3_LOW
+    if ops.FUSE_GN_APPLY:
+        assert layers.fused_operand_ok(low) and not layers.fused_operand_ok(low, ups=1)
+        assert layers.fused_operand_ok(fast) and layers.fused_operand_ok(fast, ups=1)
+
+
 def test_hip_path_refuses_cpu_tensors():
     from meshdiffusion_amd import _lib, hip_ops
     with pytest.raises(_lib.MeshDiffusionHipError):

@@ -63,6 +63,10 @@ def _stub_sampler(local_batch, seed):
     return torch.randn((local_batch, 4, 4, 4, 4), generator=g)
 
 
+def _stub_sampler_f64(local_batch, seed):      # the DDIM sampler's state is float64 like the reference's
+    return _stub_sampler(local_batch, seed).double() / 3.0
+
+
 def _worker(rank, world, port, total, q):
     sys.path.insert(0, ROOT)
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
@@ -72,6 +76,11 @@ def _worker(rank, world, port, total, q):
     assert (r, w) == (rank, world)
     out = parallel.sharded_sample(_stub_sampler, total, seed=100)
     local = parallel.sharded_sample(_stub_sampler, total, seed=100, gather=False)
+    out64 = parallel.sharded_sample(_stub_sampler_f64, total, seed=100)
+    if rank == 0:     # the gathered file keeps the sampler's dtype and bits whatever the world size
+        sizes = parallel.shard_sizes(total, world)
+        want = torch.cat([_stub_sampler_f64(sizes[r], 100 + r) for r in range(world)], 0)
+        assert out64.dtype == torch.float64 and torch.equal(out64, want)
     q.put(_wire((rank, None if out is None else out.clone(), local.clone())))
     dist.barrier()
     dist.destroy_process_group()
