@@ -12,8 +12,7 @@
  *     pointers owned by the caller (PyTorch allocator); the library never
  *     allocates, frees or retains device memory.
  *   - every call is asynchronous on `stream` (a hipStream_t passed as void*),
- *     re-entrant and stateless (the one exception is md_wgrad_set_debug, a
- *     process-wide profiling knob that production code never calls).
+ *     re-entrant and stateless.
  *   - return value: 0 = ok, negative = MD_ERR_*, positive = hipError_t.
  *
  * Device tensor layouts (see DESIGN.md "Data layout in HBM")
@@ -57,9 +56,7 @@ enum {
   MD_CFG_C3_128_V2 = 8,  /* C3_128 + conflict-free halo layout + software-pipelined loads     */
   MD_CFG_C3_128_SW = 9,  /* (A/B) conflict-free halo layout only                              */
   MD_CFG_C3_128_PIPE = 10, /* (A/B) pipelined loads only                                       */
-  MD_CFG_C3_128_V3 = 11, /* retired r01 experiment (weights L2->registers): MD_ERR_UNSUPPORTED                */
-  MD_CFG_C3_128_V3B = 12, /* retired                                                         */
-  MD_CFG_C3_128_V4 = 13, /* retired (its mid-step barrier lives on in MD_CFG_C3_128_FAST)                    */
+  /* 11..13: reserved (ids of retired experiments; md_gemm_conv answers MD_ERR_UNSUPPORTED)                  */
   MD_CFG_C3_128_FAST = 14, /* dedicated kernel for the hot conv: C3_128_V2 layout, taps unrolled, F32B out */
   MD_CFG_C5_128_K16 = 15, /* 5x5x5 s1 pad 2, tile 4x8x8, NT=128, KC=16 (ddpm_res128 stem / mask_layer)  */
   MD_CFG_C5_32_K16 = 16,  /* 5x5x5 s1 pad 2, tile 4x8x8, NT=32,  KC=16 (ddpm_res128 head)               */
@@ -468,7 +465,6 @@ int md_wgrad_finish(const float* g, float* dw, int32_t rows, int32_t cols, int32
  * accumulate; the contraction is split into `ksplit` position ranges whose partial sums live in `workspace`
  * (md_wgrad_workspace_bytes) and are reduced in a fixed order, so results are run-to-run identical.
  */
-void md_wgrad_set_debug(int32_t flags);   /* profiling ablations only (tools/bench_wgrad.py); 0 = normal */
 int64_t md_wgrad_workspace_bytes(int32_t rows, int32_t cols, int32_t taps, int32_t ksplit);
 int md_wgrad(const void* dy_pb, const void* act_pb, float* dw, void* workspace, int64_t workspace_bytes, int32_t batch,
              int32_t a_ch, int32_t b_ch, int32_t rows, int32_t cols, int32_t D, int32_t H, int32_t W, int32_t guard,

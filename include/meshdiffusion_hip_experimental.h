@@ -26,6 +26,14 @@ int md_conv3_wino43(const void* t_in, const void* wpk, float* out, const float* 
                     const float* residual, int64_t res_bstride, double* stats, int32_t batch, int32_t cin, int32_t cout,
                     int32_t D, int32_t H, int32_t W, void* stream);
 
+/*
+ * ABLATION BUILDS ONLY (MD_BUILD_ABLATIONS=1; tools/bench_wgrad.py): selects a timing-only instantiation of md_wgrad for the
+ * following launches of this process (0 = normal).  A process-wide knob, which is why it is not part of the default library,
+ * whose entry points are stateless.  The same builds accept the timing-only md_gemm_conv configuration ids 101..122
+ * (tools/bench_conv.py) and the md_conv3_wino `variant` values other than 0 (tools/bench_wino.py).
+ */
+void md_wgrad_set_debug(int32_t flags);
+
 #ifdef __cplusplus
 }
 #endif

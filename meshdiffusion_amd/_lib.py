@@ -12,7 +12,9 @@ LIB_PATH = os.path.join(_HERE, "libmeshdiffusion_hip.so")
 
 # MD_CFG_* (include/meshdiffusion_hip.h)
 (CFG_C3_128, CFG_C3_128_K16, CFG_C3_32, CFG_C3_LOW, CFG_C3_S2, CFG_G1_128, CFG_G1_128_LOW, CFG_G1_64_LOW,
- CFG_C3_128_V2, CFG_C3_128_SW, CFG_C3_128_PIPE, CFG_C3_128_V3, CFG_C3_128_V3B, CFG_C3_128_V4, CFG_C3_128_FAST, CFG_C5_128_K16, CFG_C5_32_K16, CFG_C3_128_W4, CFG_C3X_32, CFG_C5X_32_K16, CFG_C3X_128_K16, CFG_C5X_128, CFG_G1_128_N128) = range(23)
+ CFG_C3_128_V2, CFG_C3_128_SW, CFG_C3_128_PIPE) = range(11)          # 11..13 reserved (retired experiments)
+(CFG_C3_128_FAST, CFG_C5_128_K16, CFG_C5_32_K16, CFG_C3_128_W4, CFG_C3X_32, CFG_C5X_32_K16, CFG_C3X_128_K16, CFG_C5X_128,
+ CFG_G1_128_N128) = range(14, 23)
 OUT_F32B, OUT_S16B, OUT_NCDHW = 0, 1, 2
 PREC_BF16X3, PREC_FP16X2 = 0, 1
 A_PACKED, A_S16B = 0, 1
@@ -24,8 +26,9 @@ CFG_NT_KC = {
     CFG_C3_S2: (128, 32), CFG_G1_128: (128, 32), CFG_G1_128_LOW: (128, 32), CFG_G1_64_LOW: (64, 32),
     CFG_C3_128_V2: (128, 32), CFG_C3_128_SW: (128, 32), CFG_C3_128_PIPE: (128, 32),
     CFG_C3_128_FAST: (128, 32), CFG_C5_128_K16: (128, 16), CFG_C5_32_K16: (32, 16), CFG_C3_128_W4: (128, 32), CFG_C3X_32: (32, 32), CFG_C5X_32_K16: (32, 16), CFG_C3X_128_K16: (128, 16), CFG_C5X_128: (128, 32), CFG_G1_128_N128: (128, 32),
-    101: (128, 32), 102: (128, 32), 103: (128, 32), 104: (128, 32), 105: (128, 32), 111: (128, 32), 113: (128, 32), 114: (128, 32), 116: (128, 32), 117: (128, 32), 118: (128, 32), 122: (128, 32),   # timing-only ablations of C3_128_V2
 }
+# timing-only ablation ids of C3_128_V2 / C3_128_FAST: known to MD_BUILD_ABLATIONS=1 libraries only (tools/bench_conv.py)
+ABLATION_CFG_NT_KC = {c: (128, 32) for c in (101, 102, 103, 104, 105, 111, 113, 114, 116, 117, 118, 122)}
 
 
 class MdGemmConvArgs(C.Structure):
@@ -104,7 +107,6 @@ SIGNATURES = {
     "md_pb16_bytes": (_I64, [_I32, _I32, _I32, _I32, _I32, _I32, _I32]),
     "md_to_pb16": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P]),
     "md_wgrad_finish": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _I32, _I64, _I64, _I64, _P]),
-    "md_wgrad_set_debug": (None, [_I32]),
     "md_wgrad_workspace_bytes": (_I64, [_I32, _I32, _I32, _I32]),
     "md_wgrad": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I64, _I64,
                            _I64, _P]),
@@ -128,6 +130,8 @@ EXPERIMENTAL_SIGNATURES = {
     "md_wino43_pack_weights": (C.c_int, [_P, _P, _I32, _I32, _I64, _I64, _I32, _P]),
     "md_conv3_wino43": (C.c_int, [_P, _P, _P, _P, _I64, _P, _I64, _P, _I32, _I32, _I32, _I32, _I32, _I32, _P]),
 }
+# MD_BUILD_ABLATIONS=1 builds only (same header)
+ABLATION_SIGNATURES = {"md_wgrad_set_debug": (None, [_I32])}
 
 _lib = None
 
@@ -156,13 +160,15 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    for name, (res, args) in EXPERIMENTAL_SIGNATURES.items():
+    for name, (res, args) in list(EXPERIMENTAL_SIGNATURES.items()) + list(ABLATION_SIGNATURES.items()):
         fn = getattr(lib, name, None)
         if fn is not None:
             fn.restype = res
             fn.argtypes = args
     if lib.md_abi_version() != ABI_VERSION:
         raise MeshDiffusionHipError(f"ABI version mismatch: library {lib.md_abi_version()}, host code {ABI_VERSION}")
+    if hasattr(lib, "md_wgrad_set_debug"):       # an ablation build: its extra configuration ids are usable
+        CFG_NT_KC.update(ABLATION_CFG_NT_KC)
     for cfg, (nt, kc) in CFG_NT_KC.items():
         v = [C.c_int32() for _ in range(6)]
         lib.md_gemm_conv_cfg_info(cfg, *[C.byref(x) for x in v])

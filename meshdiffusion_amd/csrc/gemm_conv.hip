@@ -725,7 +725,8 @@ static void cfg_info(int32_t* nt, int32_t* kc, int32_t* cols, int32_t* taps, int
     case MD_CFG_C3_128_W4: F<Cfg_C3_128_W4>(__VA_ARGS__); break;    \
     case MD_CFG_C3_128_V2: F<Cfg_C3_128_V2>(__VA_ARGS__); break;    \
     case MD_CFG_C3_128_SW: F<Cfg_C3_128_SW>(__VA_ARGS__); break;    \
-    case MD_CFG_C3_128_PIPE: F<Cfg_C3_128_PIPE>(__VA_ARGS__); break; \
+    case MD_CFG_C3_128_PIPE: F<Cfg_C3_128_PIPE>(__VA_ARGS__); break;
+#define MD_CFG_CASES_TIMING(F, ...)                                 \
     case 101: F<Cfg_ABL1>(__VA_ARGS__); break;                      \
     case 102: F<Cfg_ABL2>(__VA_ARGS__); break;                      \
     case 103: F<Cfg_ABL3>(__VA_ARGS__); break;                      \
@@ -733,14 +734,22 @@ static void cfg_info(int32_t* nt, int32_t* kc, int32_t* cols, int32_t* taps, int
     case 105: F<Cfg_ABL5>(__VA_ARGS__); break;
 #ifdef MD_BUILD_ABLATIONS
 #define MD_CFG_SWITCH_LAUNCH(cfg, F, ...) \
-  switch (cfg) { MD_CFG_CASES_PROD(F, __VA_ARGS__) MD_CFG_CASES_ABL(F, __VA_ARGS__) default: return MD_ERR_UNSUPPORTED; }
+  switch (cfg) { MD_CFG_CASES_PROD(F, __VA_ARGS__) MD_CFG_CASES_ABL(F, __VA_ARGS__) MD_CFG_CASES_TIMING(F, __VA_ARGS__) default: return MD_ERR_UNSUPPORTED; }
 #else
 #define MD_CFG_SWITCH_LAUNCH(cfg, F, ...) \
   switch (cfg) { MD_CFG_CASES_PROD(F, __VA_ARGS__) default: return MD_ERR_UNSUPPORTED; }
 #endif
-// geometry queries never instantiate a kernel: every configuration answers
+// geometry queries never instantiate a kernel: every configuration of the header answers (the timing-only ids 101..127 in
+// ablation builds only)
+#ifdef MD_BUILD_ABLATIONS
+#define MD_CFG_SWITCH_INFO(cfg, F, ...) \
+  switch (cfg) { MD_CFG_CASES_PROD(F, __VA_ARGS__) MD_CFG_CASES_ABL(F, __VA_ARGS__) MD_CFG_CASES_TIMING(F, __VA_ARGS__) default: return MD_ERR_UNSUPPORTED; }
+#define MD_CFG_IS_TIMING_FAST(c) ((c) >= 111 && (c) <= 127)
+#else
 #define MD_CFG_SWITCH_INFO(cfg, F, ...) \
   switch (cfg) { MD_CFG_CASES_PROD(F, __VA_ARGS__) MD_CFG_CASES_ABL(F, __VA_ARGS__) default: return MD_ERR_UNSUPPORTED; }
+#define MD_CFG_IS_TIMING_FAST(c) false
+#endif
 
 int md_launch_conv3_main(const MdGemmConvArgs& a, hipStream_t stream);  // conv3_main.hip
 
@@ -749,7 +758,7 @@ extern "C" int md_gemm_conv(const MdGemmConvArgs* args, void* stream) {
     return MD_ERR_BAD_ARG;
   int rc = MD_OK;
   hipStream_t st = (hipStream_t)stream;
-  if (args->cfg == MD_CFG_C3_128_FAST || (args->cfg >= 111 && args->cfg <= 127)) return md_launch_conv3_main(*args, st);
+  if (args->cfg == MD_CFG_C3_128_FAST || MD_CFG_IS_TIMING_FAST(args->cfg)) return md_launch_conv3_main(*args, st);
   if (args->stats != nullptr && !(args->ksplit > 1 && args->out_mode == MD_OUT_F32B))
     return MD_ERR_UNSUPPORTED;   // statistics: the dedicated 3x3x3 kernel's epilogue, or the split-K finish (md_splitk_reduce_stats_kernel)
   MD_CFG_SWITCH_LAUNCH(args->cfg, rc = launch_cfg, *args, st);
@@ -758,7 +767,7 @@ extern "C" int md_gemm_conv(const MdGemmConvArgs* args, void* stream) {
 
 extern "C" int md_gemm_conv_cfg_info(int32_t cfg, int32_t* nt, int32_t* kc, int32_t* cols,
                                      int32_t* taps, int32_t* lds_bytes, int32_t* threads) {
-  if (cfg == MD_CFG_C3_128_FAST || (cfg >= 111 && cfg <= 127)) cfg = MD_CFG_C3_128_V2;  // same tile geometry and LDS image  // same tile geometry and LDS image
+  if (cfg == MD_CFG_C3_128_FAST || MD_CFG_IS_TIMING_FAST(cfg)) cfg = MD_CFG_C3_128_V2;  // same tile geometry and LDS image
   MD_CFG_SWITCH_INFO(cfg, cfg_info, nt, kc, cols, taps, lds_bytes, threads);
   return MD_OK;
 }

@@ -302,8 +302,12 @@ __global__ __launch_bounds__(256) void md_wgrad_reduce27_kernel(const float* __r
 
 }  // namespace
 
+#ifdef MD_BUILD_ABLATIONS      // include/meshdiffusion_hip_experimental.h: a process-wide knob, absent from the default library
 static int md_wgrad_debug = 0;
 extern "C" void md_wgrad_set_debug(int32_t flags) { md_wgrad_debug = flags; }
+#else
+static constexpr int md_wgrad_debug = 0;
+#endif
 
 static int md_wgrad_slots(int taps) { return taps == 1 ? 1 : (taps == 27 ? 27 : (taps == 125 ? 150 : -1)); }
 
@@ -351,9 +355,11 @@ extern "C" int md_wgrad(const void* dy_pb, const void* act_pb, float* dw, void* 
   const hipStream_t hs = (hipStream_t)stream;
   if (taps != 1 && full) {
     switch (md_wgrad_debug) {   // timing ablations exist for the dominant instantiation only
+#ifdef MD_BUILD_ABLATIONS
       case 1: hipLaunchKernelGGL((md_wgrad_kernel<3, true, 1>), grid, blk, 0, hs, g); break;
       case 2: hipLaunchKernelGGL((md_wgrad_kernel<3, true, 2>), grid, blk, 0, hs, g); break;
       case 3: hipLaunchKernelGGL((md_wgrad_kernel<3, true, 3>), grid, blk, 0, hs, g); break;
+#endif
       default: hipLaunchKernelGGL((md_wgrad_kernel<3, true, 0>), grid, blk, 0, hs, g); break;
     }
   } else if (taps != 1) hipLaunchKernelGGL((md_wgrad_kernel<3, false, 0>), grid, blk, 0, hs, g);

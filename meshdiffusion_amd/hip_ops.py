@@ -10,7 +10,7 @@ import os
 import torch
 
 from . import _lib
-from ._lib import (A_PACKED, A_S16B, PREC_BF16X3, PREC_FP16X2, CFG_C3_128, CFG_C3_128_V2, CFG_C3_128_SW, CFG_C3_128_PIPE, CFG_C3_128_V3, CFG_C3_128_V3B, CFG_C3_128_V4, CFG_C3_128_FAST, CFG_C5_128_K16, CFG_C5_32_K16, CFG_C3_128_W4, CFG_C3X_32, CFG_C5X_32_K16, CFG_C3X_128_K16, CFG_C5X_128, CFG_G1_128_N128, CFG_C3_128_K16, CFG_C3_32, CFG_C3_LOW, CFG_C3_S2,
+from ._lib import (A_PACKED, A_S16B, PREC_BF16X3, PREC_FP16X2, CFG_C3_128, CFG_C3_128_V2, CFG_C3_128_SW, CFG_C3_128_PIPE, CFG_C3_128_FAST, CFG_C5_128_K16, CFG_C5_32_K16, CFG_C3_128_W4, CFG_C3X_32, CFG_C5X_32_K16, CFG_C3X_128_K16, CFG_C5X_128, CFG_G1_128_N128, CFG_C3_128_K16, CFG_C3_32, CFG_C3_LOW, CFG_C3_S2,
                    CFG_G1_128, CFG_G1_128_LOW, CFG_G1_64_LOW, CFG_NT_KC, OUT_F32B, OUT_NCDHW, OUT_S16B,
                    MdGemmConvArgs, check)
 

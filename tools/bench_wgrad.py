@@ -22,6 +22,8 @@ def main():
     ap.add_argument("--only", type=int, default=-1, help="index into SHAPES")
     a = ap.parse_args()
     lib = _lib.load()
+    if not hasattr(lib, "md_wgrad_set_debug"):
+        raise SystemExit("--debug needs an ablation build: MD_BUILD_ABLATIONS=1 python -m meshdiffusion_amd.build --force")
     lib.md_wgrad_set_debug(a.debug)
     bw.WGRAD_BLOCKS = a.blocks
     B = 8
