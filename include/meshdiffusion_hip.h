@@ -41,7 +41,7 @@ extern "C" {
 #define MD_ERR_UNSUPPORTED (-2)
 #define MD_ERR_NO_DEVICE (-3)
 
-#define MD_ABI_VERSION 10
+#define MD_ABI_VERSION 11
 
 /* ---- tile configurations of md_gemm_conv (compile-time instantiations) ---- */
 enum {
@@ -277,6 +277,26 @@ int md_wino_pack_weights(const float* w, void* wpk, int32_t cout, int32_t cin, i
 int md_conv3_wino(const void* t_in, const void* wpk, float* out, const float* bias, int64_t bias_bstride,
                   const float* residual, int64_t res_bstride, double* stats, int32_t batch, int32_t cin, int32_t cout,
                   int32_t D, int32_t H, int32_t W, int32_t variant, void* stream);
+
+/*
+ * The same convolution (same reference lines, inference only) in the "f16f8" arithmetic: every product a*b of the Winograd-domain
+ * contraction is  fp16(a) fp16(b)  +  [e4m3(a) e4m3(b_lo 2^11) + e4m3(a_lo 2^11) e4m3(b)] 2^-11,  a_lo = a - fp16(a): one
+ * v_mfma_f32_32x32x16_f16 plus half a K-concatenated v_mfma_scale_f32_32x32x64_f8f6f4 (OCP e4m3, E8M0 scale) = two 32-cycle
+ * matrix-core units per product where bf16x3 issues three; fp32 accumulation.  Error of one conv vs fp64 1.3e-5 (bf16x3 5.5e-6).
+ * md_wino_prep_f8: as md_wino_prep (no dropout; W must divide 256), T of the same geometry with plane 0 = 8 fp16 and plane 1 =
+ *   [e4m3(t) x 8 | e4m3((t - fp16(t)) 2^11) x 8]; size: md_wino_operand_bytes.
+ * md_wino_pack_weights_f8 (two kernels: max |w| -> power-of-two pre-scale 2^sw kept on the device, then the fragments):
+ *   [Cout/128][Cin*9/32 step pairs][4][row tile 4][piece 4][lane 64][16 B] + a 256-byte header {max |w|, sw, 2^-sw};
+ *   size: md_wino_weight_bytes_f8.  Forward orientation only (s_row = Cin*27, s_k = 27 for [Cout][Cin][3][3][3]).
+ * md_conv3_wino_f8: arguments, supported shapes and outputs as md_conv3_wino with T / wpk from the two calls above.
+ */
+int md_wino_prep_f8(const float* x1, const float* x2, int32_t c1, int32_t c2, const float* ac, int32_t silu, int32_t ups,
+                    void* t_out, int32_t batch, int32_t D, int32_t H, int32_t W, void* stream);
+int64_t md_wino_weight_bytes_f8(int32_t cout, int32_t cin);
+int md_wino_pack_weights_f8(const float* w, void* wpk, int32_t cout, int32_t cin, int64_t s_row, int64_t s_k, void* stream);
+int md_conv3_wino_f8(const void* t_in, const void* wpk, float* out, const float* bias, int64_t bias_bstride,
+                     const float* residual, int64_t res_bstride, double* stats, int32_t batch, int32_t cin, int32_t cout,
+                     int32_t D, int32_t H, int32_t W, void* stream);
 
 /*
  * md_conv3_stem: the dx-folded 3x3x3 input convolution from 4 channels (csrc/conv3_stem.hip; ddpm_res64.py:87-92 applied

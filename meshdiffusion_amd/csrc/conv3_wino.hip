@@ -24,6 +24,7 @@
 //                        issues 48 MFMAs, 8 ds_read_b128 (0.17 per MFMA; conv3_main: 0.67) and 8 global loads.
 //                        Only the epilogue meets: accumulators cross through LDS (m0..m3 of a pair live in 4 waves),
 //                        y0 / y1 + bias + residual + GroupNorm sums as in md_conv3_main_kernel.
+#include <type_traits>
 #include "md_common.h"
 #include "md_pack.h"
 
@@ -139,6 +140,36 @@ __global__ __launch_bounds__(256) void md_wino_pack_weights_kernel(const float* 
   wpk[id] = md_pack_wino_item(w, cout, cin, s_row, s_k, flip, id);
 }
 
+// f16f8 weights: max |w| of the tensor (the pre-scale 2^sw is derived from it on the device: no host round trip), then the
+// fragments; header behind the fragments: {max |w| (float bits), sw (int), 2^-sw (float), 0}
+__global__ __launch_bounds__(256) void md_wino_amax_kernel(const float* __restrict__ w, int cout, int cin, int64_t s_row, int64_t s_k,
+                                                           uint32_t* __restrict__ hdr) {
+  const int64_t n = (int64_t)cout * cin * 27;
+  float m = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int t = (int)(i % 27);
+    const int64_t r = i / 27;
+    const float v = fabsf(w[(r / cin) * s_row + (r % cin) * s_k + t]);
+    m = v > m ? v : m;                       // NaN never wins: a non-finite weight tensor packs with sw = 0
+  }
+  m = md_wave_max(m);
+  if ((threadIdx.x & 63) == 0) atomicMax(hdr, __float_as_uint(m));      // non-negative floats order like their bit patterns
+}
+
+__global__ __launch_bounds__(256) void md_wino_pack_weights_f8_kernel(const float* __restrict__ w, uint4* __restrict__ wpk, int cout, int cin,
+                                                                      int64_t s_row, int64_t s_k, uint32_t* __restrict__ hdr) {
+  const int64_t n = (int64_t)cout * cin * 9;             // 16-byte items: cout * cin * 36 values * 4 B / 16
+  const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const float wscale = md_wino_f8_wscale(__uint_as_float(hdr[0]));
+  if (id == 0) {
+    hdr[1] = (uint32_t)ilogbf(wscale);
+    hdr[2] = __float_as_uint(1.0f / wscale);
+    hdr[3] = 0u;
+  }
+  if (id >= n) return;
+  wpk[id] = md_pack_wino_f8_item(w, cout, cin, s_row, s_k, wscale, id);
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // md_conv3_wino
 // ------------------------------------------------------------------------------------------------------------------
@@ -149,6 +180,7 @@ struct WnArgs {
   const float* bias;       // may be null; per sample with stride bias_bstride (0 = shared)
   const float* residual;   // F32B like out, may be null
   double* stats;           // may be null
+  const float* hdr;        // F8: the weight buffer's header {max |w|, sw, 2^-sw} behind the fragments (md_wino_pack_weights_f8)
   int64_t bias_bstride, res_bstride;
   int batch, cin, cout, D, H, W;
 };
@@ -159,7 +191,17 @@ struct WnArgs {
 //   HBM stream, bit 7 (valid results, no statistics) per-wave s_memtime stamps of the first 1024 workgroups into the buffer
 //   passed as `stats` (tools/bench_wino.py --stamps: where a workgroup's time goes).  NOTE: with bit 0 / 3 the MFMAs run on constant operands and the chip clocks higher (data-dependent power):
 //   such runs bound the MFMA time from below, they do not price the removed traffic.
-template <int ABL>
+//
+// F8 = the "f16f8" arithmetic (md_common.h md_split_f16f8; operand from md_wino_prep_f8, weights from md_wino_pack_weights_f8): a
+// product is fp16(a) fp16(b) + [e4m3(a) e4m3(b_lo 2^11) + e4m3(a_lo 2^11) e4m3(b)] 2^-11.  Per TWO steps (a "pair-step": steps 2p, 2p+1
+// of the sequence step = chunk * 9 + tap) and accumulator tile: two v_mfma_f32_32x32x16_f16 + ONE v_mfma_scale_f32_32x32x64_f8f6f4
+// whose K = 64 is [lanes 0-31: step 2p | lanes 32-63: step 2p+1] x [16 channels x (e4m3(a), e4m3(a_lo))] -- 4 matrix-core units
+// of 32 cycles where bf16x3 issues 6 (measured on random data, tools/probes/f8_probe.hip: 0.636 of the bf16x3 time).  Same T
+// geometry, same halo image, same epilogue (times 2^-sw, the weights' power-of-two pre-scale).
+typedef int wn_i32x8 __attribute__((ext_vector_type(8)));
+typedef int wn_i32x4 __attribute__((ext_vector_type(4)));
+
+template <int ABL, bool F8 = false>
 __global__ __launch_bounds__(WN_THREADS) void md_conv3_wino_kernel(const WnArgs A) {
   __shared__ __attribute__((aligned(16))) unsigned char wn_smem[WN_LDS_BYTES];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -196,6 +238,11 @@ __global__ __launch_bounds__(WN_THREADS) void md_conv3_wino_kernel(const WnArgs 
     const int z = z0 + dz - 1, y = y0 + hy - 1;
     const bool live = (z >= 0) & (z < D) & (y >= 0) & (y < H);
     // cg = 2 chunk + (hp >> 1); inside a cg: [f][plane][Ph]; the f term is in the base
+    if constexpr (F8) {      // 32-bit and unconditional (16 Ph < 2^31 is checked at launch): stays a select, no branch in the loop
+      const int Phi = (int)Ph;
+      const int off = (hp >> 1) * 8 * Phi + (hp & 1) * Phi + (z * H + y) * Wp + (x0 >> 1) + pr;
+      return live ? off : -1;
+    }
     return live ? (int)((int64_t)(hp >> 1) * 8 * Ph + (int64_t)(hp & 1) * Ph + ((int64_t)z * H + y) * Wp + (x0 >> 1) + pr) : -1;
   };
   const uint4* tbase = A.T + ((int64_t)b * CG * 8 + wid * 2) * Ph;                              // + chunk * 16 * Ph
@@ -244,94 +291,244 @@ __global__ __launch_bounds__(WN_THREADS) void md_conv3_wino_kernel(const WnArgs 
       for (int r = 0; r < 16; ++r) acc[rt][ct][r] = 0.f;
       asm volatile("" : "+a"(acc[rt][ct]));          // the 256 accumulator registers are the AccVGPR half of the file
     }
+  float descale = 1.f;
+  if constexpr (F8) {
+    static_assert(ABL == 0 || ABL == 128, "timing ablations exist for the bf16x3 loop only");
+    descale = A.hdr[2];
+    // ---- F8 main loop -------------------------------------------------------------------------------------------------
+    // Pair-step u of a body (2 chunks = 18 steps = 9 pair-steps; chunk c0 in halo buffer 0, c0 + 1 in buffer 1; pair-step 4 is
+    // tap 8 of the first and tap 0 of the second chunk) = 4 GROUPS, one per column tile ct (output plane z0 + ct):
+    //     12 MFMAs: fp16 step 2u x 4 row tiles, fp16 step 2u+1 x 4 row tiles, fp8 (both steps) x 4 row tiles   (512 cycles)
+    //  || the 4 B fragments of the NEXT group (16 registers, double-buffered per group: LDS latency is one group at most)
+    //  || 8 of the 16 weight pieces of the NEXT pair-step in groups 0 and 1 (two register sets of 64: a piece is a 1 KB-contiguous
+    //     16-byte load per lane as before; this wave's 16 pieces of a pair-step are 16 KB contiguous)
+    //  || one halo piece of a later chunk requested, one requested two pair-steps earlier stored (two register slots of 4 pieces):
+    //     chunk c0 + 1 (buffer 1, free from pair-step 0 on: its last reader is pair-step 8 of the body before): requested at
+    //     pair-steps 7, 8 (of the body before; the prologue for chunk 1) and 0, 1, stored at 0, 1, 2, 3 -- the first reader is the
+    //     prefetch of pair-step 4's fragments in the last group of pair-step 3, issued after that group's store;
+    //     chunk c0 + 2 (buffer 0, free after pair-step 4): requested at 3, 4, 5, 6, stored at 5, 6, 7, 8.
+    // A body has an odd number of pair-steps, so two bodies (PB = 0 / 1: which weight set holds pair-step 0) are unrolled.
+    const int npairs = nsteps >> 1;
+    const uint4* wbase8 = A.wpk + (((int64_t)rtb * npairs) * 4 + wid) * 1024 + lane;       // + p * 4096 + piece * 64
+    // weights [set][row tile]: the two fp16 fragments (step 2p, 2p+1) and the 32-byte fp8 fragment (8 consecutive registers: its two
+    // 16-byte loads write the halves directly); halo fragments of one group [group parity] likewise; halo pieces in flight [slot][group]
+    uint4 A8h[2][4][2], B8h[2][2], hs8[2][4];
+    wn_i32x8 A8f[2][4], B8f[2];
+    // The source offsets of the 15 halo pieces (loop-invariant, ~45 VALU each to recompute, 15 registers to keep) live in a
+    // 3.75 KB table per wave behind the halo buffers (the epilogue's exchange area reuses the space): one ds_read_b32 per request.
+    // Bit k of live_mask: this lane's entry of piece k lies inside the grid (the compiler keeps the 15 masks in SGPR pairs).
+    int* otab = (int*)(wn_smem + 4 * WN_WAVE_LDS) + wid * (WN_NDMA * 64) + lane;
+    static_assert(4 * WN_WAVE_LDS + 4 * WN_NDMA * 64 * 4 <= WN_LDS_BYTES, "offset tables fit behind the halo buffers");
+    uint32_t live_mask = 0;
+#pragma unroll
+    for (int k = 0; k < WN_NDMA; ++k) {
+      const int dk = halo_off(k);
+      otab[k * 64] = dk >= 0 ? dk : 0;          // outside the grid: a valid address (entry 0 of the chunk), zeroed on its way to LDS
+      live_mask |= (dk >= 0 ? 1u : 0u) << k;
+    }
+    constexpr int D1 = 64, D2 = (40 - 8) * 16, D3 = WN_HBUF - (2 * 40 + 2 * 4) * 16;      // address of step 2u+1 minus step 2u
+    const unsigned char* vBh = my_smem + h * 2 * WN_TPOS * 16 + j * 16;                    // k-group h, plane 0 (fp16)
+    const unsigned char* vB8a = my_smem + WN_TPOS * 16 + j * 16 + h * D1;                  // k-group 0, plane 1 (fp8), step 2u + h
+    const unsigned char* vB8b = my_smem + WN_TPOS * 16 + j * 16 + h * D2;
+    const unsigned char* vB8c = my_smem + WN_TPOS * 16 + j * 16 + h * D3;
+    auto step_off = [](int s) constexpr -> int { return (s / 9) * WN_HBUF + (((s % 9) / 3) * 40 + ((s % 9) % 3) * 4) * 16; };
+    auto cat8 = [](const uint4& x, const uint4& y) -> wn_i32x8 {
+      const wn_i32x4 a = __builtin_bit_cast(wn_i32x4, x), b = __builtin_bit_cast(wn_i32x4, y);
+      return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+    auto halo_load8 = [&](int chunk, int k) -> uint4 { return wn_gload16(tbase + (int64_t)chunk * 16 * Ph + otab[k * 64]); };
+    auto halo_store8 = [&](int buf, int k, uint4 v) {
+      const bool lv = (live_mask >> k) & 1u;
+      v.x = lv ? v.x : 0u; v.y = lv ? v.y : 0u; v.z = lv ? v.z : 0u; v.w = lv ? v.w : 0u;
+      *(uint4*)(my_smem + buf * WN_HBUF + k * 1024 + lane * 16) = v;
+    };
+    auto read_B8 = [&](auto uc, auto ctc, uint4 (&dh)[2], wn_i32x8& df) {
+      constexpr int u = decltype(uc)::value, ct = decltype(ctc)::value;
+      constexpr int o0 = step_off(2 * u) + ct * 40 * 16, o1 = step_off(2 * u + 1) + ct * 40 * 16, dk = o1 - o0;
+      static_assert(dk == D1 || dk == D2 || dk == D3, "three kinds of step pairs");
+      const unsigned char* v8 = dk == D1 ? vB8a : (dk == D2 ? vB8b : vB8c);
+      dh[0] = *(const uint4*)(vBh + o0);
+      dh[1] = *(const uint4*)(vBh + o1);
+      df = cat8(*(const uint4*)(v8 + o0), *(const uint4*)(v8 + o0 + 2 * WN_TPOS * 16));
+    };
+    auto load_A8 = [&](int p, int set, int rt0, int nrt) {      // row tiles rt0 .. rt0 + nrt - 1 of pair-step p
+      const uint4* wp = wbase8 + (int64_t)p * 4096;
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt)
+        if (rt >= rt0 && rt < rt0 + nrt) {
+          A8h[set][rt][0] = wp[(rt * 4 + 0) * 64];
+          A8h[set][rt][1] = wp[(rt * 4 + 1) * 64];
+          A8f[set][rt] = cat8(wp[(rt * 4 + 2) * 64], wp[(rt * 4 + 3) * 64]);
+        }
+    };
+    // ---- prologue: chunk 0 -> buffer 0; pieces 0..7 of chunk 1 into the two slots; weights of pair-step 0 ----
+    {
+      uint4 h0[WN_NDMA];
+#pragma unroll
+      for (int k = 0; k < WN_NDMA; ++k) h0[k] = halo_load8(0, k);
+      load_A8(0, 0, 0, 4);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { hs8[0][q] = halo_load8(1, q); hs8[1][q] = halo_load8(1, 4 + q); }
+#pragma unroll
+      for (int k = 0; k < WN_NDMA; ++k) halo_store8(0, k, h0[k]);
+    }
+    read_B8(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, B8h[0], B8f[0]);
+    mark(1);
+    const int scale_a = 127 - 11, scale_b = 127;       // E8M0: the fp8 products carry 2^-11
+    auto body = [&](auto pbc, int c0) {
+      constexpr int PB = decltype(pbc)::value;
+      const int p0 = (c0 * 9) >> 1;
+      const int cn1 = c0 + 1, cn2 = c0 + 2 < nchunk ? c0 + 2 : nchunk - 1, cn3 = c0 + 3 < nchunk ? c0 + 3 : nchunk - 1;
+      auto group = [&](auto uc, auto ctc) {
+        constexpr int u = decltype(uc)::value, ct = decltype(ctc)::value;
+        constexpr int aset = (PB + u) & 1, bset = ct & 1;
+        // -- halo piece stored (requested two pair-steps ago), then the next group's fragments (LDS executes a wave's accesses in order)
+        constexpr int st_piece = u <= 3 ? u * 4 + ct : (u >= 5 ? (u - 5) * 4 + ct : 99);
+        constexpr int st_slot = u <= 3 ? (u & 1) : ((u - 5) & 1);
+        if constexpr (st_piece < WN_NDMA) halo_store8(u <= 3 ? 1 : 0, st_piece, hs8[st_slot][ct]);
+        if constexpr (ct < 3) read_B8(uc, std::integral_constant<int, ct + 1>{}, B8h[bset ^ 1], B8f[bset ^ 1]);
+        else read_B8(std::integral_constant<int, (u + 1) % 9>{}, std::integral_constant<int, 0>{}, B8h[bset ^ 1], B8f[bset ^ 1]);
+        // -- weights of the next pair-step: 8 pieces in each of the first two groups
+        if constexpr (ct < 2) {
+          const int pn = p0 + u + 1 < npairs ? p0 + u + 1 : npairs - 1;      // clamped: the redundant tail request is never used
+          load_A8(pn, aset ^ 1, ct * 2, 2);
+        }
+        // -- halo piece of a later chunk requested
+        constexpr int ld_piece = u == 0 ? 8 + ct : (u == 1 ? 12 + ct : (u >= 3 && u <= 6 ? (u - 3) * 4 + ct : (u >= 7 ? (u - 7) * 4 + ct : 99)));
+        constexpr int ld_slot = u == 0 ? 0 : (u == 1 ? 1 : ((u - 3) & 1));      // alternates over the eight requesting pair-steps 0 1 3 4 5 6 7 8
+        if constexpr (ld_piece < WN_NDMA) hs8[ld_slot][ct] = halo_load8(u <= 1 ? cn1 : (u <= 6 ? cn2 : cn3), ld_piece);
+        // -- the 12 MFMAs
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt)
+          acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A8h[aset][rt][0]), __builtin_bit_cast(f16x8, B8h[bset][0]),
+                                                               acc[rt][ct], 0, 0, 0);
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt)
+          acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A8h[aset][rt][1]), __builtin_bit_cast(f16x8, B8h[bset][1]),
+                                                               acc[rt][ct], 0, 0, 0);
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt)
+          acc[rt][ct] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A8f[aset][rt], B8f[bset], acc[rt][ct], 0, 0, 0, scale_a, 0, scale_b);
+        // -- placement: one memory operation and a handful of the address VALU (the ~50 of a halo request, the 4 selects of a
+        // halo store) behind every MFMA: the LDS store and the 4 fragment reads first, then the weight loads, the halo request last
+#pragma unroll
+        for (int i_ = 0; i_ < 12; ++i_) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          if (i_ == 0 && st_piece < WN_NDMA) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+          if (i_ == 0 && ld_piece < WN_NDMA) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // the piece's table entry
+          if (i_ >= 1 && i_ <= 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          if (i_ >= 5 && i_ <= 8 && ct < 2) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+          if (i_ == 10 && ld_piece < WN_NDMA) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+          if (i_ < 10) __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      auto pair_step = [&](auto uc) {
+        group(uc, std::integral_constant<int, 0>{});
+        group(uc, std::integral_constant<int, 1>{});
+        group(uc, std::integral_constant<int, 2>{});
+        group(uc, std::integral_constant<int, 3>{});
+      };
+      pair_step(std::integral_constant<int, 0>{}); pair_step(std::integral_constant<int, 1>{}); pair_step(std::integral_constant<int, 2>{});
+      pair_step(std::integral_constant<int, 3>{}); pair_step(std::integral_constant<int, 4>{}); pair_step(std::integral_constant<int, 5>{});
+      pair_step(std::integral_constant<int, 6>{}); pair_step(std::integral_constant<int, 7>{}); pair_step(std::integral_constant<int, 8>{});
+      (void)cn1;
+    };
+    for (int c0 = 0; c0 < nchunk; c0 += 4) {
+      body(std::integral_constant<int, 0>{}, c0);
+      if (c0 + 2 >= nchunk) break;
+      body(std::integral_constant<int, 1>{}, c0 + 2);
+    }
+  } else {
   bf16x8 Ar[3][8];      // weights  [step % 3][rt * 2 + plane]
-  bf16x8 Bf[2][8];      // halo     [step parity][ct * 2 + plane]
-  uint4 hst[2][3];      // halo pieces on their way from global memory to LDS: [tap parity][piece of the step]
-
-  // ---- prologue: chunk 0 of the halo (15 pieces, all requested before the first is stored), weights of steps 0 and 1 ----
-  {
-    uint4 h0[WN_NDMA];
-#pragma unroll
-    for (int k = 0; k < WN_NDMA; ++k) h0[k] = halo_load(0, k);
-    load_A(0, Ar[0]);
-    load_A(nsteps > 1 ? 1 : 0, Ar[1]);
-    if constexpr (ABL & 4) load_A(nsteps > 2 ? 2 : 0, Ar[2]);      // timing only: three real weight sets, reused for every step
-#pragma unroll
-    for (int k = 0; k < WN_NDMA; ++k) halo_store(0, k, h0[k]);
-    if constexpr (ABL & 2) {      // timing only: real data in both buffers, no halo traffic after this
-#pragma unroll
-      for (int k = 0; k < WN_NDMA; ++k) halo_store(1, k, h0[k]);
+    bf16x8 Bf[2][8];      // halo     [step parity][ct * 2 + plane]
+    uint4 hst[2][3];      // halo pieces on their way from global memory to LDS: [tap parity][piece of the step]
+  
+    // ---- prologue: chunk 0 of the halo (15 pieces, all requested before the first is stored), weights of steps 0 and 1 ----
+    {
+      uint4 h0[WN_NDMA];
+  #pragma unroll
+      for (int k = 0; k < WN_NDMA; ++k) h0[k] = halo_load(0, k);
+      load_A(0, Ar[0]);
+      load_A(nsteps > 1 ? 1 : 0, Ar[1]);
+      if constexpr (ABL & 4) load_A(nsteps > 2 ? 2 : 0, Ar[2]);      // timing only: three real weight sets, reused for every step
+  #pragma unroll
+      for (int k = 0; k < WN_NDMA; ++k) halo_store(0, k, h0[k]);
+      if constexpr (ABL & 2) {      // timing only: real data in both buffers, no halo traffic after this
+  #pragma unroll
+        for (int k = 0; k < WN_NDMA; ++k) halo_store(1, k, h0[k]);
+      }
     }
-  }
-  read_B(0, 0, Bf[0], true);
-  mark(1);
-
-  // ---- main loop: two chunks (18 steps) per iteration so that every register-set index is a compile-time constant ----
-  // No LDS-DMA: an LDS-DMA instruction costs the issuing wave 150-230 cycles (measured; with one wave per SIMD nobody else
-  // feeds the matrix pipe meanwhile), a plain load + ds_write_b128 a fraction of that, and hipcc counts plain loads exactly.
-  // Step s = 48 MFMAs (three passes a_lo*b_hi, a_hi*b_lo, a_hi*b_hi over the 16 accumulator tiles):
-  //   pass 0   || 8 weight loads of step s+2, 8 ds_reads of the halo fragments of step s+1
-  //   pass 1-2 || taps 0..4: 3 halo pieces of the NEXT chunk requested (after this step's weight loads, so that the wait
-  //               for those weights two steps later does not cover them); taps 2..6: the 3 pieces requested two steps
-  //               earlier stored to the other halo buffer at the END of the step -- ~2.7 steps (2 us) after the request.
-  // The other halo buffer is free from tap 0 on (its last reads, issued at tap 7 of the chunk before, returned at tap 8);
-  // its first reader is the fragment read of tap 8, two steps after the last store (LDS executes a wave's accesses in order).
-#define WN_MFMA(PASS, IDX, a, bq)                                                                                       \
-  acc[(IDX) >> 2][(IDX) & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[((IDX) >> 2) * 2 + ((PASS) == 0 ? 1 : 0)],   \
-                                                                       bq[((IDX) & 3) * 2 + ((PASS) == 1 ? 1 : 0)],    \
-                                                                       acc[(IDX) >> 2][(IDX) & 3], 0, 0, 0)
-  for (int c0 = 0; c0 < nchunk; c0 += 2) {
-#pragma unroll
-    for (int u = 0; u < 18; ++u) {
-      const int tap = u % 9, cpar = u / 9;             // chunk c0 + cpar lives in halo buffer cpar
-      const int s = c0 * 9 + u;
-      const int sw = s + 2 < nsteps ? s + 2 : nsteps - 1;                     // clamped: the redundant tail requests are never used
-      const int cn = c0 + cpar + 1 < nchunk ? c0 + cpar + 1 : nchunk - 1;     // clamped likewise
-      bf16x8 (&Aw)[8] = Ar[u % 3], (&Bc)[8] = Bf[u & 1], (&Bn)[8] = Bf[(u + 1) & 1];
-      if constexpr (!(ABL & 4)) load_A(sw, Ar[(u + 2) % 3]);
-      if (tap < 8) read_B(tap + 1, cpar, Bn, false);
-      else read_B(0, cpar ^ 1, Bn, false);
-      // (MFMA order inside a step measured neutral, profiles/r03_wino_epilogue_ab.txt: column-tile-major passes, and the three
-      // products of a tile adjacent -- the kernel is power-limited, issue order does not change the energy)
-#pragma unroll
-      for (int m = 0; m < 16; ++m) WN_MFMA(0, m, Aw, Bc);
-#pragma unroll
-      for (int i_ = 0; i_ < 8; ++i_) {                 // 8 LDS reads and 8 global loads under the 16 MFMAs of the first pass
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    read_B(0, 0, Bf[0], true);
+    mark(1);
+  
+    // ---- main loop: two chunks (18 steps) per iteration so that every register-set index is a compile-time constant ----
+    // No LDS-DMA: an LDS-DMA instruction costs the issuing wave 150-230 cycles (measured; with one wave per SIMD nobody else
+    // feeds the matrix pipe meanwhile), a plain load + ds_write_b128 a fraction of that, and hipcc counts plain loads exactly.
+    // Step s = 48 MFMAs (three passes a_lo*b_hi, a_hi*b_lo, a_hi*b_hi over the 16 accumulator tiles):
+    //   pass 0   || 8 weight loads of step s+2, 8 ds_reads of the halo fragments of step s+1
+    //   pass 1-2 || taps 0..4: 3 halo pieces of the NEXT chunk requested (after this step's weight loads, so that the wait
+    //               for those weights two steps later does not cover them); taps 2..6: the 3 pieces requested two steps
+    //               earlier stored to the other halo buffer at the END of the step -- ~2.7 steps (2 us) after the request.
+    // The other halo buffer is free from tap 0 on (its last reads, issued at tap 7 of the chunk before, returned at tap 8);
+    // its first reader is the fragment read of tap 8, two steps after the last store (LDS executes a wave's accesses in order).
+  #define WN_MFMA(PASS, IDX, a, bq)                                                                                       \
+    acc[(IDX) >> 2][(IDX) & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[((IDX) >> 2) * 2 + ((PASS) == 0 ? 1 : 0)],   \
+                                                                         bq[((IDX) & 3) * 2 + ((PASS) == 1 ? 1 : 0)],    \
+                                                                         acc[(IDX) >> 2][(IDX) & 3], 0, 0, 0)
+    for (int c0 = 0; c0 < nchunk; c0 += 2) {
+  #pragma unroll
+      for (int u = 0; u < 18; ++u) {
+        const int tap = u % 9, cpar = u / 9;             // chunk c0 + cpar lives in halo buffer cpar
+        const int s = c0 * 9 + u;
+        const int sw = s + 2 < nsteps ? s + 2 : nsteps - 1;                     // clamped: the redundant tail requests are never used
+        const int cn = c0 + cpar + 1 < nchunk ? c0 + cpar + 1 : nchunk - 1;     // clamped likewise
+        bf16x8 (&Aw)[8] = Ar[u % 3], (&Bc)[8] = Bf[u & 1], (&Bn)[8] = Bf[(u + 1) & 1];
+        if constexpr (!(ABL & 4)) load_A(sw, Ar[(u + 2) % 3]);
+        if (tap < 8) read_B(tap + 1, cpar, Bn, false);
+        else read_B(0, cpar ^ 1, Bn, false);
+        // (MFMA order inside a step measured neutral, profiles/r03_wino_epilogue_ab.txt: column-tile-major passes, and the three
+        // products of a tile adjacent -- the kernel is power-limited, issue order does not change the energy)
+  #pragma unroll
+        for (int m = 0; m < 16; ++m) WN_MFMA(0, m, Aw, Bc);
+  #pragma unroll
+        for (int i_ = 0; i_ < 8; ++i_) {                 // 8 LDS reads and 8 global loads under the 16 MFMAs of the first pass
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (tap >= 2 && tap <= 6 && !(ABL & 2)) {
+  #pragma unroll
+          for (int q = 0; q < 3; ++q) halo_store(cpar ^ 1, (tap - 2) * 3 + q, hst[tap & 1][q]);
+        }
+        if (tap <= 4 && !(ABL & 2)) {
+  #pragma unroll
+          for (int q = 0; q < 3; ++q) hst[tap & 1][q] = halo_load(cn, tap * 3 + q);
+        }
+  #pragma unroll
+        for (int m = 0; m < 32; ++m) {
+          if (m < 16) WN_MFMA(1, m, Aw, Bc); else WN_MFMA(2, m - 16, Aw, Bc);
+        }
+        // inside the region: the 3 loads early (one per 2 MFMAs), the 3 stores behind the last MFMAs
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
         __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 20, 0);
+        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
-      __builtin_amdgcn_sched_barrier(0);
-      if (tap >= 2 && tap <= 6 && !(ABL & 2)) {
-#pragma unroll
-        for (int q = 0; q < 3; ++q) halo_store(cpar ^ 1, (tap - 2) * 3 + q, hst[tap & 1][q]);
-      }
-      if (tap <= 4 && !(ABL & 2)) {
-#pragma unroll
-        for (int q = 0; q < 3; ++q) hst[tap & 1][q] = halo_load(cn, tap * 3 + q);
-      }
-#pragma unroll
-      for (int m = 0; m < 32; ++m) {
-        if (m < 16) WN_MFMA(1, m, Aw, Bc); else WN_MFMA(2, m - 16, Aw, Bc);
-      }
-      // inside the region: the 3 loads early (one per 2 MFMAs), the 3 stores behind the last MFMAs
-      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 20, 0);
-      __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-      __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-      __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-      __builtin_amdgcn_sched_barrier(0);
     }
+  #undef WN_MFMA
   }
-#undef WN_MFMA
 
   mark(2);
   // ---- epilogue: the four frequencies of an output pair meet through LDS, one 32-row tile per round ----------------------
@@ -435,8 +632,14 @@ __global__ __launch_bounds__(WN_THREADS) void md_conv3_wino_kernel(const WnArgs 
     f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1;
 #pragma unroll
     for (int pr = 0; pr < 4; ++pr) {
-      f32x4 o0 = ((m[0][pr] + m[1][pr]) + m[2][pr]) + bv + pres[r & 1][pr][0];
-      f32x4 o1 = ((m[1][pr] - m[2][pr]) - m[3][pr]) + bv + pres[r & 1][pr][1];
+      f32x4 o0, o1;
+      if constexpr (F8) {       // the accumulators hold 2^sw x the products (the weights' pre-scale): an exact power of two
+        o0 = ((m[0][pr] + m[1][pr]) + m[2][pr]) * descale + bv + pres[r & 1][pr][0];
+        o1 = ((m[1][pr] - m[2][pr]) - m[3][pr]) * descale + bv + pres[r & 1][pr][1];
+      } else {
+        o0 = ((m[0][pr] + m[1][pr]) + m[2][pr]) + bv + pres[r & 1][pr][0];
+        o1 = ((m[1][pr] - m[2][pr]) - m[3][pr]) + bv + pres[r & 1][pr][1];
+      }
       *(f32x4*)(op + pr * 16) = o0;
       *(f32x4*)(op + pr * 16 + 8) = o1;
       s1 += o0 + o1;
@@ -512,6 +715,49 @@ extern "C" int md_wino_pack_weights(const float* w, void* wpk, int32_t cout, int
   return MD_OK;
 }
 
+extern "C" int64_t md_wino_weight_bytes_f8(int32_t cout, int32_t cin) {
+  if (cout <= 0 || cin <= 0 || (cout % 128) || (cin % 32)) return MD_ERR_BAD_ARG;
+  return (int64_t)cout * cin * 36 * 4 + 256;             // fragments + header
+}
+
+extern "C" int md_wino_pack_weights_f8(const float* w, void* wpk, int32_t cout, int32_t cin, int64_t s_row, int64_t s_k, void* stream) {
+  if (!w || !wpk || cout <= 0 || cin <= 0 || (cout % 128) || (cin % 32)) return MD_ERR_BAD_ARG;
+  const int64_t n = (int64_t)cout * cin * 9;
+  uint32_t* hdr = (uint32_t*)((unsigned char*)wpk + n * 16);
+  MD_HIP_CLEAR_ERROR();
+  hipError_t e = hipMemsetAsync(hdr, 0, 256, (hipStream_t)stream);
+  if (e != hipSuccess) return (int)e;
+  const int64_t nel = (int64_t)cout * cin * 27;
+  int ab = (int)((nel + 255) / 256);
+  if (ab > 1024) ab = 1024;
+  hipLaunchKernelGGL(md_wino_amax_kernel, dim3((unsigned)ab), dim3(256), 0, (hipStream_t)stream, w, cout, cin, s_row, s_k, hdr);
+  MD_HIP_CHECK_LAUNCH();
+  hipLaunchKernelGGL(md_wino_pack_weights_f8_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, (uint4*)wpk,
+                     cout, cin, s_row, s_k, hdr);
+  MD_HIP_CHECK_LAUNCH();
+  return MD_OK;
+}
+
+extern "C" int md_conv3_wino_f8(const void* t_in, const void* wpk, float* out, const float* bias, int64_t bias_bstride,
+                                const float* residual, int64_t res_bstride, double* stats, int32_t batch, int32_t cin,
+                                int32_t cout, int32_t D, int32_t H, int32_t W, void* stream) {
+  if (!t_in || !wpk || !out || batch <= 0) return MD_ERR_BAD_ARG;
+  if (cin <= 0 || cout <= 0 || (cin % 32) || (cout % 128)) return MD_ERR_UNSUPPORTED;
+  if (D <= 0 || H <= 0 || W <= 0 || (D % WN_TZ) || (H % WN_TY) || (W % WN_TX)) return MD_ERR_UNSUPPORTED;
+  if ((int64_t)D * H * W * 8 >= (int64_t)1 << 31) return MD_ERR_UNSUPPORTED;
+  WnArgs a;
+  a.T = (const uint4*)t_in; a.wpk = (const uint4*)wpk; a.out = out; a.bias = bias; a.residual = residual; a.stats = stats;
+  a.hdr = (const float*)((const unsigned char*)wpk + (int64_t)cout * cin * 36 * 4);
+  a.bias_bstride = bias_bstride; a.res_bstride = res_bstride;
+  a.batch = batch; a.cin = cin; a.cout = cout; a.D = D; a.H = H; a.W = W;
+  const int tiles = (D / WN_TZ) * (H / WN_TY) * (W / WN_TX);
+  MD_HIP_CLEAR_ERROR();
+  hipLaunchKernelGGL((md_conv3_wino_kernel<0, true>), dim3((unsigned)(tiles * batch), (unsigned)(cout / 128)), dim3(WN_THREADS), 0,
+                     (hipStream_t)stream, a);
+  MD_HIP_CHECK_LAUNCH();
+  return MD_OK;
+}
+
 extern "C" int md_conv3_wino(const void* t_in, const void* wpk, float* out, const float* bias, int64_t bias_bstride,
                              const float* residual, int64_t res_bstride, double* stats, int32_t batch, int32_t cin,
                              int32_t cout, int32_t D, int32_t H, int32_t W, int32_t variant, void* stream) {
@@ -521,6 +767,7 @@ extern "C" int md_conv3_wino(const void* t_in, const void* wpk, float* out, cons
   if ((int64_t)D * H * W * 8 >= (int64_t)1 << 31) return MD_ERR_UNSUPPORTED;       // 32-bit halo offsets (16 Ph items)
   WnArgs a;
   a.T = (const uint4*)t_in; a.wpk = (const uint4*)wpk; a.out = out; a.bias = bias; a.residual = residual; a.stats = stats;
+  a.hdr = nullptr;
   a.bias_bstride = bias_bstride; a.res_bstride = res_bstride;
   a.batch = batch; a.cin = cin; a.cout = cout; a.D = D; a.H = H; a.W = W;
   const int tiles = (D / WN_TZ) * (H / WN_TY) * (W / WN_TX);

@@ -55,6 +55,37 @@ __device__ __forceinline__ void md_split_f16(float x, uint32_t& hi, uint32_t& lo
   lo = md_f2h(x - md_h2f(hi));
 }
 
+// "f16f8" split (the Winograd conv's second arithmetic, conv3_wino.hip F8 path): t ~= hi + lo with hi = fp16(t) (RNE) and
+// lo = t - hi (exact in fp32).  A product a*b is then  fp16(a)*fp16(b)  [one v_mfma_f32_32x32x16_f16]  +  the two cross terms
+// a*b_lo + a_lo*b  computed from 4-bit-significand images  q8(a) q8(b_lo 2^11) + q8(a_lo 2^11) q8(b)  [OCP e4m3, RNE, saturated
+// at +-448] as HALF of one K-concatenated v_mfma_scale_f32_32x32x64_f8f6f4 with scale 2^-11: two 32-cycle matrix-core units per
+// product instead of bf16x3's three (tools/probes/f8_probe.hip pins the instruction's lane / byte / scale semantics and the
+// rounding of v_cvt_pk_fp8_f32; tools/f16f8_numerics.py the error: 1.3e-5 per conv against 5.5e-6).
+// 8 values -> `hi`: 8 fp16; `q`: [q8(t0..7) | q8(lo0..7 * 2^11)] (an activation item; weights swap the halves, see
+// md_pack_wino_f8_item).
+__device__ __forceinline__ float md_clamp448(float x) { return __builtin_amdgcn_fmed3f(x, -448.f, 448.f); }
+__device__ __forceinline__ uint32_t md_f16f8_pair(float a, float b, float& la, float& lb) {      // fp16 pair (RNE) + the scaled remainders
+  const _Float16 ha = (_Float16)__builtin_amdgcn_fmed3f(a, -65504.f, 65504.f), hb = (_Float16)__builtin_amdgcn_fmed3f(b, -65504.f, 65504.f);
+  la = (a - (float)ha) * 2048.f;
+  lb = (b - (float)hb) * 2048.f;
+  return (uint32_t)__builtin_bit_cast(unsigned short, ha) | ((uint32_t)__builtin_bit_cast(unsigned short, hb) << 16);
+}
+__device__ __forceinline__ uint32_t md_e4m3x4(float a, float b, float c, float d) {                 // bytes a | b | c | d, low first
+  int v = __builtin_amdgcn_cvt_pk_fp8_f32(md_clamp448(a), md_clamp448(b), 0, false);
+  return (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(md_clamp448(c), md_clamp448(d), v, true);
+}
+__device__ __forceinline__ void md_split_f16f8(const float (&t)[8], uint4& hi, uint32_t (&q)[2], uint32_t (&ql)[2]) {
+  float l[8];
+  hi.x = md_f16f8_pair(t[0], t[1], l[0], l[1]);
+  hi.y = md_f16f8_pair(t[2], t[3], l[2], l[3]);
+  hi.z = md_f16f8_pair(t[4], t[5], l[4], l[5]);
+  hi.w = md_f16f8_pair(t[6], t[7], l[6], l[7]);
+  q[0] = md_e4m3x4(t[0], t[1], t[2], t[3]);
+  q[1] = md_e4m3x4(t[4], t[5], t[6], t[7]);
+  ql[0] = md_e4m3x4(l[0], l[1], l[2], l[3]);
+  ql[1] = md_e4m3x4(l[4], l[5], l[6], l[7]);
+}
+
 // Counter-based dropout mask (training).  One 64-bit hash per 4 consecutive channels of one position gives four
 // 16-bit uniforms; element e is kept when its field >= thr16 = round(p * 65536).  `q` = ((b * c_total + first channel
 // of the quad) / 4) * P + pos identifies the quad, so the forward, the backward and md_dropout_scale regenerate the

@@ -65,3 +65,49 @@ __device__ __forceinline__ uint4 md_pack_wino_item(const float* __restrict__ w, 
   (void)cout;
   return make_uint4(word[0], word[1], word[2], word[3]);
 }
+
+// Winograd F(2,3) weight fragments of the "f16f8" arithmetic (md_conv3_wino_f8; md_split_f16f8 in md_common.h):
+//   [cout/128][pair p = step / 2][f 4][row tile 4][piece 4][lane 64][16 B],   step s = chunk * 9 + (kd, kh) tap, cin / 16 chunks
+//   piece 0 / 1: the fp16 MFMA A fragment of step 2p / 2p + 1: lane (row = lane & 31, h = lane >> 5) holds hi(G') of channels
+//                chunk * 16 + 8 h + 0..7
+//   piece 2 / 3: the two halves of the K-concatenated fp8 A fragment: lane (row, h) belongs to step 2p + h and holds
+//                [e4m3(lo(G') 2^11) ch 0..7 | e4m3(G') ch 0..7] (piece 2) and the same of channels 8..15 (piece 3) -- lo first:
+//                it meets the activation item's e4m3(t) half, the plain image the e4m3(lo(t) 2^11) half.
+// G' = G * wscale with wscale = 2^sw chosen from the tensor's max |w| so that max |G'| lies in [128, 256) (e4m3's top binades,
+// far from fp16's subnormals whatever the layer's weight scale); the conv's epilogue multiplies by 2^-sw.
+__device__ __forceinline__ float md_wino_f8_wscale(float amax) {       // 2^sw; amax = max |w| of the raw 3x3x3 weights
+  if (!(amax > 0.f) || !(amax < 1e30f)) return 1.f;
+  const int e = ilogbf(1.5f * amax);                                   // |G| <= 1.5 max |w|
+  int sw = 7 - e;
+  sw = sw < -100 ? -100 : (sw > 100 ? 100 : sw);
+  return ldexpf(1.f, sw);
+}
+__device__ __forceinline__ uint4 md_pack_wino_f8_item(const float* __restrict__ w, int cout, int cin, int64_t s_row, int64_t s_k, float wscale,
+                                                      int64_t id) {
+  int64_t r = id;
+  const int lane = (int)(r % 64); r /= 64;
+  const int piece = (int)(r % 4); r /= 4;
+  const int rtile = (int)(r % 4); r /= 4;
+  const int f = (int)(r % 4); r /= 4;
+  const int npairs = (cin / 16) * 9 / 2;
+  const int p = (int)(r % npairs); r /= npairs;
+  const int rtb = (int)r;
+  const int row = lane & 31, h = lane >> 5;
+  const int co = (rtb * 4 + rtile) * 32 + row;
+  const int step = 2 * p + (piece < 2 ? piece : h);
+  const int chunk = step / 9, tap = step % 9;
+  const int ci0 = chunk * 16 + (piece < 2 ? h : piece - 2) * 8;
+  float g8[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float* g = w + (int64_t)co * s_row + (int64_t)(ci0 + e) * s_k + tap * 3;
+    const float g0 = g[0], g1 = g[1], g2 = g[2];
+    const float G = f == 0 ? g0 : f == 1 ? (g0 + g1 + g2) * 0.5f : f == 2 ? (g0 - g1 + g2) * 0.5f : g2;
+    g8[e] = G * wscale;
+  }
+  uint4 hi;
+  uint32_t q[2], ql[2];
+  md_split_f16f8(g8, hi, q, ql);
+  (void)cout;
+  return piece < 2 ? hi : make_uint4(ql[0], ql[1], q[0], q[1]);
+}

@@ -18,7 +18,9 @@ constexpr int P2_STRIDE = 12;             // floats per position in LDS (8 + pad
 // DUAL (md_wino_prep_dual): also writes U, the transposed algorithm's transform of the same activated tensor,
 //   u = (d1, d1 + d2, d1 - d2, d2) per pair (d1, d2 = the pair's own two positions), in the layout of T -- the dY operand of
 //   the Winograd weight gradient (csrc/wgrad_wino.hip) when the tensor is an output gradient.
-template <bool DUAL>
+// F8 (md_wino_prep_f8): T in the "f16f8" operand format of md_conv3_wino_f8 -- same geometry, plane 0 = 8 fp16 (hi), plane 1 =
+//   [e4m3(t) x 8 | e4m3((t - hi) 2^11) x 8] (md_split_f16f8) instead of the bf16 hi / lo planes.
+template <bool DUAL, bool F8 = false>
 __global__ __launch_bounds__(256) void md_wino_prep2_kernel(const float* __restrict__ x1, const float* __restrict__ x2,
                                                             int c1, int c2, const float* __restrict__ ac, int silu, int ups,
                                                             uint4* __restrict__ T, uint4* __restrict__ U, float* __restrict__ sums,
@@ -135,11 +137,19 @@ __global__ __launch_bounds__(256) void md_wino_prep2_kernel(const float* __restr
 #pragma unroll
       for (int e = 0; e < 8; ++e)
         t[e] = f == 0 ? d[0][e] - d[2][e] : f == 1 ? d[1][e] + d[2][e] : f == 2 ? d[2][e] - d[1][e] : d[1][e] - d[3][e];
-      uint32_t hw[4], lw[4];
+      if constexpr (F8) {
+        uint4 hv;
+        uint32_t q8[2], ql8[2];
+        md_split_f16f8(t, hv, q8, ql8);
+        out[(int64_t)(f * 2) * Ph] = hv;
+        out[(int64_t)(f * 2 + 1) * Ph] = make_uint4(q8[0], q8[1], ql8[0], ql8[1]);
+      } else {
+        uint32_t hw[4], lw[4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) md_split2(t[2 * q], t[2 * q + 1], hw[q], lw[q]);
-      out[(int64_t)(f * 2) * Ph] = make_uint4(hw[0], hw[1], hw[2], hw[3]);
-      out[(int64_t)(f * 2 + 1) * Ph] = make_uint4(lw[0], lw[1], lw[2], lw[3]);
+        for (int q = 0; q < 4; ++q) md_split2(t[2 * q], t[2 * q + 1], hw[q], lw[q]);
+        out[(int64_t)(f * 2) * Ph] = make_uint4(hw[0], hw[1], hw[2], hw[3]);
+        out[(int64_t)(f * 2 + 1) * Ph] = make_uint4(lw[0], lw[1], lw[2], lw[3]);
+      }
     }
     if constexpr (DUAL) {
       uint4* uo = U + ((int64_t)b * CG + cg) * 8 * Ph + pos2;
@@ -162,7 +172,7 @@ __global__ __launch_bounds__(256) void md_wino_prep2_kernel(const float* __restr
 
 static int md_wino_prep2_launch(const float* x1, const float* x2, int32_t c1, int32_t c2, const float* ac, int32_t silu,
                                 int32_t ups, void* t_out, void* u_out, float* sums, int32_t batch, int32_t D, int32_t H, int32_t W, float drop_p,
-                                uint64_t drop_seed, void* stream) {
+                                uint64_t drop_seed, void* stream, bool f8 = false) {
   if (!x1 || !t_out || batch <= 0 || c1 <= 0 || c2 < 0 || (c1 & 7) || (c2 & 7) || (c2 > 0 && !x2)) return MD_ERR_BAD_ARG;
   if (silu && !ac) return MD_ERR_BAD_ARG;      // SiLU is applied together with the folded GroupNorm affine only
   if (D <= 0 || H <= 0 || W <= 0 || (W & 1) || (ups && ((D | H | W) & 1))) return MD_ERR_BAD_ARG;
@@ -172,7 +182,11 @@ static int md_wino_prep2_launch(const float* x1, const float* x2, int32_t c1, in
   const int64_t blocks = (int64_t)batch * ((c1 + c2) / 8) * (P / P2_POS);
   if (blocks > 0x7fffffff) return MD_ERR_UNSUPPORTED;
   MD_HIP_CLEAR_ERROR();
-  if (u_out)
+  if (f8)
+    hipLaunchKernelGGL((md_wino_prep2_kernel<false, true>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x1, x2, c1, c2, ac,
+                       silu, ups, (uint4*)t_out, (uint4*)nullptr, (float*)nullptr, batch, D, H, W, md_drop_thr16(drop_p),
+                       1.0f / (1.0f - drop_p), drop_seed);
+  else if (u_out)
     hipLaunchKernelGGL((md_wino_prep2_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x1, x2, c1, c2, ac,
                        silu, ups, (uint4*)t_out, (uint4*)u_out, sums, batch, D, H, W, md_drop_thr16(drop_p), 1.0f / (1.0f - drop_p),
                        drop_seed);
@@ -195,4 +209,10 @@ extern "C" int md_wino_prep_dual(const float* x1, const float* x2, int32_t c1, i
                                  int32_t W, float drop_p, uint64_t drop_seed, void* stream) {
   if (!u_out || (sums && ups)) return MD_ERR_BAD_ARG;
   return md_wino_prep2_launch(x1, x2, c1, c2, ac, silu, ups, t_out, u_out, sums, batch, D, H, W, drop_p, drop_seed, stream);
+}
+
+
+extern "C" int md_wino_prep_f8(const float* x1, const float* x2, int32_t c1, int32_t c2, const float* ac, int32_t silu,
+                               int32_t ups, void* t_out, int32_t batch, int32_t D, int32_t H, int32_t W, void* stream) {
+  return md_wino_prep2_launch(x1, x2, c1, c2, ac, silu, ups, t_out, nullptr, nullptr, batch, D, H, W, 0.f, 0, stream, true);
 }

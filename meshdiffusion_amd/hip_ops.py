@@ -24,13 +24,24 @@ DEBUG_ACT_FP16 = 2 if os.environ.get("MD_DEBUG_ACT_FP16") == "1" else 0   # prec
 # Arithmetic of the dedicated 3x3x3 conv kernel: "bf16x3" (default; ~1e-5 per U-Net evaluation) or "fp16x2"
 # (weights split fp16, activations one fp16; ~1e-3 per evaluation, 7e-5 after the 999-step sampler).
 PRECISION = os.environ.get("MD_PRECISION", "bf16x3")
+# "f16f8": bf16x3 everywhere except the INFERENCE Winograd convs (md_wino_prep_f8 + md_conv3_wino_f8): a product there is
+# fp16(a) fp16(b) + [e4m3(a) e4m3(b_lo 2^11) + e4m3(a_lo 2^11) e4m3(b)] 2^-11 -- one fp16 MFMA + half a K-concatenated scaled fp8
+# MFMA = 2 matrix-core units per product instead of 3 (1.3e-5 per conv against bf16x3's 5.5e-6: tools/f16f8_numerics.py).
+# Training keeps bf16x3 (the backward reads the forward's bf16 T, and gradients need bf16's exponent range).
+WINO_F8 = False
+if PRECISION == "f16f8":
+    PRECISION, WINO_F8 = "bf16x3", True
 
 
 def set_precision(mode):
-    global PRECISION
-    if mode not in ("bf16x3", "fp16x2"):
+    global PRECISION, WINO_F8
+    if mode not in ("bf16x3", "fp16x2", "f16f8"):
         raise ValueError(f"unknown precision mode {mode!r}")
-    PRECISION = mode
+    PRECISION, WINO_F8 = ("bf16x3", True) if mode == "f16f8" else (mode, False)
+
+
+def precision_name():
+    return "f16f8" if (WINO_F8 and PRECISION == "bf16x3") else PRECISION
 
 
 def fast_prec(cfg):
@@ -389,6 +400,24 @@ class WinoWeight:
         return self._data
 
 
+class WinoWeightF8:
+    """Conv3d weight [Co][Ci][3][3][3] -> the "f16f8" fragments of md_conv3_wino_f8 (md_wino_pack_weights_f8: fp16 hi fragments +
+    K-concatenated e4m3 fragments of the power-of-two pre-scaled G-transformed weights, header with the scale).  Inference only."""
+
+    def __init__(self, w, device):
+        lib = _lib.load()
+        w = w.detach().to(device=device, dtype=torch.float32).contiguous()
+        _require_cuda(w, "weight")
+        assert w.dim() == 5 and tuple(w.shape[2:]) == (3, 3, 3)
+        self.rows, self.kdim = w.shape[0], w.shape[1]
+        nbytes = lib.md_wino_weight_bytes_f8(self.rows, self.kdim)
+        if nbytes <= 0:
+            raise _lib.MeshDiffusionHipError("md_wino_weight_bytes_f8: unsupported weight shape")
+        self.data = torch.empty(nbytes // 2, dtype=torch.bfloat16, device=device)
+        check(lib.md_wino_pack_weights_f8(_ptr(w), _ptr(self.data), self.rows, self.kdim, self.kdim * 27, 27, _stream()),
+              "md_wino_pack_weights_f8")
+
+
 WINO_MIN_WGS = int(os.environ.get("MD_WINO_MIN_WGS", "256"))   # fewest workgroups the Winograd kernel is launched with
 
 
@@ -442,7 +471,13 @@ def release_scratch():
     _WINO_SCRATCH.clear()
 
 
-def wino_prep(parts, ac, silu, ups, B, S, drop=None, keep=False, dual=False, sums=None):
+def wino_f8_ok(S, drop=None, keep=False):
+    """The f16f8 arithmetic of the Winograd path: inference launches (no dropout, T not kept for a backward) on grids the
+    two-phase operand pass takes."""
+    return WINO_F8 and PRECISION == "bf16x3" and not drop and not keep and 256 % S == 0
+
+
+def wino_prep(parts, ac, silu, ups, B, S, drop=None, keep=False, dual=False, sums=None, f8=False):
     """fp32 F32B parts (+ folded GroupNorm affine, SiLU, nearest-x2 upsampling) -> transformed split operand T.
     drop = (p, seed): training dropout after SiLU, the mask gn_apply(drop=...) produces for the same pair.
     keep: T goes to its own tensor instead of the shared scratch buffer (training forward: the Winograd weight gradient of the
@@ -461,7 +496,10 @@ def wino_prep(parts, ac, silu, ups, B, S, drop=None, keep=False, dual=False, sum
     ev = _prof_begin()
     args = (_ptr(parts[0][0]), _ptr(x2), parts[0][1], c2, _ptr(ac), 1 if silu else 0, 1 if ups else 0)
     tail = (B, S, S, S, drop[0] if drop else 0.0, drop[1] if drop else 0, _stream())
-    if dual:
+    if f8:
+        assert not (dual or keep or drop), "the f16f8 operand is an inference format"
+        check(lib.md_wino_prep_f8(*args, _ptr(t), B, S, S, S, _stream()), "md_wino_prep_f8")
+    elif dual:
         if 256 % S:
             raise _lib.MeshDiffusionHipError("md_wino_prep_dual needs W | 256")
         u = _wino_scratch(nbytes // 2, dev, slot="u")
@@ -470,7 +508,7 @@ def wino_prep(parts, ac, silu, ups, B, S, drop=None, keep=False, dual=False, sum
         fn = lib.md_wino_prep_v2 if (WINO_PREP_V2 and 256 % S == 0) else lib.md_wino_prep
         check(fn(*args, _ptr(t), *tail), "md_wino_prep")
     _prof_end(ev, "wino_prep", 0.0, 4.0 * B * cin * (S ** 3 // (8 if ups else 1)) + (16.0 if dual else 8.0) * B * cin * S ** 3,   # fp32 in, 2 x bf16 x 2 out
-              f"{cin}@{S}x{S}x{S}" + ("/ups" if ups else "") + ("/dual" if dual else ""))
+              f"{cin}@{S}x{S}x{S}" + ("/ups" if ups else "") + ("/dual" if dual else "") + ("/f8" if f8 else ""))
     return (t, u) if dual else t
 
 
@@ -508,12 +546,18 @@ def conv3_wino(ww, t, B, S, *, bias=None, bias_bstride=0, residual=None, res_bst
     if out is None:
         out = f32b_empty(B, ww.rows, P, t.device)
     ev = _prof_begin()
-    check(lib.md_conv3_wino(_ptr(t), _ptr(ww.data), _ptr(out), _ptr(bias), bias_bstride, _ptr(residual), res_bstride,
-                            _ptr(stats), B, ww.kdim, ww.rows, S, S, S, WINO_VARIANT if variant is None else variant, _stream()),
-          "md_conv3_wino")
+    f8 = isinstance(ww, WinoWeightF8)        # the weight object fixes the arithmetic; `t` must come from wino_prep(f8=...) accordingly
+    if f8:
+        check(lib.md_conv3_wino_f8(_ptr(t), _ptr(ww.data), _ptr(out), _ptr(bias), bias_bstride, _ptr(residual), res_bstride,
+                                   _ptr(stats), B, ww.kdim, ww.rows, S, S, S, _stream()), "md_conv3_wino_f8")
+    else:
+        check(lib.md_conv3_wino(_ptr(t), _ptr(ww.data), _ptr(out), _ptr(bias), bias_bstride, _ptr(residual), res_bstride,
+                                _ptr(stats), B, ww.kdim, ww.rows, S, S, S, WINO_VARIANT if variant is None else variant, _stream()),
+              "md_conv3_wino")
     _prof_end(ev, "wino", 2.0 * B * ww.rows * ww.kdim * 27 * P,
               4.0 * (2 * B * ww.kdim * P + ww.rows * ww.kdim * 36 + B * ww.rows * P * (2 if residual is not None else 1)),
-              f"{ww.kdim}->{ww.rows}@{S}x{S}x{S}" + ("/res" if residual is not None else "") + ("/stats" if stats is not None else ""))
+              f"{ww.kdim}->{ww.rows}@{S}x{S}x{S}" + ("/res" if residual is not None else "") + ("/stats" if stats is not None else "")
+              + ("/f8" if f8 else ""))
     return out
 
 

@@ -113,8 +113,13 @@ def conv3_packed(layer, name, conv, cfg):
 
 
 def conv3_wino_packed(layer, name, conv):
-    """Lazy builder of the Winograd-transformed weight tiles of `conv` (cached like conv3_packed)."""
-    return lambda: layer._cached(f"{name}/wino", [conv.weight], lambda: ops.WinoWeight(conv.weight, conv.weight.device))
+    """Lazy builder of the Winograd-transformed weight tiles of `conv` (cached like conv3_packed); f8: the fragments of the
+    f16f8 arithmetic (hip_ops.WinoWeightF8, inference)."""
+    def build(f8=False):
+        if f8:
+            return layer._cached(f"{name}/wino_f8", [conv.weight], lambda: ops.WinoWeightF8(conv.weight, conv.weight.device))
+        return layer._cached(f"{name}/wino", [conv.weight], lambda: ops.WinoWeight(conv.weight, conv.weight.device))
+    return build
 
 
 def fused_operand_ok(pw, ups=0):
@@ -148,11 +153,12 @@ def run_conv3(pw, act_s16, B, S_out, *, bias=None, bias_bstride=0, residual=None
     if (b_f32 is not None and wino is not None and out_mode == ops.OUT_F32B and rows_alloc == pw.rows
             and pw.prec == ops.PREC_BF16X3 and ops.wino_ok(pw.rows, pw.kdim, S_out, B)):
         stats = ops.stats_zeros(B, rows_alloc, dev) if want_stats and ops.FUSE_GN_STATS else None
+        f8 = ops.wino_f8_ok(S_out, drop=b_f32.get("drop"), keep=bool(b_f32.get("keep"))) and not b_f32.get("wino_only")
         t = ops.wino_prep(b_f32["parts"], b_f32.get("ac"), b_f32.get("silu"), ups, B, S_out, drop=b_f32.get("drop"),
-                          keep=bool(b_f32.get("keep")))
+                          keep=bool(b_f32.get("keep")), f8=f8)
         if b_f32.get("keep"):
             b_f32["t_out"] = t           # training: the Winograd weight gradient reads the operand again (tape)
-        ops.conv3_wino(wino(), t, B, S_out, bias=bias, bias_bstride=bias_bstride, residual=residual,
+        ops.conv3_wino(wino(f8) if f8 else wino(), t, B, S_out, bias=bias, bias_bstride=bias_bstride, residual=residual,
                        res_bstride=res_bstride or 0, stats=stats, out=out)
         if stats is not None:
             out._md_sums = stats

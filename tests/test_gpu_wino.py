@@ -349,3 +349,200 @@ def test_wgrad_nin_s16b_vs_torch(ops, case):
     dw2 = dw0.clone()
     ops.wgrad_nin(dys, xs, B, co, ci, P, dw2)
     assert torch.equal(dw2, dw)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# "f16f8" arithmetic of the inference Winograd convs (md_wino_prep_f8 + md_wino_pack_weights_f8 + md_conv3_wino_f8):
+# product = fp16(a) fp16(b) + [e4m3(a) e4m3(b_lo 2^11) + e4m3(a_lo 2^11) e4m3(b)] 2^-11.  The torch restatement below is the
+# arithmetic of tools/f16f8_numerics.py (OCP e4m3 through torch.float8_e4m3fn, RNE, saturating).
+# ---------------------------------------------------------------------------------------------------------------------
+def _q8(x):
+    return x.clamp(-448, 448).to(torch.float8_e4m3fn)
+
+
+def _f16f8_images(x):
+    """hi (fp16), e4m3(x), e4m3((x - hi) 2^11) of an fp32 tensor."""
+    hi = x.clamp(-65504, 65504).half()
+    return hi, _q8(x), _q8((x - hi.float()) * 2048.0)
+
+
+def _wino_T(x):
+    S = x.shape[-1]
+    xp = F.pad(x, (1, 1))
+    d = [xp[..., k:k + S:2] for k in range(4)]
+    return [d[0] - d[2], d[1] + d[2], d[2] - d[1], d[1] - d[3]]
+
+
+def _wino_G(w):
+    g0, g1, g2 = w[..., 0], w[..., 1], w[..., 2]
+    return [g0, (g0 + g1 + g2) * 0.5, (g0 - g1 + g2) * 0.5, g2]
+
+
+def test_wino_prep_f8_layout_and_values(ops):
+    """T of md_wino_prep_f8: plane 0 = 8 fp16 (RNE), plane 1 = [e4m3(t) x 8 | e4m3((t - fp16(t)) 2^11) x 8], bit-exact against
+    the same arithmetic in torch (two parts, zero padding after the activation)."""
+    B, S, cs = 2, 8, [16, 8]
+    cin = sum(cs)
+    xs = [_rand((B, c, S, S, S), 130 + i) * (3.0 if i else 0.7) for i, c in enumerate(cs)]
+    parts = [(ops.ncdhw_to_f32b(t.cuda()), c) for t, c in zip(xs, cs)]
+    t = ops.wino_prep(parts, None, False, False, B, S, f8=True).cpu()
+    t = t.view(B, cin // 8, 4, 2, S, S, S // 2, 8)            # 8 bf16-sized slots = 16 bytes
+    tr = _wino_T(torch.cat(xs, 1))
+    for f in range(4):
+        hi, q, ql = _f16f8_images(tr[f])
+        blk = lambda v: v.view(B, cin // 8, 8, S, S, S // 2).permute(0, 1, 3, 4, 5, 2).contiguous()      # noqa: E731
+        assert torch.equal(t[:, :, f, 0].contiguous().view(torch.int16), blk(hi).view(torch.int16)), f
+        got = t[:, :, f, 1].contiguous().view(torch.uint8).view(B, cin // 8, S, S, S // 2, 16)
+        assert torch.equal(got[..., :8], blk(q).view(torch.uint8)), f
+        assert torch.equal(got[..., 8:], blk(ql).view(torch.uint8)), f
+
+
+def _pack_f8_reference(w):
+    """Torch restatement of md_wino_pack_weights_f8: (fragments as uint8 [n_items][16], sw)."""
+    cout, cin = w.shape[:2]
+    amax = float(w.abs().max())
+    sw = 0 if amax == 0 else 7 - int(np.floor(np.log2(1.5 * np.float32(amax))))
+    G = torch.stack(_wino_G(w.reshape(cout, cin, 9, 3)), -1) * (2.0 ** sw)        # [co][ci][tap 9][f 4]
+    hi, q, ql = _f16f8_images(G)
+    nch, npairs = cin // 16, cin // 16 * 9 // 2
+    out = torch.zeros((cout // 128, npairs, 4, 4, 4, 64, 16), dtype=torch.uint8)
+    step = lambda s: (s // 9, s % 9)                                                   # noqa: E731
+    lane = torch.arange(64)
+    row, h = lane % 32, lane // 32
+    for rtb in range(cout // 128):
+        for rt in range(4):
+            co = (rtb * 4 + rt) * 32 + row                                             # [64]
+            for p in range(npairs):
+                for piece in range(4):
+                    for f in range(4):
+                        if piece < 2:
+                            ch, tap = step(2 * p + piece)
+                            ci = ch * 16 + h[:, None] * 8 + torch.arange(8)[None]      # [64][8]
+                            v = hi[co[:, None], ci, tap, f]                            # [64][8] fp16
+                            out[rtb, p, f, rt, piece] = v.contiguous().view(torch.uint8).view(64, 16)
+                        else:
+                            s_l = 2 * p + h                                            # per lane
+                            ch, tap = s_l // 9, s_l % 9
+                            ci = ch[:, None] * 16 + (piece - 2) * 8 + torch.arange(8)[None]
+                            a = ql[co[:, None], ci, tap[:, None], f].view(torch.uint8)
+                            b = q[co[:, None], ci, tap[:, None], f].view(torch.uint8)
+                            out[rtb, p, f, rt, piece] = torch.cat([a, b], 1)
+    assert nch * 9 == 2 * npairs
+    return out.view(-1, 16), sw
+
+
+def test_wino_pack_weights_f8_layout(ops):
+    """md_wino_pack_weights_f8: pre-scale from max |w| (device side), fp16 fragments of both steps of a pair, the K-concatenated
+    e4m3 fragment [lo | plain] per 8 channels with lane half h owning step 2p + h -- bit-exact against torch, header included."""
+    co, ci = 128, 64
+    w = _rand((co, ci, 3, 3, 3), 140, 0.04)
+    w[3, 5] *= 1e-4                                            # a nearly dead filter: fp16 subnormals without the pre-scale
+    ww = ops.WinoWeightF8(w.cuda(), "cuda")
+    raw = ww.data.cpu().view(torch.uint8)
+    want, sw = _pack_f8_reference(w)
+    n = co * ci * 9
+    assert raw.numel() == n * 16 + 256
+    hdr = raw[n * 16:n * 16 + 16].view(torch.int32)
+    assert hdr[0].view(torch.float32).item() == float(w.abs().max()) and int(hdr[1]) == sw
+    assert hdr[2].view(torch.float32).item() == 2.0 ** -sw
+    got = raw[:n * 16].view(n, 16)
+    bad = (got != want).any(dim=1).nonzero().flatten()
+    assert bad.numel() == 0, (bad[:8].tolist(), got[bad[:2]].tolist(), want[bad[:2]].tolist())
+
+
+def _conv_f16f8_reference(ref_in, w):
+    """The f16f8 Winograd conv restated in torch (fp32 accumulation by F.conv3d on exact operand images)."""
+    B, _, S = ref_in.shape[:3]
+    cout = w.shape[0]
+    amax = float(w.abs().max())
+    sw = 7 - int(np.floor(np.log2(1.5 * np.float32(amax))))
+    T = _wino_T(F.pad(ref_in, (0, 0, 1, 1, 1, 1)))           # z / y zero padding; _wino_T pads w
+    G = [g * (2.0 ** sw) for g in _wino_G(w)]
+    m = []
+    for f in range(4):
+        th, tq, tl = _f16f8_images(T[f])
+        gh, gq, gl = _f16f8_images(G[f][..., None])
+        cross = F.conv3d(tq.float(), gl.float()) + F.conv3d(tl.float(), gq.float())
+        m.append(F.conv3d(th.float(), gh.float()) + cross * 2.0 ** -11)
+    y0, y1 = (m[0] + m[1]) + m[2], (m[1] - m[2]) - m[3]
+    return torch.stack([y0, y1], -1).reshape(B, cout, S, S, S) * 2.0 ** -sw
+
+
+@pytest.mark.parametrize("case", ["plain_128", "two_parts_gn_silu_res_stats", "ups_256rows", "k64_32cube"])
+def test_conv3_wino_f8_vs_torch(ops, case):
+    """md_conv3_wino_f8 against torch fp32 (budget: 3e-5, measured ~1.3e-5 = the arithmetic's own error), against the torch
+    restatement of the SAME arithmetic (only the fp32 accumulation order differs: < 2e-6) and bit-identical between launches.
+    Shapes: one / several chunk pairs (cin 32: a single body, 64: both unrolled bodies, 128: the loop), two row blocks, two
+    parts with GroupNorm + SiLU + residual + statistics, the upsampled operand."""
+    cfgs = {
+        "plain_128": dict(cs=[128], cout=128, S=16, B=2, gn=False, silu=False, ups=False, res=False, stats=False),
+        "two_parts_gn_silu_res_stats": dict(cs=[96, 32], cout=128, S=16, B=2, gn=True, silu=True, ups=False, res=True, stats=True),
+        "ups_256rows": dict(cs=[32], cout=256, S=16, B=1, gn=False, silu=False, ups=True, res=False, stats=True),
+        "k64_32cube": dict(cs=[32, 32], cout=128, S=32, B=1, gn=True, silu=True, ups=False, res=True, stats=False),
+    }
+    c = cfgs[case]
+    cs, cout, S, B = c["cs"], c["cout"], c["S"], c["B"]
+    cin = sum(cs)
+    Sin = S // 2 if c["ups"] else S
+    xs = [_rand((B, k, Sin, Sin, Sin), 150 + i) * (1.0 + i) + 0.3 * i for i, k in enumerate(cs)]
+    x = torch.cat(xs, 1)
+    gamma, beta = 1.0 + 0.2 * _rand((cin,), 160), 0.5 * _rand((cin,), 161)
+    w = _rand((cout, cin, 3, 3, 3), 162, 0.05)
+    bias = _rand((B, cout), 163)
+    res = _rand((B, cout, S, S, S), 164) if c["res"] else None
+    parts = [(ops.ncdhw_to_f32b(t.cuda()), k) for t, k in zip(xs, cs)]
+    ac, ref_in = None, x
+    if c["gn"]:
+        _, ac = ops.gn_params(parts, gamma.cuda(), beta.cuda(), B, Sin ** 3, want_ac=True)
+        ref_in = F.group_norm(x, 32, gamma, beta, eps=1e-6)
+        ref_in = F.silu(ref_in) if c["silu"] else ref_in
+    if c["ups"]:
+        ref_in = F.interpolate(ref_in, scale_factor=2, mode="nearest")
+    ww = ops.WinoWeightF8(w.cuda(), "cuda")
+    res_f = ops.ncdhw_to_f32b(res.cuda()) if res is not None else None
+    outs = []
+    for _ in range(2):
+        t = ops.wino_prep(parts, ac, c["silu"], c["ups"], B, S, f8=True)
+        stats = torch.zeros((B, cout, 2), dtype=torch.float64, device="cuda") if c["stats"] else None
+        outs.append(ops.conv3_wino(ww, t, B, S, bias=bias.cuda(), bias_bstride=cout, residual=res_f,
+                                   res_bstride=cout * S ** 3 if res is not None else 0, stats=stats).clone())
+    assert torch.equal(outs[0], outs[1])
+    y = ops.f32b_to_ncdhw(outs[0], (S, S, S)).cpu()
+    extra = bias[:, :, None, None, None] + (res if res is not None else 0.0)
+    ref = F.conv3d(ref_in.double(), w.double(), padding=1).float() + extra
+    e = rel_l2(y, ref)
+    # the restatement needs the kernel's own activated operand for a tight comparison only up to the activation's rounding
+    # (v_exp / v_rcp in the operand pass): 1e-6-level differences in t, far below the arithmetic's 1e-5
+    emu = _conv_f16f8_reference(ref_in, w) + extra
+    e_emu = rel_l2(y, emu)
+    print(f"f16f8 wino conv ({case}): vs torch fp64 {e:.2e}, vs the torch restatement of the arithmetic {e_emu:.2e}")
+    assert e < TOL_MFMA
+    assert e_emu < (4e-6 if c["gn"] else 2e-6)
+    if c["stats"]:
+        st, yd = stats.cpu(), y.double()
+        assert rel_l2(st[..., 0], yd.sum(dim=(2, 3, 4))) < 1e-6
+        assert rel_l2(st[..., 1], (yd * yd).sum(dim=(2, 3, 4))) < 1e-6
+
+
+def test_conv3_wino_f8_against_bf16x3_on_full_tiles(ops):
+    """256 -> 128 at 32^3, B = 2 (512 workgroups): the two arithmetics of the Winograd path on the same operands differ by
+    their rounding only (1.5e-5), and the f16f8 path is bit-identical between launches."""
+    B, S, cs, cout = 2, 32, [128, 128], 128
+    cin = sum(cs)
+    xs = [_rand((B, k, S, S, S), 170 + i) for i, k in enumerate(cs)]
+    gamma, beta = 1.0 + 0.2 * _rand((cin,), 172), 0.5 * _rand((cin,), 173)
+    w = _rand((cout, cin, 3, 3, 3), 174, 0.03)
+    bias = _rand((B, cout), 175)
+    parts = [(ops.ncdhw_to_f32b(t.cuda()), k) for t, k in zip(xs, cs)]
+    _, ac = ops.gn_params(parts, gamma.cuda(), beta.cuda(), B, S ** 3, want_ac=True)
+    w8, wb = ops.WinoWeightF8(w.cuda(), "cuda"), ops.WinoWeight(w.cuda(), "cuda")
+    outs = []
+    for _ in range(2):
+        t = ops.wino_prep(parts, ac, True, False, B, S, f8=True)
+        outs.append(ops.conv3_wino(w8, t, B, S, bias=bias.cuda(), bias_bstride=cout).clone())
+    assert torch.equal(outs[0], outs[1])
+    t = ops.wino_prep(parts, ac, True, False, B, S)
+    yb = ops.conv3_wino(wb, t, B, S, bias=bias.cuda(), bias_bstride=cout)
+    e = rel_l2(outs[0].cpu(), yb.cpu())
+    print(f"f16f8 vs bf16x3 Winograd conv: {e:.2e}")
+    assert e < 3e-5

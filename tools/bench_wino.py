@@ -27,6 +27,8 @@ def main():
     ap.add_argument("--out", default=None)
     ap.add_argument("--prep-v2", action="store_true", help="also time the experimental two-phase operand pass")
     ap.add_argument("--f43", action="store_true", help="also time the experimental F(4,3) kernels (md_wino43_*)")
+    ap.add_argument("--f8", action="store_true", help="also time the f16f8 arithmetic (md_wino_prep_f8 + md_conv3_wino_f8), interleaved with "
+                                                       "the bf16x3 production kernel (same box, same clocks)")
     ap.add_argument("--no-stats", action="store_true", help="launch without the GroupNorm-sum epilogue")
     ap.add_argument("--no-res", action="store_true", help="launch without the residual operand")
     ap.add_argument("--stamps", action="store_true", help="variant 128 (MD_BUILD_ABLATIONS=1): per-wave s_memtime stamps of the first 1024 workgroups")
@@ -79,6 +81,24 @@ def main():
                                  issued_frac_of_peak=round(flops * 0.5 * 3 / ms / 1e9 / 2500.0, 4)))
                 print(json.dumps(rows[-1]), flush=True)
             t = ops.wino_prep([(x, cin)], ac, True, False, B, S)      # the two paths share one scratch buffer: restore T
+        if a.f8 and 256 % S == 0:
+            ww8 = ops.WinoWeightF8(w, dev)
+            kw = dict(bias=bias, bias_bstride=cout, residual=None if a.no_res else res, res_bstride=0 if a.no_res else cout * S ** 3,
+                      stats=None if a.no_stats else stats, out=out)
+            for rep in range(3):           # a, b, a, b, a, b
+                ops.WINO_PREP_V2 = True
+                t = ops.wino_prep([(x, cin)], ac, True, False, B, S)
+                ms_p = timed(lambda: ops.wino_prep([(x, cin)], ac, True, False, B, S))
+                ms_a = timed(lambda: ops.conv3_wino(ww, t, B, S, variant=0, **kw))
+                t8 = ops.wino_prep([(x, cin)], ac, True, False, B, S, f8=True)
+                ms_p8 = timed(lambda: ops.wino_prep([(x, cin)], ac, True, False, B, S, f8=True))
+                ms_b = timed(lambda: ops.conv3_wino(ww8, t8, B, S, **kw))
+                ops.WINO_PREP_V2 = False
+                rows.append(dict(shape=sh, kernel="A/B bf16x3 vs f16f8", rep=rep, bf16x3_ms=round(ms_a, 4), f16f8_ms=round(ms_b, 4),
+                                 ratio=round(ms_b / ms_a, 4), prep_ms=round(ms_p, 4), prep_f8_ms=round(ms_p8, 4),
+                                 bf16x3_tflops_alg=round(flops / ms_a / 1e9, 1), f16f8_tflops_alg=round(flops / ms_b / 1e9, 1)))
+                print(json.dumps(rows[-1]), flush=True)
+            t = ops.wino_prep([(x, cin)], ac, True, False, B, S)      # restore the bf16 operand in the shared scratch buffer
         for v in [int(k) for k in a.variants.split(",")]:
             try:
                 ms = timed(lambda: ops.conv3_wino(ww, t, B, S, bias=bias, bias_bstride=cout, residual=None if a.no_res else res,

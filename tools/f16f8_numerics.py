@@ -1,0 +1,136 @@
+"""Numerics of the fp16 + fp8-cross-term operand split ("f16f8") on the CPU (PyTorch emulation):
+    a * b ~= fp16(a) * fp16(b)                                            one v_mfma_f32_32x32x16_f16
+           + [ e4m3(a) * e4m3(b_lo 2^11) + e4m3(a_lo 2^11) * e4m3(b) ] 2^-11   HALF a v_mfma_scale_f32_32x32x64_f8f6f4 (K-concatenated)
+ with a_lo = a - fp16(a): two 32-cycle matrix-core units per product instead of bf16x3's three.
+ (1) one 128 -> 128 3x3x3 conv through Winograd F(2,3) along w, vs fp64:   bf16x3 | f16f8
+ (2) --unet: one res64 U-Net evaluation (B = 1, sensitised weights, the SURVEY 7.1 experiment) where every conv that runs
+     on the Winograd path (3x3x3, stride 1, >= 16^3, Cin % 32 == 0, Cout % 128 == 0) is computed in the emulated arithmetic and
+     the rest in fp32, vs the same network in fp64.
+    python tools/f16f8_numerics.py [--unet] [--threads 32]
+"""
+import argparse
+import os
+import sys
+
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def q8(x):      # OCP e4m3fn, round to nearest even, saturating at +-448 (the kernel clamps before v_cvt_pk_fp8_f32)
+    return x.clamp(-448, 448).to(torch.float8_e4m3fn).float()
+
+
+def split_bf(x):
+    hi = x.to(torch.bfloat16).float()
+    return hi, (x - hi).to(torch.bfloat16).float()
+
+
+def conv_bf16x3(t, g):
+    th, tl = split_bf(t); gh, gl = split_bf(g)
+    return F.conv3d(th, gh) + F.conv3d(th, gl) + F.conv3d(tl, gh)
+
+
+def weight_exp(g):
+    """Power-of-two pre-scale of a weight tensor for its e4m3 images: max |g| 2^e in [128, 256)."""
+    m = float(g.abs().max())
+    return 0 if m == 0 else 7 - int(torch.floor(torch.log2(torch.tensor(m))).item())
+
+
+def conv_f16f8(t, g, sw=None):
+    sw = weight_exp(g) if sw is None else sw
+    th, gh = t.half().float(), g.half().float()
+    tl, gl = t - th, g - gh
+    cross = F.conv3d(q8(t), q8(gl * 2.0 ** (11 + sw))) + F.conv3d(q8(tl * 2.0 ** 11), q8(g * 2.0 ** sw))
+    return F.conv3d(th, gh) + cross * 2.0 ** -(11 + sw)
+
+
+def wino_conv(x, w, conv):
+    """3x3x3 pad-1 conv as F(2,3) along w with `conv` for the four (3,3,1) frequency contractions."""
+    B, Ci, D, H, W = x.shape
+    xp = F.pad(x, (1, 1, 1, 1, 1, 1)); Wd = W + 2
+    d0 = xp[..., 0:Wd - 3:2]; d1 = xp[..., 1:Wd - 2:2]; d2 = xp[..., 2:Wd - 1:2]; d3 = xp[..., 3:Wd:2]
+    T = [d0 - d2, d1 + d2, d2 - d1, d1 - d3]
+    g0, g1, g2 = w[..., 0], w[..., 1], w[..., 2]
+    G = [g0, (g0 + g1 + g2) * 0.5, (g0 - g1 + g2) * 0.5, g2]
+    m = [conv(T[f].contiguous(), G[f][..., None].contiguous()) for f in range(4)]
+    return torch.stack([m[0] + m[1] + m[2], m[1] - m[2] - m[3]], -1).reshape(B, w.shape[0], D, H, W)
+
+
+def rel(y, ref):
+    return float((y.double() - ref).norm() / ref.norm())
+
+
+def one_conv():
+    torch.manual_seed(0)
+    B, Ci, Co, S = 1, 128, 128, 16
+    x = F.silu(torch.randn(B, Ci, S, S, S) * 1.5 + 0.3)
+    w = torch.randn(Co, Ci, 3, 3, 3) * (1.0 / (27 * Ci) ** 0.5)
+    ref = F.conv3d(x.double(), w.double(), padding=1)
+    print("one 128->128 conv at 16^3 (SiLU-like input), rel-L2 vs fp64:")
+    print("  Winograd fp32        %.3e" % rel(wino_conv(x, w, F.conv3d), ref))
+    print("  Winograd bf16x3      %.3e" % rel(wino_conv(x, w, conv_bf16x3), ref))
+    print("  Winograd f16f8       %.3e" % rel(wino_conv(x, w, conv_f16f8), ref))
+    for sw in (0, 3, 12):
+        print("  Winograd f16f8, weight pre-scale 2^%-2d (auto: 2^%d)  %.3e" % (sw, weight_exp(w), rel(wino_conv(x, w, lambda t, g: conv_f16f8(t, g, sw)), ref)))
+
+
+def unet(seeds):
+    from meshdiffusion_amd import synth
+    from meshdiffusion_amd.config import get_config_res64
+    from meshdiffusion_amd.lib.diffusion.models import ddpm_res64, utils as mutils  # noqa: F401
+    from oracle import unet_oracle as uo
+    cfg = get_config_res64(); cfg.device = torch.device("cpu")
+    R = cfg.data.image_size
+    model = mutils.create_model(cfg, use_parallel=False)
+    sd = synth.sensitised_state_dict(model.state_dict(), seed=1234, grid_mask=synth.synthetic_grid_mask(R))
+    del model
+    ocfg = synth.oracle_cfg(cfg)
+    real_conv3d = F.conv3d
+    mode = {"m": None}
+
+    def patched(x, w, b=None, stride=1, padding=0, *a, **k):
+        st = stride if isinstance(stride, int) else stride[0]
+        pd = padding if isinstance(padding, int) else padding[0]
+        if (mode["m"] is not None and x.dtype == torch.float32 and tuple(w.shape[2:]) == (3, 3, 3) and st == 1 and pd == 1
+                and x.shape[-1] >= 16 and w.shape[1] % 32 == 0 and w.shape[0] % 128 == 0 and not a and not k):
+            y = wino_conv(x, w, mode["m"])
+            return y if b is None else y + b[None, :, None, None, None]
+        return real_conv3d(x, w, b, stride, padding, *a, **k)
+
+    for seed in seeds:
+        x = synth.synthetic_inputs(1, 4, R, seed=seed) * synth.synthetic_grid_mask(R).view(1, 1, R, R, R)
+        lab = torch.tensor([500.3])
+        with torch.no_grad():
+            sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+            te = uo.timestep_embedding
+            uo.timestep_embedding = lambda t, dim: te(t, dim).double()      # the oracle builds it in fp32
+            try:
+                ref = uo.unet_res64_forward(sd64, ocfg, x.double(), lab.double())
+            finally:
+                uo.timestep_embedding = te
+            F.conv3d = patched
+            try:
+                out = {}
+                for name, m in (("fp32", None), ("bf16x3 (Winograd convs)", conv_bf16x3), ("f16f8  (Winograd convs)", conv_f16f8)):
+                    mode["m"] = m
+                    out[name] = rel(uo.unet_res64_forward(sd, ocfg, x, lab), ref)
+            finally:
+                F.conv3d = real_conv3d
+        print(f"res64 U-Net evaluation, B = 1, t = 500.3, input seed {seed}: rel-L2 of eps vs fp64")
+        for k, v in out.items():
+            print(f"  {k:28s} {v:.3e}")
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--unet", action="store_true")
+    ap.add_argument("--threads", type=int, default=32)
+    ap.add_argument("--seeds", default="42")
+    a = ap.parse_args()
+    torch.set_num_threads(a.threads)
+    one_conv()
+    if a.unet:
+        unet([int(s) for s in a.seeds.split(",")])
