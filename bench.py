@@ -19,7 +19,7 @@ region carries no instrumentation.  Extra objects, all measured AFTER the timed 
   train_step    BASELINE configs[2] per GPU (res64 training step, batch 8, dropout 0.1) through the trainer's step
                 function; with N > 1 the gradients are exchanged by parallel.GradReducer over RCCL (the path's one
                 real collective: 1.456 GB of fp32 gradients per step)
-  other_configs configs[3] res128 B=2 sampling step (N = 1)
+  other_configs configs[3] res128 B=2 sampling step, configs[0] res64 B=1, configs[4] cond_gen B=32 + marching tets x 32 (N = 1)
   cpu_baseline  the CPU oracle restatement of the reference on the host cores (rank 0, N = 1 only)
 """
 import argparse
@@ -54,9 +54,10 @@ def parse():
     ap.add_argument("--batch", type=int, default=8, help="samples per GPU (configs[1]: 8)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
-    ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "fp16x2"],
-                    help="arithmetic of the hot conv kernel for the headline number (DESIGN.md section 3)")
-    ap.add_argument("--no-fast-mode", action="store_true", help="skip the extra fp16x2 measurement")
+    ap.add_argument("--precision", default="f16f8", choices=["bf16x3", "fp16x2", "f16f8"],
+                    help="arithmetic of the hot conv kernel for the headline number (DESIGN.md section 3): f16f8 = the package default "
+                         "(config.model.hip_precision), bf16x3 = the round-1..3 arithmetic")
+    ap.add_argument("--no-fast-mode", action="store_true", help="skip the second measurement in the other arithmetic (bf16x3_mode)")
     ap.add_argument("--no-train-step", action="store_true", help="skip the configs[2] training-step measurement")
     ap.add_argument("--train-steps", type=int, default=3)
     ap.add_argument("--no-res128", action="store_true", help="skip the configs[3] res128 B=2 measurement")
@@ -188,7 +189,7 @@ def main():
             events, hip_ops.PROFILE = hip_ops.PROFILE, None
             # the same convolutions through the DIRECT 27-tap kernel (fused operand loader, no Winograd transform), 2 steps:
             # the r02 mid-round build, measured in the same process on the same box
-            if hip_ops.WINO and a.precision == "bf16x3":
+            if hip_ops.WINO and a.precision in ("bf16x3", "f16f8"):
                 hip_ops.WINO = False
                 x2, _ = run.step(model_fn, x, it)                     # packs the direct kernel's weight tiles (untimed)
                 hip_ops.PROFILE = []
@@ -198,13 +199,13 @@ def main():
                 events_unfused, hip_ops.PROFILE = hip_ops.PROFILE, None
                 hip_ops.WINO = True
 
-    # ---- optional second measurement: the opt-in fp16x2 arithmetic on the same workload ----
+    # ---- second measurement on the same workload, same process: the round-1..3 arithmetic (bf16x3 in the Winograd convs too) ----
     fast = None
-    if a.precision == "bf16x3" and not a.no_fast_mode and world == 1:
-        model.module.hip_precision = "fp16x2"
+    if a.precision == "f16f8" and not a.no_fast_mode and world == 1:
+        model.module.hip_precision = "bf16x3"
         with torch.no_grad():
             xf = stepper.prior()
-            for k in range(max(a.warmup, 1)):
+            for k in range(max(a.warmup, 2)):      # packs the bf16x3 Winograd fragments (untimed)
                 xf, _ = stepper.step(model_fn, xf, k)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
@@ -214,12 +215,12 @@ def main():
             wf = time.perf_counter() - t1
         model.module.hip_precision = a.precision
         hip_ops.set_precision(a.precision)
-        fast = {"precision": "fp16x2 (weights split fp16, activations fp16, 2 MFMAs/product; opt-in: "
-                             "config.model.hip_precision)", "value": round(B * a.steps / wf, 3),
-                "unit": "sample-steps/s", "ms_per_step": round(wf / a.steps * 1e3, 3),
-                "parity": "999-step sampled grids 6.9e-5 rel-L2 vs fp32 (profiles/r01_longrun_999step_act_fp16_experiment.json); "
-                          "~1e-3 per U-Net evaluation"}
-
+        fast = {"precision": "bf16x3 everywhere (three bf16 MFMAs per product; config.model.hip_precision = \"bf16x3\"): the headline "
+                             "arithmetic of rounds 1-3, measured here in the same process on the same box",
+                "value": round(B * a.steps / wf, 3), "unit": "sample-steps/s", "ms_per_step": round(wf / a.steps * 1e3, 3),
+                "parity": "per U-Net evaluation 1.2-2.2e-5, 999-step sampled grids 8.4-8.6e-6 rel-L2 vs the fp32 oracle (profiles/r02_*, r03_longrun_*); "
+                          "f16f8 (the headline): 4e-5 per evaluation (tools/f16f8_numerics.py), long-run record in profiles/r04_longrun_*"}
+        del xf, xmf
     # ---- BASELINE configs[0] on the GPU: res64, batch 1 (single-sample latency), same weights ----
     b1 = None
     if world == 1 and B != 1 and not a.no_res128:
@@ -243,6 +244,13 @@ def main():
     if dist is not None:
         dist.all_reduce(wall_t, op=dist.ReduceOp.MAX)
     wall = float(wall_t.item())
+
+    # ---- BASELINE configs[4] (N = 1): cond_gen inpainting at batch 32 and the marching-tets launch ----
+    cfg4 = None
+    if world == 1 and not a.no_res128:
+        model.module.hip_precision = a.precision
+        cfg4 = {"cond_gen_res64_b32": cond_gen_bench(dev, model, cfg), "marching_tets_b32": marching_tets_bench(dev)}
+        torch.cuda.empty_cache()
 
     # ---- BASELINE configs[2]: the training step of this rank's batch shard (all ranks; RCCL gradient exchange) ----
     train = None
@@ -287,6 +295,8 @@ def main():
             other = {"res128_b2": res128_step(dev)}
             if b1 is not None:
                 other["res64_b1"] = b1
+            if cfg4 is not None:
+                other.update(cfg4)
         cpu = None
         if world == 1 and not a.no_cpu_baseline:
             cpu = cpu_baseline(sd_cpu, cfg, synth)
@@ -295,15 +305,20 @@ def main():
             "value": round(value, 3), "unit": "sample-steps/s",
             "n_gpus": dist.get_world_size() if dist is not None else 1, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": ("bf16x3 (split-bf16 MFMA operands, fp32 accumulate/IO)" if a.precision == "bf16x3" else
-                                           "fp16x2 (weights split fp16, activations fp16, fp32 accumulate/IO)"),
+            "scaling": "weak", "vs_baseline": None,
+            "parity": "sampled grids vs the fp32 oracle over the full schedule and per-evaluation figures: profiles/r04_longrun_*.json, "
+                      "DESIGN.md section 5 (target 1e-3 rel-L2)",
+            "dtype": {"bf16x3": "bf16x3 (split-bf16 MFMA operands, fp32 accumulate/IO)",
+                                            "fp16x2": "fp16x2 (weights split fp16, activations fp16, fp32 accumulate/IO)",
+                                            "f16f8": "f16f8 in the Winograd convs (fp16 hi*hi MFMA + e4m3 cross terms in a K-concatenated scaled fp8 "
+                                                     "MFMA: 2 matrix-core units per product), bf16x3 elsewhere; fp32 accumulate/IO"}[a.precision],
             "data": "synthetic (seeded prior noise, sensitised random-init res64 weights, synthetic grid mask)",
             "config": {"workload": "BASELINE configs[1]: res64 4-ch grid DDPM ancestral sampling steps, batch=8 per GPU",
                        "batch_per_gpu": B, "grid": [cfg.data.num_channels, R, R, R],
                        "sharding": "independent sample shards per GPU, no data-path collective",
                        "launch": "hipGraph replay" if a.graph else "eager launches through the C ABI"},
             "roofline": roof, "whole_step": whole, "train_step": train, "other_configs": other,
-            "hbm_bound_kernels": hbm_kernels, "cpu_baseline": cpu, "fast_mode": fast,
+            "hbm_bound_kernels": hbm_kernels, "cpu_baseline": cpu, "bf16x3_mode": fast,
             "setup_s": round(t_setup, 1),
         }
         print(json.dumps(line), flush=True)
@@ -349,14 +364,19 @@ def roofline(events, hip_ops, a, B, wall_prof):
         with open(TRAFFIC_FILE) as fh:
             tr = json.load(fh)
         ent = tr.get(key)
-        if ent and a.precision == "bf16x3" and B == ent.get("batch", 8):
+        if ent and a.precision == ent.get("precision", "bf16x3") and B == ent.get("batch", 8):
             traffic, traffic_src = ent["hbm_bytes_per_launch"], f"profiles/conv_traffic.json[{key}] <- {ent.get('source')}"
         else:
             traffic_src = f"profiles/conv_traffic.json has no entry for kernel build {key} (batch {B}, {a.precision}): re-profile"
     except OSError:
         traffic_src = "profiles/conv_traffic.json missing"
-    fused = bool(hip_ops.FUSE_GN_APPLY and a.precision == "bf16x3")
-    if wino:
+    fused = bool(hip_ops.FUSE_GN_APPLY and a.precision in ("bf16x3", "f16f8"))
+    f8 = wino and a.precision == "f16f8"
+    if f8:
+        kname = ("md_conv3_wino_kernel<0, true> (md_conv3_wino_f8: 3x3x3 conv as Winograd F(2,3) along w, 9 taps x 4 frequencies, one frequency "
+                 "per wave; f16f8 arithmetic: per two steps and accumulator tile two v_mfma_f32_32x32x16_f16 + one K-concatenated "
+                 "v_mfma_scale_f32_32x32x64_f8f6f4 (e4m3 cross terms); operand prepared by md_wino_prep_f8)")
+    elif wino:
         kname = ("md_conv3_wino_kernel<0> (3x3x3 conv as Winograd F(2,3) along w: 9 taps x 4 frequencies, bf16x3 MFMA, one frequency "
                  "per wave; operand prepared by md_wino_prep)")
     elif fused:
@@ -382,10 +402,13 @@ def roofline(events, hip_ops, a, B, wall_prof):
                               "conv_plus_prep_tflops": round(tot_f / (tot_t + prep_t) / 1e12, 2),
                               "conv_plus_prep_frac": round(tot_f / (tot_t + prep_t) / 1e12 / PEAK_BF16_TFLOPS, 4)} if wino and prep_t > 0 else None),
             "per_shape": per_shape,
-            "note": "achieved = algorithmic 2*27*Cin*Cout*P flops of the convolution (1x: not the 3 bf16 MFMAs issued per product, "
+            "issued_matrix_core_frac": round(ach * (4.0 / 3.0 if f8 else 2.0) / PEAK_BF16_TFLOPS, 4) if wino else None,
+            "note": "achieved = algorithmic 2*27*Cin*Cout*P flops of the convolution (1x: not the matrix-core units issued per product, "
                     "and not reduced by the Winograd factor 2/3) / HIP-event time of every launch of this kernel in an untimed "
                     "pass right after the timed region (the timed region itself carries no events); the kernel ISSUES "
-                    "achieved * 3 * 2/3 = 2 * achieved of bf16 MFMA work"}
+                    + ("achieved * 2 * 2/3 = 4/3 * achieved of 32-cycle matrix-core units (one fp16 MFMA + half an fp8 K = 64 MFMA per "
+                       "product; issued_matrix_core_frac prices them at the bf16 peak)" if f8 else
+                       "achieved * 3 * 2/3 = 2 * achieved of bf16 MFMA work")}
 
 
 def train_step_bench(a, cfg, model, rank, world, dev, dist, barrier):
@@ -483,6 +506,79 @@ def res128_step(dev, steps=3, warmup=2):
     del model, st, x, xm
     torch.cuda.empty_cache()
     return out
+
+
+def kuhn_tet_grid(n):
+    """A synthetic tet grid of the reference grid's size class (the real 64-resolution grid is a data asset of the reference:
+    159 330 tets / 195 331 edges): an n^3 cube lattice, every cube split into the 6 Kuhn tetrahedra."""
+    ax = torch.arange(n + 1)
+    X, Y, Z = torch.meshgrid(ax, ax, ax, indexing="ij")
+    verts = torch.stack([X, Y, Z], -1).reshape(-1, 3).float() / n * 2 - 1
+    vid = lambda x, y, z: (x * (n + 1) + y) * (n + 1) + z      # noqa: E731
+    cx, cy, cz = [t.reshape(-1) for t in torch.meshgrid(torch.arange(n), torch.arange(n), torch.arange(n), indexing="ij")]
+    import itertools
+    tets = []
+    for perm in itertools.permutations(range(3)):
+        p = [cx, cy, cz]
+        corners = [vid(*p)]
+        for axis in perm:
+            p = [c + (1 if k == axis else 0) for k, c in enumerate(p)]
+            corners.append(vid(*p))
+        tets.append(torch.stack(corners, -1))
+    return verts, torch.cat(tets, 0)
+
+
+def marching_tets_bench(dev, M=32):
+    """BASELINE configs[4], first half: md_marching_tets on M = 32 meshes per launch (deformed tet grid + SDF per mesh)."""
+    from meshdiffusion_amd import dmtet
+    verts, tets = kuhn_tet_grid(30)
+    tables = dmtet.TetTables(tets, dev)
+    g = torch.Generator().manual_seed(11)
+    N = verts.shape[0]
+    pos = (verts[None] + 0.01 * torch.randn((M, N, 3), generator=g)).to(dev)
+    r = verts.norm(dim=1)
+    sdf = torch.stack([0.55 + 0.01 * m - r + 0.05 * torch.sin(9 * verts[:, 0] + m) for m in range(M)]).to(dev)
+    meshes, cnt = dmtet.marching_tets_batch(pos, sdf, tables)
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(5):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        meshes, cnt = dmtet.marching_tets_batch(pos, sdf, tables)       # includes the one host sync for the result sizes
+        torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+    dt = sorted(ts)[len(ts) // 2]
+    V, F = int(cnt[:, 0].sum()), int(cnt[:, 1].sum())
+    T, E = tables.n_tets, tables.n_edges
+    alg = M * (N * 16 + T * 40 + E * 8) + V * 12 + F * 32       # per mesh: sdf + pos, the static tables (L2-resident), verts + faces + face->tet out
+    return {"workload": f"BASELINE configs[4]: marching tetrahedra, {M} meshes per launch (synthetic Kuhn tet grid: {T} tets, {E} unique "
+                        f"edges, {N} vertices; the reference's 64-resolution grid has 159330 / 195331 / 36562)",
+            "ms_per_launch": round(dt * 1e3, 3), "meshes_per_s": round(M / dt, 1), "verts_total": V, "faces_total": F,
+            "algorithmic_bytes_per_launch": alg, "achieved_gbs": round(alg / dt / 1e9, 1), "hbm_frac": round(alg / dt / 1e9 / PEAK_HBM_GBS, 4),
+            "note": "includes the call's one device->host copy of the per-mesh vertex / face counts"}
+
+
+def cond_gen_bench(dev, model, cfg, B=32, iters=3):
+    """BASELINE configs[4], second half: the pc sampler with a partial grid (cond_gen inpainting: blend + re-noise every
+    iteration), res64, batch 32 on one GPU; a few iterations from the start of the schedule."""
+    from meshdiffusion_amd import synth
+    from meshdiffusion_amd.lib.diffusion import sampling, sde_lib
+    R = cfg.data.image_size
+    sde = sde_lib.VPSDE(cfg.model.beta_min, cfg.model.beta_max, cfg.model.num_scales, device=dev)
+    mask = synth.synthetic_grid_mask(R).to(dev)
+    g = torch.Generator().manual_seed(5)
+    partial = torch.sign(torch.randn((1, 1, R, R, R), generator=g)).to(dev)
+    pmask = (torch.rand((1, 1, R, R, R), generator=g) < 0.5).float().to(dev) * mask.view(1, 1, R, R, R)
+    pmask[..., R // 2:] = 0
+    fn = sampling.get_sampling_fn(cfg, sde, (B, 4, R, R, R), lambda t: t, 1e-3, grid_mask=mask.view(1, 1, R, R, R))
+    torch.cuda.reset_peak_memory_stats()
+    fn(model, partial=partial, partial_mask=pmask, freeze_iters=950, n_iters=1)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    out, _ = fn(model, partial=partial, partial_mask=pmask, freeze_iters=950, n_iters=iters)
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / iters
+    assert bool(torch.isfinite(out).all())
+    return {"workload": f"BASELINE configs[4]: cond_gen partial-grid inpainting sampler (pc, blend + re-noise), res64, batch {B}",
+            "ms_per_iteration": round(dt * 1e3, 1), "sample_steps_per_s": round(B / dt, 2), "iterations": iters,
+            "mfma_frac_step": round(B * FLOPS_PER_SAMPLE_STEP / dt / (PEAK_BF16_TFLOPS * 1e12), 4),
+            "peak_hbm_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}
 
 
 def hbm_bound_kernels(dev, B):

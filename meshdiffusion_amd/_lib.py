@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmeshdiffusion_hip.so")
+LIB_PATH = os.environ.get("MD_LIB") or os.path.join(_HERE, "libmeshdiffusion_hip.so")   # MD_LIB: an A/B build (build.py MD_LIB_SUFFIX)
 
 # MD_CFG_* (include/meshdiffusion_hip.h)
 (CFG_C3_128, CFG_C3_128_K16, CFG_C3_32, CFG_C3_LOW, CFG_C3_S2, CFG_G1_128, CFG_G1_128_LOW, CFG_G1_64_LOW,

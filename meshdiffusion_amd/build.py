@@ -11,8 +11,11 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
-OBJDIR = os.path.join(CSRC, "build")
-LIB_PATH = os.path.join(HERE, "libmeshdiffusion_hip.so")
+# A/B builds of a kernel under development (tools/bench_wino.py --lib): MD_LIB_SUFFIX=_v1 MD_EXTRA_DEFINES="-DW8_SCHED=1" writes
+# libmeshdiffusion_hip_v1.so from its own object directory; MD_LIB=<path> makes _lib.py load it.  The default build has neither.
+_SUFFIX = os.environ.get("MD_LIB_SUFFIX", "")
+OBJDIR = os.path.join(CSRC, "build" + _SUFFIX)
+LIB_PATH = os.path.join(HERE, f"libmeshdiffusion_hip{_SUFFIX}.so")
 ARCH = "gfx950"
 SOURCES = ["capi.hip", "gemm_conv.hip", "conv3_main.hip", "conv3_wino.hip", "conv3_s2.hip", "conv3_head.hip", "conv3_stem.hip", "pack_batch.hip", "wino_prep2.hip", "norm.hip", "elementwise.hip", "attention.hip", "nin_stream.hip", "train.hip", "backward.hip", "wgrad.hip", "wgrad_wino.hip", "dmtet.hip"]
 # default-off experiments (MD_BUILD_EXPERIMENTAL=1): declared in include/meshdiffusion_hip_experimental.h, bound lazily by _lib.py
@@ -46,7 +49,7 @@ def build(verbose=False, force=False):
     headers = [os.path.join(CSRC, "md_common.h"), os.path.join(CSRC, "md_pack.h"), os.path.join(INCLUDE, "meshdiffusion_hip.h")]
     flags = FLAGS + (["-DMD_BUILD_ABLATIONS"] if os.environ.get("MD_BUILD_ABLATIONS") == "1" else [])
     experimental = os.environ.get("MD_BUILD_EXPERIMENTAL") == "1"
-    flags = flags + (["-DMD_BUILD_EXPERIMENTAL"] if experimental else [])
+    flags = flags + (["-DMD_BUILD_EXPERIMENTAL"] if experimental else []) + os.environ.get("MD_EXTRA_DEFINES", "").split()
     stamp = os.path.join(OBJDIR, "flags.txt")
     if not os.path.exists(stamp) or open(stamp).read() != " ".join(flags):
         force = True

@@ -302,7 +302,8 @@ __global__ __launch_bounds__(WN_THREADS) void md_conv3_wino_kernel(const WnArgs 
     //  || the 4 B fragments of the NEXT group (16 registers, double-buffered per group: LDS latency is one group at most)
     //  || 8 of the 16 weight pieces of the NEXT pair-step in groups 0 and 1 (two register sets of 64: a piece is a 1 KB-contiguous
     //     16-byte load per lane as before; this wave's 16 pieces of a pair-step are 16 KB contiguous)
-    //  || one halo piece of a later chunk requested, one requested two pair-steps earlier stored (two register slots of 4 pieces):
+    //  || up to four halo pieces of a later chunk requested (groups 2, 3), one requested two pair-steps earlier stored per group (two
+    //     register slots of 4 pieces):
     //     chunk c0 + 1 (buffer 1, free from pair-step 0 on: its last reader is pair-step 8 of the body before): requested at
     //     pair-steps 7, 8 (of the body before; the prologue for chunk 1) and 0, 1, stored at 0, 1, 2, 3 -- the first reader is the
     //     prefetch of pair-step 4's fragments in the last group of pair-step 3, issued after that group's store;
@@ -317,15 +318,9 @@ __global__ __launch_bounds__(WN_THREADS) void md_conv3_wino_kernel(const WnArgs 
     // The source offsets of the 15 halo pieces (loop-invariant, ~45 VALU each to recompute, 15 registers to keep) live in a
     // 3.75 KB table per wave behind the halo buffers (the epilogue's exchange area reuses the space): one ds_read_b32 per request.
     // Bit k of live_mask: this lane's entry of piece k lies inside the grid (the compiler keeps the 15 masks in SGPR pairs).
-    int* otab = (int*)(wn_smem + 4 * WN_WAVE_LDS) + wid * (WN_NDMA * 64) + lane;
+    uint32_t* otab = (uint32_t*)(wn_smem + 4 * WN_WAVE_LDS) + wid * (WN_NDMA * 64) + lane;      // unsigned: no sign extension behind the read
     static_assert(4 * WN_WAVE_LDS + 4 * WN_NDMA * 64 * 4 <= WN_LDS_BYTES, "offset tables fit behind the halo buffers");
     uint32_t live_mask = 0;
-#pragma unroll
-    for (int k = 0; k < WN_NDMA; ++k) {
-      const int dk = halo_off(k);
-      otab[k * 64] = dk >= 0 ? dk : 0;          // outside the grid: a valid address (entry 0 of the chunk), zeroed on its way to LDS
-      live_mask |= (dk >= 0 ? 1u : 0u) << k;
-    }
     constexpr int D1 = 64, D2 = (40 - 8) * 16, D3 = WN_HBUF - (2 * 40 + 2 * 4) * 16;      // address of step 2u+1 minus step 2u
     const unsigned char* vBh = my_smem + h * 2 * WN_TPOS * 16 + j * 16;                    // k-group h, plane 0 (fp16)
     const unsigned char* vB8a = my_smem + WN_TPOS * 16 + j * 16 + h * D1;                  // k-group 0, plane 1 (fp8), step 2u + h
@@ -336,7 +331,6 @@ __global__ __launch_bounds__(WN_THREADS) void md_conv3_wino_kernel(const WnArgs 
       const wn_i32x4 a = __builtin_bit_cast(wn_i32x4, x), b = __builtin_bit_cast(wn_i32x4, y);
       return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
     };
-    auto halo_load8 = [&](int chunk, int k) -> uint4 { return wn_gload16(tbase + (int64_t)chunk * 16 * Ph + otab[k * 64]); };
     auto halo_store8 = [&](int buf, int k, uint4 v) {
       const bool lv = (live_mask >> k) & 1u;
       v.x = lv ? v.x : 0u; v.y = lv ? v.y : 0u; v.z = lv ? v.z : 0u; v.w = lv ? v.w : 0u;
@@ -361,20 +355,30 @@ __global__ __launch_bounds__(WN_THREADS) void md_conv3_wino_kernel(const WnArgs 
           A8f[set][rt] = cat8(wp[(rt * 4 + 2) * 64], wp[(rt * 4 + 3) * 64]);
         }
     };
-    // ---- prologue: chunk 0 -> buffer 0; pieces 0..7 of chunk 1 into the two slots; weights of pair-step 0 ----
+    // ---- prologue: weights of pair-step 0; chunk 0 -> buffer 0 and pieces 0..7 of chunk 1 into the two slots, every request issued
+    // as soon as its offset is known (the ~45 VALU of an offset run under the requests already in flight); the offset table ----
     {
       uint4 h0[WN_NDMA];
-#pragma unroll
-      for (int k = 0; k < WN_NDMA; ++k) h0[k] = halo_load8(0, k);
       load_A8(0, 0, 0, 4);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) { hs8[0][q] = halo_load8(1, q); hs8[1][q] = halo_load8(1, 4 + q); }
+      for (int k = 0; k < WN_NDMA; ++k) {
+        const int dk = halo_off(k);
+        const uint32_t o = dk >= 0 ? (uint32_t)dk : 0u;      // outside the grid: a valid address (entry 0 of the chunk), zeroed on its way to LDS
+        live_mask |= (dk >= 0 ? 1u : 0u) << k;
+        otab[k * 64] = o;
+        h0[k] = wn_gload16(tbase + o);
+        if (k < 8) hs8[k >> 2][k & 3] = wn_gload16(tbase + (int64_t)16 * Ph + o);
+      }
 #pragma unroll
       for (int k = 0; k < WN_NDMA; ++k) halo_store8(0, k, h0[k]);
     }
     read_B8(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, B8h[0], B8f[0]);
     mark(1);
     const int scale_a = 127 - 11, scale_b = 127;       // E8M0: the fp8 products carry 2^-11
+    // first of the (up to) four halo pieces pair-step u requests, two in group 2 and two in group 3 (99 = none): pieces 8..14 of
+    // chunk c0 + 1 at pair-steps 0, 1; all of c0 + 2 at 3..6; 0..7 of c0 + 3 at 7, 8
+    auto base_of = [](int u) constexpr -> int { return u == 0 ? 8 : (u == 1 ? 12 : (u >= 3 && u <= 6 ? (u - 3) * 4 : (u >= 7 ? (u - 7) * 4 : 99))); };
+    uint32_t off_next[2] = {0u, 0u};                     // source offsets of the next group's requests, read one group ahead
     auto body = [&](auto pbc, int c0) {
       constexpr int PB = decltype(pbc)::value;
       const int p0 = (c0 * 9) >> 1;
@@ -382,44 +386,74 @@ __global__ __launch_bounds__(WN_THREADS) void md_conv3_wino_kernel(const WnArgs 
       auto group = [&](auto uc, auto ctc) {
         constexpr int u = decltype(uc)::value, ct = decltype(ctc)::value;
         constexpr int aset = (PB + u) & 1, bset = ct & 1;
-        // -- halo piece stored (requested two pair-steps ago), then the next group's fragments (LDS executes a wave's accesses in order)
+        constexpr int un = ct < 3 ? u : (u + 1) % 9, ctn = ct < 3 ? ct + 1 : 0;      // the group after this one
+        // Three fenced parts, one per MFMA pass over the 4 row tiles (hipcc otherwise lines the three MFMAs of an accumulator up
+        // back to back -- a dependent chain with hazard nops between the fp16 and the fp8 form -- and clumps the memory operations):
+        // -- pass 0 (fp16, step 2u): the halo piece requested two pair-steps ago goes to LDS, then the next group's fragments are
+        //    read (LDS executes a wave's accesses in order: the first reader of a refilled buffer is issued behind its last store)
         constexpr int st_piece = u <= 3 ? u * 4 + ct : (u >= 5 ? (u - 5) * 4 + ct : 99);
         constexpr int st_slot = u <= 3 ? (u & 1) : ((u - 5) & 1);
         if constexpr (st_piece < WN_NDMA) halo_store8(u <= 3 ? 1 : 0, st_piece, hs8[st_slot][ct]);
-        if constexpr (ct < 3) read_B8(uc, std::integral_constant<int, ct + 1>{}, B8h[bset ^ 1], B8f[bset ^ 1]);
-        else read_B8(std::integral_constant<int, (u + 1) % 9>{}, std::integral_constant<int, 0>{}, B8h[bset ^ 1], B8f[bset ^ 1]);
-        // -- weights of the next pair-step: 8 pieces in each of the first two groups
-        if constexpr (ct < 2) {
-          const int pn = p0 + u + 1 < npairs ? p0 + u + 1 : npairs - 1;      // clamped: the redundant tail request is never used
-          load_A8(pn, aset ^ 1, ct * 2, 2);
-        }
-        // -- halo piece of a later chunk requested
-        constexpr int ld_piece = u == 0 ? 8 + ct : (u == 1 ? 12 + ct : (u >= 3 && u <= 6 ? (u - 3) * 4 + ct : (u >= 7 ? (u - 7) * 4 + ct : 99)));
-        constexpr int ld_slot = u == 0 ? 0 : (u == 1 ? 1 : ((u - 3) & 1));      // alternates over the eight requesting pair-steps 0 1 3 4 5 6 7 8
-        if constexpr (ld_piece < WN_NDMA) hs8[ld_slot][ct] = halo_load8(u <= 1 ? cn1 : (u <= 6 ? cn2 : cn3), ld_piece);
-        // -- the 12 MFMAs
+        read_B8(std::integral_constant<int, un>{}, std::integral_constant<int, ctn>{}, B8h[bset ^ 1], B8f[bset ^ 1]);
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt)
           acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A8h[aset][rt][0]), __builtin_bit_cast(f16x8, B8h[bset][0]),
                                                                acc[rt][ct], 0, 0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if constexpr (st_piece < WN_NDMA) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        // -- pass 1 (fp16, step 2u + 1): groups 2 and 3 request two halo pieces of a later chunk each, from the offsets read out of
+        //    the table one group earlier -- BEHIND the weight loads of groups 0 and 1 in the memory queue: loads return in order,
+        //    and the wait for the weights at the next pair-step must not cover a halo request (an HBM access) issued just before them
+        constexpr int ld_base = base_of(u), ldn_base = base_of(un);
+        constexpr int ld_slot = u == 0 ? 0 : (u == 1 ? 1 : ((u - 3) & 1));      // alternates over the eight requesting pair-steps 0 1 3 4 5 6 7 8
+        constexpr int q0 = 2 * (ct - 2), qn = 2 * (ctn - 2);
+        constexpr int n_ld = ct < 2 ? 0 : ((ld_base + q0 < WN_NDMA) + (ld_base + q0 + 1 < WN_NDMA));
+        constexpr int n_rd = ctn < 2 ? 0 : ((ldn_base + qn < WN_NDMA) + (ldn_base + qn + 1 < WN_NDMA));
+        if constexpr (n_ld > 0) {
+          const uint4* cb = tbase + (int64_t)(u <= 1 ? cn1 : (u <= 6 ? cn2 : cn3)) * 16 * Ph;
+          hs8[ld_slot][q0] = wn_gload16(cb + off_next[0]);
+          if constexpr (n_ld > 1) hs8[ld_slot][q0 + 1] = wn_gload16(cb + off_next[1]);
+        }
+        if constexpr (n_rd > 0) off_next[0] = otab[(ldn_base + qn) * 64];
+        if constexpr (n_rd > 1) off_next[1] = otab[(ldn_base + qn + 1) * 64];
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt)
           acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A8h[aset][rt][1]), __builtin_bit_cast(f16x8, B8h[bset][1]),
                                                                acc[rt][ct], 0, 0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if constexpr (n_rd > 0) __builtin_amdgcn_sched_group_barrier(0x100, n_rd, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if constexpr (n_ld > 0) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if constexpr (n_ld > 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        // -- pass 2 (fp8, both steps; 64 cycles per MFMA): in the first two groups the 16 weight pieces of the next pair-step
+#ifndef W8_NA
+#define W8_NA 2
+#endif
+        constexpr int NA = W8_NA;            // groups that carry the 16 weight loads (A/B: 1 = all in group 0)
+        if constexpr (ct < NA) {
+          const int pn = p0 + u + 1 < npairs ? p0 + u + 1 : npairs - 1;      // clamped: the redundant tail request is never used
+          load_A8(pn, aset ^ 1, ct * (4 / NA), 4 / NA);
+        }
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt)
           acc[rt][ct] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A8f[aset][rt], B8f[bset], acc[rt][ct], 0, 0, 0, scale_a, 0, scale_b);
-        // -- placement: one memory operation and a handful of the address VALU (the ~50 of a halo request, the 4 selects of a
-        // halo store) behind every MFMA: the LDS store and the 4 fragment reads first, then the weight loads, the halo request last
+        if constexpr (ct < NA) {
 #pragma unroll
-        for (int i_ = 0; i_ < 12; ++i_) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          if (i_ == 0 && st_piece < WN_NDMA) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-          if (i_ == 0 && ld_piece < WN_NDMA) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // the piece's table entry
-          if (i_ >= 1 && i_ <= 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-          if (i_ >= 5 && i_ <= 8 && ct < 2) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
-          if (i_ == 10 && ld_piece < WN_NDMA) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-          if (i_ < 10) __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+          for (int i_ = 0; i_ < 4; ++i_) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 8 / NA / 2, 0);      // 16 / NA loads over the 4 MFMAs
+          }
         }
         __builtin_amdgcn_sched_barrier(0);
       };
@@ -752,8 +786,13 @@ extern "C" int md_conv3_wino_f8(const void* t_in, const void* wpk, float* out, c
   a.batch = batch; a.cin = cin; a.cout = cout; a.D = D; a.H = H; a.W = W;
   const int tiles = (D / WN_TZ) * (H / WN_TY) * (W / WN_TX);
   MD_HIP_CLEAR_ERROR();
+#ifdef W8_STAMPS      // A/B build only (tools/bench_wino.py --f8 --stamps): `stats` receives the per-wave s_memtime stamps, no statistics
+  hipLaunchKernelGGL((md_conv3_wino_kernel<128, true>), dim3((unsigned)(tiles * batch), (unsigned)(cout / 128)), dim3(WN_THREADS), 0,
+                     (hipStream_t)stream, a);
+#else
   hipLaunchKernelGGL((md_conv3_wino_kernel<0, true>), dim3((unsigned)(tiles * batch), (unsigned)(cout / 128)), dim3(WN_THREADS), 0,
                      (hipStream_t)stream, a);
+#endif
   MD_HIP_CHECK_LAUNCH();
   return MD_OK;
 }

@@ -33,8 +33,12 @@ if PRECISION == "f16f8":
     PRECISION, WINO_F8 = "bf16x3", True
 
 
+FORCE_PRECISION = os.environ.get("MD_FORCE_PRECISION")      # A/B runs of the test suite / CLI: wins over config.model.hip_precision
+
+
 def set_precision(mode):
     global PRECISION, WINO_F8
+    mode = FORCE_PRECISION or mode
     if mode not in ("bf16x3", "fp16x2", "f16f8"):
         raise ValueError(f"unknown precision mode {mode!r}")
     PRECISION, WINO_F8 = ("bf16x3", True) if mode == "f16f8" else (mode, False)

@@ -40,10 +40,18 @@ def main():
                     help="oracle: the fp32 PyTorch restatement on the same GPU (default); direct: the HIP path with the direct 27-tap "
                          "kernels (MD_WINO=0) -- the build whose 999-step parity vs the oracle is on record -- so that a B = 8 run "
                          "of the full schedule costs minutes instead of half an hour of fp32 torch convolutions")
+    ap.add_argument("--precision", default=None, help="config.model.hip_precision of the HIP path (default: the config's: f16f8)")
+    ap.add_argument("--oracle-samples", default=None,
+                    help="comma-separated sample indices: the HIP path runs the whole batch (the graded B = 8 launches), the fp32 oracle "
+                         "only these samples of it on the same noise (samples are independent: GroupNorm is per sample) -- a 999-step "
+                         "B = 8 run then costs 2/8 of the 27 GPU-minutes of fp32 torch convolutions")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     cfg = get_config_res64() if a.config == "res64" else synth.small_config()
     cfg.device = dev
+    if a.precision:
+        cfg.model.hip_precision = a.precision
+    a.sel = [int(v) for v in a.oracle_samples.split(",")] if a.oracle_samples else None
     R = cfg.data.image_size
     model = mutils.create_model(cfg).eval()
     sd = synth.sensitised_state_dict(model.module.state_dict(), seed=1234, grid_mask=synth.synthetic_grid_mask(R))
@@ -70,7 +78,8 @@ def main():
 def one_seed(a, seed, st, model_fn, sd_gpu, ocfg, shape, dev, mask):
     torch.manual_seed(seed)
     x_h = st.prior()
-    x_o = x_h.clone()
+    sel = a.sel if a.sel is not None else list(range(shape[0]))
+    x_o = x_h[sel].clone()
     ts = st.timesteps
     marks = sorted(set([1, 10, 50, 100, 200, 400, 600, 800, a.steps]))
     log = []
@@ -91,20 +100,26 @@ def one_seed(a, seed, st, model_fn, sd_gpu, ocfg, shape, dev, mask):
                 finally:
                     hip_ops.WINO = keep
             else:
-                e = torch.cat([uo.unet_res64_forward(sd_gpu, ocfg, x_o[b:b + 1], st.labels[i][b:b + 1]) for b in range(shape[0])])
+                e = torch.cat([uo.unet_res64_forward(sd_gpu, ocfg, x_o[b:b + 1], st.labels[i][sel[b]:sel[b] + 1]) for b in range(len(sel))])
             # per-evaluation error of the HIP U-Net on the PARTNER's state (no trajectory feedback)
             if (i + 1) in marks:
-                e_h = model_fn(x_o, st.labels[i])
+                if a.sel is None:
+                    e_h = model_fn(x_o, st.labels[i])
+                else:                              # the partner's samples inside a full batch of the HIP state
+                    xb = x_h.clone(); xb[sel] = x_o
+                    e_h = model_fn(xb, st.labels[i])[sel]
                 eval_err = rel(e_h, e)
-            x_o, xm_o = uo_step(x_o, e, z, st, i, mask)
+            x_o, xm_o = uo_step(x_o, e, z[sel], st, i, mask)
             torch.cuda.synchronize(); t2 = time.perf_counter()
             t_h += t1 - t0; t_o += t2 - t1
             if (i + 1) in marks:
-                rec = {"step": i + 1, "x_rel_l2": rel(x_h, x_o), "x_mean_rel_l2": rel(xm_h, xm_o),
+                rec = {"step": i + 1, "x_rel_l2": rel(x_h[sel], x_o), "x_mean_rel_l2": rel(xm_h[sel], xm_o),
                        "unet_eval_rel_l2": eval_err}
                 log.append(rec)
                 print(json.dumps(rec), flush=True)
+    from meshdiffusion_amd import hip_ops
     return {"config": a.config, "batch": a.batch, "steps": a.steps, "seed": seed, "partner": a.partner,
+            "hip_precision": hip_ops.precision_name(), "oracle_samples": sel,
             "final_x_mean_rel_l2": log[-1]["x_mean_rel_l2"],
             "target": 1e-3, "hip_s_per_step": t_h / a.steps, "oracle_gpu_s_per_step": t_o / a.steps, "trace": log}
 

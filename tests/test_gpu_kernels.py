@@ -68,6 +68,8 @@ def test_gemm_asymmetric_identity(ops):
 @pytest.mark.parametrize("cin,cout,S,B", [(32, 128, 8, 2), (64, 256, 16, 1), (160, 128, 8, 1)])
 def test_conv3_main(ops, cin, cout, S, B, cfg_name):
     cfg = getattr(ops, cfg_name)
+    if cfg_name == "CFG_FAST_EC" and cfg not in ops._lib.CFG_NT_KC:
+        pytest.skip("timing-only / A/B configuration ids exist in MD_BUILD_ABLATIONS=1 libraries only")
     x = _rand((B, cin, S, S, S), 1)
     w = _rand((cout, cin, 3, 3, 3), 2, 0.05)
     bias = _rand((B, cout), 3)

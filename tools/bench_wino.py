@@ -113,6 +113,11 @@ def main():
         if a.stamps:
             dbg = torch.zeros((1024, 4, 10), dtype=torch.int64, device=dev)
             for _ in range(2):
+                if a.f8:      # a library built with MD_EXTRA_DEFINES=-DW8_STAMPS: md_conv3_wino_f8 runs its stamping instantiation
+                    t8 = ops.wino_prep([(x, cin)], ac, True, False, B, S, f8=True)
+                    ops.conv3_wino(ops.WinoWeightF8(w, dev), t8, B, S, bias=bias, bias_bstride=cout, residual=None if a.no_res else res,
+                                   res_bstride=0 if a.no_res else cout * S ** 3, stats=dbg, out=out)
+                    continue
                 ops.conv3_wino(ww, t, B, S, bias=bias, bias_bstride=cout, residual=None if a.no_res else res,
                                res_bstride=0 if a.no_res else cout * S ** 3, stats=dbg, out=out, variant=128)
             torch.cuda.synchronize()
