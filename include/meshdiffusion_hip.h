@@ -41,7 +41,7 @@ extern "C" {
 #define MD_ERR_UNSUPPORTED (-2)
 #define MD_ERR_NO_DEVICE (-3)
 
-#define MD_ABI_VERSION 11
+#define MD_ABI_VERSION 12
 
 /* ---- tile configurations of md_gemm_conv (compile-time instantiations) ---- */
 enum {
@@ -538,8 +538,8 @@ int md_grad_resample(const float* in, float* out, int32_t batch, int32_t C, int3
                      int32_t mode, int32_t accumulate, void* stream);
 
 /*
- * Marching tetrahedra on a STATIC tet grid (nvdiffrec/lib/geometry/dmtet.py:105-163),
- * one workgroup per mesh, n_meshes meshes per call.
+ * Marching tetrahedra on a STATIC tet grid (nvdiffrec/lib/geometry/dmtet.py:105-163), n_meshes meshes per call:
+ * chunks of 1024 edges / tets per workgroup, four launches on `stream` (chunk totals, per-mesh scan, vertices, faces).
  * Static tables (built once on the host from the tet file, see meshdiffusion_amd/dmtet.py):
  *   tets       int32 [T][4]
  *   edges      int32 [E][2]   lexicographically sorted unique (min,max) vertex pairs of all tets
@@ -550,9 +550,10 @@ int md_grad_resample(const float* in, float* out, int32_t batch, int32_t C, int3
  *             face_tet int64 [M][2T]  (tet id of each face = face_to_valid_tet; may be NULL),
  *             counts int32 [M][4] = {n_verts, n_faces, n_tets_1tri, n_tets_2tri}
  * Face order == reference: all 1-triangle tets (tet order), then 2-triangle tets.
- * Workspace:  md_marching_tets_workspace_bytes(M, E) bytes.
+ * Workspace:  md_marching_tets_workspace_bytes(M, E, T) bytes (edge -> vertex id table + per-chunk counters).
+ * tets must be 16-byte and edges 8-byte aligned (rows are read whole).  n_meshes <= 65535.
  */
-int64_t md_marching_tets_workspace_bytes(int32_t n_meshes, int32_t n_edges);
+int64_t md_marching_tets_workspace_bytes(int32_t n_meshes, int32_t n_edges, int32_t n_tets);
 int md_marching_tets(const float* pos, const float* sdf, const int32_t* tets,
                      const int32_t* edges, const int32_t* tet_edges, int32_t n_meshes,
                      int32_t n_verts, int32_t n_edges, int32_t n_tets, float* verts,

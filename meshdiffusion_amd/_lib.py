@@ -53,7 +53,7 @@ class MdPackJob(C.Structure):
 
 
 PACK_WPK, PACK_WINO = 0, 1
-ABI_VERSION = 11     # MD_ABI_VERSION of include/meshdiffusion_hip.h this host code was written against
+ABI_VERSION = 12     # MD_ABI_VERSION of include/meshdiffusion_hip.h this host code was written against
 _P, _I32, _I64, _F, _U64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint64
 
 # name -> (restype, argtypes); exactly the entry points of include/meshdiffusion_hip.h
@@ -121,7 +121,7 @@ SIGNATURES = {
     "md_s16b_transpose": (C.c_int, [_P, _P, _I32, _I32, _I32, _P]),
     "md_softmax_keys_bwd": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _F, _P]),
     "md_grad_resample": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P]),
-    "md_marching_tets_workspace_bytes": (_I64, [_I32, _I32]),
+    "md_marching_tets_workspace_bytes": (_I64, [_I32, _I32, _I32]),
     "md_vertex_normals": (C.c_int, [_P, _P, _I64, _I64, _P, _P, _P]),
     "md_marching_tets": (C.c_int, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _I64, _P]),
 }

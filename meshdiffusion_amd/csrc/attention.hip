@@ -79,13 +79,22 @@ __global__ __launch_bounds__(AT_THREADS) void md_attn_fwd_kernel(const uint4* __
     for (int i = 0; i < AT_PF; ++i) {
       const int idx = tid + i * AT_THREADS;
       *(uint4*)(base + idx * 16) = pfk[i];
-      // V: the two 8-byte halves (keys 0-3 / 4-7 of the group) go to separate planes so that a half-wave's 32 lanes read
-      // 32 consecutive 8-byte words: [kg*2+plane][half][c]
-      const int gp = idx / AT_C, c = idx % AT_C;
-      unsigned char* vbase = base + AT_K_ITEMS * 16 + ((gp * 2) * AT_C + c) * 8;
-      *(uint2*)(vbase) = make_uint2(pfv[i].x, pfv[i].y);
-      *(uint2*)(vbase + AT_C * 8) = make_uint2(pfv[i].z, pfv[i].w);
     }
+    // V: thread tid holds channel c = tid of all 8 (key group, plane) items of the tile.  The MFMA wants, per key step ks and
+    // lane half h, keys 16ks + 4h + {0..3} (group 2ks, half h) followed by 16ks + 8 + 4h + {0..3} (group 2ks + 1, half h):
+    // those 16 bytes are assembled here and stored as ONE item [ks][plane][h][c], so that a half-wave reads 32 consecutive
+    // 16-byte items with one ds_read_b128 (the 8-byte pieces compiled to ds_read2_b64: half the LDS rate and, per
+    // SQ_LDS_BANK_CONFLICT, a conflict cycle for every cycle of data -- profiles/r03_final_pmc_sq.summary.txt).
+    static_assert(AT_PF == 8 && AT_THREADS == AT_C, "one thread = one channel of all 4 key groups x 2 planes");
+    unsigned char* vbase = base + AT_K_ITEMS * 16 + tid * 16;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        const uint4 g0 = pfv[(2 * ks) * 2 + p], g1 = pfv[(2 * ks + 1) * 2 + p];
+        *(uint4*)(vbase + (((ks * 2 + p) * 2 + 0) * AT_C) * 16) = make_uint4(g0.x, g0.y, g1.x, g1.y);
+        *(uint4*)(vbase + (((ks * 2 + p) * 2 + 1) * AT_C) * 16) = make_uint4(g0.z, g0.w, g1.z, g1.w);
+      }
   };
 
   const int ntiles = N / AT_TK;
@@ -156,13 +165,9 @@ __global__ __launch_bounds__(AT_THREADS) void md_attn_fwd_kernel(const uint4* __
       const int c = rt * 32 + j;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        // V fragment in the P key order: keys 16ks + 4h + {0..3} (group 2ks, half h) then 16ks + 8 + 4h + {0..3} (group 2ks+1)
-        const uint2 a0 = *(const uint2*)(vbuf + ((((2 * ks) * 2 + 0) * 2 + h) * AT_C + c) * 8);
-        const uint2 a1 = *(const uint2*)(vbuf + ((((2 * ks + 1) * 2 + 0) * 2 + h) * AT_C + c) * 8);
-        const uint2 l0 = *(const uint2*)(vbuf + ((((2 * ks) * 2 + 1) * 2 + h) * AT_C + c) * 8);
-        const uint2 l1 = *(const uint2*)(vbuf + ((((2 * ks + 1) * 2 + 1) * 2 + h) * AT_C + c) * 8);
-        const bf16x8 vhi = __builtin_bit_cast(bf16x8, make_uint4(a0.x, a0.y, a1.x, a1.y));
-        const bf16x8 vlo = __builtin_bit_cast(bf16x8, make_uint4(l0.x, l0.y, l1.x, l1.y));
+        // V fragment in the P key order: item [ks][plane][h][c] = keys 16ks + 4h + {0..3}, 16ks + 8 + 4h + {0..3}
+        const bf16x8 vhi = *(const bf16x8*)(vbuf + (((ks * 2 + 0) * 2 + h) * AT_C + c) * 16);
+        const bf16x8 vlo = *(const bf16x8*)(vbuf + (((ks * 2 + 1) * 2 + h) * AT_C + c) * 16);
         oacc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vlo, pbh[ks], oacc[rt], 0, 0, 0);
         oacc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vhi, pbl[ks], oacc[rt], 0, 0, 0);
         oacc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vhi, pbh[ks], oacc[rt], 0, 0, 0);

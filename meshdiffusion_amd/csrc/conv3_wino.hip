@@ -283,18 +283,23 @@ __global__ __launch_bounds__(WN_THREADS) void md_conv3_wino_kernel(const WnArgs 
   };
 
   f32x16 acc[4][4];
+  auto zero_acc = [&]() {
 #pragma unroll
-  for (int rt = 0; rt < 4; ++rt)
+    for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct) {
+      for (int ct = 0; ct < 4; ++ct) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[rt][ct][r] = 0.f;
-      asm volatile("" : "+a"(acc[rt][ct]));          // the 256 accumulator registers are the AccVGPR half of the file
-    }
+        for (int r = 0; r < 16; ++r) acc[rt][ct][r] = 0.f;
+        asm volatile("" : "+a"(acc[rt][ct]));          // the 256 accumulator registers are the AccVGPR half of the file
+      }
+  };
+#ifndef W8_PRO_FENCE
+#define W8_PRO_FENCE 1      // A/B: 0 = the prologue order hipcc chooses by itself (accumulators zeroed and all offsets computed before the first request)
+#endif
+  if constexpr (!F8 || !W8_PRO_FENCE) zero_acc();
   float descale = 1.f;
   if constexpr (F8) {
     static_assert(ABL == 0 || ABL == 128, "timing ablations exist for the bf16x3 loop only");
-    descale = A.hdr[2];
     // ---- F8 main loop -------------------------------------------------------------------------------------------------
     // Pair-step u of a body (2 chunks = 18 steps = 9 pair-steps; chunk c0 in halo buffer 0, c0 + 1 in buffer 1; pair-step 4 is
     // tap 8 of the first and tap 0 of the second chunk) = 4 GROUPS, one per column tile ct (output plane z0 + ct):
@@ -355,11 +360,15 @@ __global__ __launch_bounds__(WN_THREADS) void md_conv3_wino_kernel(const WnArgs 
           A8f[set][rt] = cat8(wp[(rt * 4 + 2) * 64], wp[(rt * 4 + 3) * 64]);
         }
     };
-    // ---- prologue: weights of pair-step 0; chunk 0 -> buffer 0 and pieces 0..7 of chunk 1 into the two slots, every request issued
-    // as soon as its offset is known (the ~45 VALU of an offset run under the requests already in flight); the offset table ----
+    // ---- prologue: weights of pair-step 0; chunk 0 -> buffer 0 and pieces 0..7 of chunk 1 into the two slots; the offset table.
+    // Order FENCED (hipcc otherwise computes all 15 offsets and zeroes the 256 accumulator registers -- ~800 VALU, ~2 us -- before
+    // the first request leaves, and sinks the weight requests behind the halo stores: profiles/r04_mid_*, ISA of f0db013): the 16
+    // weight requests first (their address is scalar + lane), then offset k -> request k, the accumulators are zeroed while the
+    // requests are in flight, and only then the stores wait for the data ----
     {
       uint4 h0[WN_NDMA];
       load_A8(0, 0, 0, 4);
+      if constexpr (W8_PRO_FENCE) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int k = 0; k < WN_NDMA; ++k) {
         const int dk = halo_off(k);
@@ -368,7 +377,11 @@ __global__ __launch_bounds__(WN_THREADS) void md_conv3_wino_kernel(const WnArgs 
         otab[k * 64] = o;
         h0[k] = wn_gload16(tbase + o);
         if (k < 8) hs8[k >> 2][k & 3] = wn_gload16(tbase + (int64_t)16 * Ph + o);
+        if constexpr (W8_PRO_FENCE) __builtin_amdgcn_sched_barrier(0);
       }
+      if constexpr (W8_PRO_FENCE) zero_acc();
+      descale = A.hdr[2];
+      if constexpr (W8_PRO_FENCE) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int k = 0; k < WN_NDMA; ++k) halo_store8(0, k, h0[k]);
     }
@@ -653,13 +666,21 @@ __global__ __launch_bounds__(WN_THREADS) void md_conv3_wino_kernel(const WnArgs 
     write_round(r);
     if (r < 3) prefetch(r + 1);
     __syncthreads();
+#if defined(W8_FLUSH_LATE) && !W8_FLUSH_LATE
     if (want_stats && r > 0) flush_stats(r - 1);
+#endif
     f32x4 m[4][4];
 #pragma unroll
     for (int ff = 0; ff < 4; ++ff)
 #pragma unroll
       for (int pr = 0; pr < 4; ++pr)
         m[ff][pr] = *(const f32x4*)(xr + ((ff * 128 + wid * 32 + yr * 4 + pr) * WN_XSTRIDE + 4 * cq));
+    // the statistics of the round before (wave 0 only: 8 dependent LDS reads + 64 fp64 atomics) go BEHIND this round's reads in the
+    // LDS queue: issued first they delayed wave 0 -- and with it the next barrier -- by their latency every round
+#ifndef W8_FLUSH_LATE
+#define W8_FLUSH_LATE 1     // A/B: 0 = the round-3 order (statistics first)
+#endif
+    if (W8_FLUSH_LATE && want_stats && r > 0) flush_stats(r - 1);
     const int row = rtb * 128 + r * 32 + 4 * cq;
     float* op = outp + ((int64_t)(row >> 3) * P + gp0) * 8 + (row & 7);
     const f32x4 bv = pbias[r & 1];

@@ -1,4 +1,6 @@
-// Marching tetrahedra on a static tet grid, one workgroup (16 wavefronts) per mesh.
+// Marching tetrahedra on a static tet grid: chunks of 1024 edges / tets per workgroup, M meshes per call, four launches
+// (count -> per-mesh scan of the chunk totals -> vertices -> faces) so that 32 meshes of the 64-resolution grid are
+// ~11 000 workgroups instead of 32 (one workgroup per mesh ran on 32 of the 256 CUs at ~95 GB/s, latency-bound).
 //
 // Reference: nvdiffrec/lib/geometry/dmtet.py:105-163 (DMTet.__call__), LUTs :34-54.
 // The reference sorts+uniques the edges of the valid tets at run time (torch.unique(dim=0));
@@ -7,12 +9,13 @@
 // sdf > 0) always belongs to a valid tet, so numbering the crossing edges by an exclusive
 // prefix sum over that static sorted order reproduces the reference's vertex ids exactly;
 // faces are emitted 1-triangle tets first (tet order), then 2-triangle tets, like the
-// reference's torch.cat.  Prefix sums are wave-level ballots + popcounts (wave64).
+// reference's torch.cat.  Prefix sums: wave-level ballots + popcounts (wave64) inside a chunk, the chunk offsets from the
+// scan kernel -- every number is an integer, so the result does not depend on how the work is cut.
 #include "md_common.h"
 
 #pragma clang fp contract(off)
 
-static constexpr int MT_THREADS = 1024;
+static constexpr int MT_THREADS = 1024;          // = items (edges or tets) per chunk
 static constexpr int MT_WAVES = MT_THREADS / 64;
 
 __device__ __constant__ int8_t c_tri_table[16][6] = {
@@ -41,124 +44,189 @@ __device__ __forceinline__ int block_excl_scan_flag(bool flag, int* lds_wave, in
   return base + wprefix;
 }
 
-__global__ __launch_bounds__(MT_THREADS) void md_marching_tets_kernel(
-    const float* __restrict__ pos, const float* __restrict__ sdf, const int32_t* __restrict__ tets,
-    const int32_t* __restrict__ edges, const int32_t* __restrict__ tet_edges, int n_verts, int n_edges,
-    int n_tets, float* __restrict__ verts, int64_t* __restrict__ faces, int64_t* __restrict__ face_tet,
-    int32_t* __restrict__ counts, int32_t* __restrict__ workspace) {
-  __shared__ int lds_wave[MT_WAVES];
+// exclusive prefix of an int over the block
+__device__ __forceinline__ int block_excl_scan_int(int v, int* lds_wave, int& total) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  int inc = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += t;
+  }
+  if (lane == 63) lds_wave[wid] = inc;
+  __syncthreads();
+  int base = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < MT_WAVES; ++w) {
+    const int c = lds_wave[w];
+    if (w < wid) base += c;
+    tot += c;
+  }
+  __syncthreads();
+  total = tot;
+  return base + inc - v;
+}
+
+struct MtArgs {
+  const float* pos; const float* sdf; const int32_t* tets; const int32_t* edges; const int32_t* tet_edges;
+  int n_verts, n_edges, n_tets, ce, ct;           // ce / ct: edge / tet chunks per mesh
+  float* verts; int64_t* faces; int64_t* face_tet; int32_t* counts;
+  int32_t* vid;                                   // [M][E]  edge -> vertex id or -1
+  int32_t* chunk;                                 // [M][ce + 2 ct]: crossing edges per edge chunk | 1-triangle | 2-triangle tets per tet chunk
+};
+
+__device__ __forceinline__ int mt_tet_case(const float* msdf, const int32_t* tets, int t) {
+  const int4 tv = *(const int4*)(tets + 4 * (int64_t)t);
+  return ((msdf[tv.x] > 0.f) ? 1 : 0) | ((msdf[tv.y] > 0.f) ? 2 : 0) | ((msdf[tv.z] > 0.f) ? 4 : 0) | ((msdf[tv.w] > 0.f) ? 8 : 0);
+}
+
+// ---- launch 1: per-chunk totals.  blockIdx.x < ce: an edge chunk, else a tet chunk; blockIdx.y = mesh ----
+__global__ __launch_bounds__(MT_THREADS) void md_mt_count_kernel(const MtArgs g) {
   __shared__ int lds_red[2][MT_WAVES];
-  const int m = blockIdx.x, tid = threadIdx.x;
-  const float* mpos = pos + (int64_t)m * n_verts * 3;
-  const float* msdf = sdf + (int64_t)m * n_verts;
-  float* mverts = verts + (int64_t)m * n_edges * 3;
-  int64_t* mfaces = faces + (int64_t)m * n_tets * 2 * 3;
-  int64_t* mftet = face_tet ? face_tet + (int64_t)m * n_tets * 2 : nullptr;
-  int32_t* vid = workspace + (int64_t)m * n_edges;  // edge -> vertex id or -1
-
-  // ---- phase 1: crossing edges -> vertex ids + interpolated positions ----
-  int vbase = 0;
-  for (int e0 = 0; e0 < n_edges; e0 += MT_THREADS) {
-    const int e = e0 + tid;
-    bool cross = false;
-    int a = 0, b = 0;
-    float sa = 0.f, sb = 0.f;
-    if (e < n_edges) {
-      a = edges[2 * e]; b = edges[2 * e + 1];
-      sa = msdf[a]; sb = msdf[b];
-      cross = (sa > 0.f) != (sb > 0.f);
+  const int m = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const float* msdf = g.sdf + (int64_t)m * g.n_verts;
+  int32_t* mchunk = g.chunk + (int64_t)m * (g.ce + 2 * g.ct);
+  bool f1 = false, f2 = false;
+  const bool is_edge = (int)blockIdx.x < g.ce;
+  if (is_edge) {
+    const int e = blockIdx.x * MT_THREADS + tid;
+    if (e < g.n_edges) {
+      const int2 ab = *(const int2*)(g.edges + 2 * (int64_t)e);
+      f1 = (msdf[ab.x] > 0.f) != (msdf[ab.y] > 0.f);
     }
-    int tot;
-    const int pre = block_excl_scan_flag(cross, lds_wave, tot);
-    if (e < n_edges) {
-      if (cross) {
-        const int v = vbase + pre;
-        vid[e] = v;
-        // reference: sdf pair (s0, -s1); w = flip(pair)/sum(pair); vert = p0*w0 + p1*w1
-        const float nsb = -sb;
-        const float den = sa + nsb;
-        const float w0 = nsb / den, w1 = sa / den;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          const float t0 = mpos[a * 3 + k] * w0;
-          const float t1 = mpos[b * 3 + k] * w1;
-          mverts[(int64_t)v * 3 + k] = t0 + t1;
-        }
-      } else {
-        vid[e] = -1;
-      }
+  } else {
+    const int t = (blockIdx.x - g.ce) * MT_THREADS + tid;
+    if (t < g.n_tets) {
+      const int nt = c_num_tri[mt_tet_case(msdf, g.tets, t)];
+      f1 = nt == 1; f2 = nt == 2;
     }
-    vbase += tot;
   }
-  __threadfence_block();
+  const int w1 = __popcll(__ballot(f1)), w2 = __popcll(__ballot(f2));
+  if (lane == 0) { lds_red[0][wid] = w1; lds_red[1][wid] = w2; }
   __syncthreads();
-
-  // ---- phase 2a: count 1- and 2-triangle tets ----
-  int c1 = 0, c2 = 0;
-  for (int t = tid; t < n_tets; t += MT_THREADS) {
-    int idx = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) idx |= (msdf[tets[4 * t + k]] > 0.f) ? (1 << k) : 0;
-    const int nt = c_num_tri[idx];
-    c1 += (nt == 1);
-    c2 += (nt == 2);
-  }
-  {
-    int s1 = c1, s2 = c2;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
-    if ((tid & 63) == 0) { lds_red[0][tid >> 6] = s1; lds_red[1][tid >> 6] = s2; }
-  }
-  __syncthreads();
-  int N1 = 0, N2 = 0;
-#pragma unroll
-  for (int w = 0; w < MT_WAVES; ++w) { N1 += lds_red[0][w]; N2 += lds_red[1][w]; }
-  __syncthreads();
-
-  // ---- phase 2b: emit faces (1-tri tets first, then 2-tri tets, both in tet order) ----
-  int b1 = 0, b2 = 0;
-  for (int t0 = 0; t0 < n_tets; t0 += MT_THREADS) {
-    const int t = t0 + tid;
-    int idx = 0, nt = 0;
-    if (t < n_tets) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) idx |= (msdf[tets[4 * t + k]] > 0.f) ? (1 << k) : 0;
-      nt = c_num_tri[idx];
-    }
-    int tot1, tot2;
-    const int p1 = block_excl_scan_flag(nt == 1, lds_wave, tot1);
-    const int p2 = block_excl_scan_flag(nt == 2, lds_wave, tot2);
-    if (nt > 0) {
-      int ev[6];
-#pragma unroll
-      for (int k = 0; k < 6; ++k) ev[k] = vid[tet_edges[6 * t + k]];
-      const int64_t f0 = (nt == 1) ? (int64_t)(b1 + p1) : (int64_t)N1 + 2 * (int64_t)(b2 + p2);
-      for (int f = 0; f < nt; ++f) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          const int ei = c_tri_table[idx][f * 3 + k];
-          int v = 0;
-#pragma unroll
-          for (int q = 0; q < 6; ++q) v = (ei == q) ? ev[q] : v;
-          mfaces[(f0 + f) * 3 + k] = (int64_t)v;
-        }
-        if (mftet) mftet[f0 + f] = (int64_t)t;
-      }
-    }
-    b1 += tot1;
-    b2 += tot2;
-  }
   if (tid == 0) {
-    counts[m * 4 + 0] = vbase;
-    counts[m * 4 + 1] = N1 + 2 * N2;
-    counts[m * 4 + 2] = N1;
-    counts[m * 4 + 3] = N2;
+    int s1 = 0, s2 = 0;
+#pragma unroll
+    for (int w = 0; w < MT_WAVES; ++w) { s1 += lds_red[0][w]; s2 += lds_red[1][w]; }
+    if (is_edge) mchunk[blockIdx.x] = s1;
+    else { mchunk[blockIdx.x] = s1; mchunk[blockIdx.x + g.ct] = s2; }
   }
 }
 
-extern "C" int64_t md_marching_tets_workspace_bytes(int32_t n_meshes, int32_t n_edges) {
-  if (n_meshes <= 0 || n_edges <= 0) return MD_ERR_BAD_ARG;
-  return (int64_t)n_meshes * n_edges * 4;
+// ---- launch 2: one workgroup per mesh turns the chunk totals into exclusive offsets (in place) and writes counts ----
+__global__ __launch_bounds__(MT_THREADS) void md_mt_scan_kernel(const MtArgs g) {
+  __shared__ int lds_wave[MT_WAVES];
+  const int m = blockIdx.x, tid = threadIdx.x;
+  int32_t* mchunk = g.chunk + (int64_t)m * (g.ce + 2 * g.ct);
+  int tot3[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    int32_t* arr = mchunk + (a == 0 ? 0 : (a == 1 ? g.ce : g.ce + g.ct));
+    const int n = a == 0 ? g.ce : g.ct;
+    int base = 0;
+    for (int i0 = 0; i0 < n; i0 += MT_THREADS) {
+      const int i = i0 + tid;
+      const int v = i < n ? arr[i] : 0;
+      int tot;
+      const int pre = block_excl_scan_int(v, lds_wave, tot);
+      if (i < n) arr[i] = base + pre;
+      base += tot;
+    }
+    tot3[a] = base;
+  }
+  if (tid == 0) {
+    g.counts[m * 4 + 0] = tot3[0];
+    g.counts[m * 4 + 1] = tot3[1] + 2 * tot3[2];
+    g.counts[m * 4 + 2] = tot3[1];
+    g.counts[m * 4 + 3] = tot3[2];
+  }
+}
+
+// ---- launch 3: crossing edges -> vertex ids + interpolated positions ----
+__global__ __launch_bounds__(MT_THREADS) void md_mt_verts_kernel(const MtArgs g) {
+  __shared__ int lds_wave[MT_WAVES];
+  const int m = blockIdx.y, tid = threadIdx.x;
+  const float* mpos = g.pos + (int64_t)m * g.n_verts * 3;
+  const float* msdf = g.sdf + (int64_t)m * g.n_verts;
+  float* mverts = g.verts + (int64_t)m * g.n_edges * 3;
+  int32_t* vid = g.vid + (int64_t)m * g.n_edges;
+  const int vbase = g.chunk[(int64_t)m * (g.ce + 2 * g.ct) + blockIdx.x];
+  const int e = blockIdx.x * MT_THREADS + tid;
+  bool cross = false;
+  int a = 0, b = 0;
+  float sa = 0.f, sb = 0.f;
+  if (e < g.n_edges) {
+    const int2 ab = *(const int2*)(g.edges + 2 * (int64_t)e);
+    a = ab.x; b = ab.y;
+    sa = msdf[a]; sb = msdf[b];
+    cross = (sa > 0.f) != (sb > 0.f);
+  }
+  int tot;
+  const int pre = block_excl_scan_flag(cross, lds_wave, tot);
+  if (e < g.n_edges) {
+    if (cross) {
+      const int v = vbase + pre;
+      vid[e] = v;
+      // reference: sdf pair (s0, -s1); w = flip(pair)/sum(pair); vert = p0*w0 + p1*w1
+      const float nsb = -sb;
+      const float den = sa + nsb;
+      const float w0 = nsb / den, w1 = sa / den;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const float t0 = mpos[a * 3 + k] * w0;
+        const float t1 = mpos[b * 3 + k] * w1;
+        mverts[(int64_t)v * 3 + k] = t0 + t1;
+      }
+    } else {
+      vid[e] = -1;
+    }
+  }
+}
+
+// ---- launch 4: faces (1-triangle tets first, then 2-triangle tets, both in tet order) ----
+__global__ __launch_bounds__(MT_THREADS) void md_mt_faces_kernel(const MtArgs g) {
+  __shared__ int lds_wave[MT_WAVES];
+  const int m = blockIdx.y, tid = threadIdx.x;
+  const float* msdf = g.sdf + (int64_t)m * g.n_verts;
+  int64_t* mfaces = g.faces + (int64_t)m * g.n_tets * 2 * 3;
+  int64_t* mftet = g.face_tet ? g.face_tet + (int64_t)m * g.n_tets * 2 : nullptr;
+  const int32_t* vid = g.vid + (int64_t)m * g.n_edges;
+  const int32_t* mchunk = g.chunk + (int64_t)m * (g.ce + 2 * g.ct);
+  const int b1 = mchunk[g.ce + blockIdx.x], b2 = mchunk[g.ce + g.ct + blockIdx.x];
+  const int N1 = g.counts[m * 4 + 2];
+  const int t = blockIdx.x * MT_THREADS + tid;
+  int idx = 0, nt = 0;
+  if (t < g.n_tets) {
+    idx = mt_tet_case(msdf, g.tets, t);
+    nt = c_num_tri[idx];
+  }
+  int tot1, tot2;
+  const int p1 = block_excl_scan_flag(nt == 1, lds_wave, tot1);
+  const int p2 = block_excl_scan_flag(nt == 2, lds_wave, tot2);
+  if (nt > 0) {
+    int ev[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) ev[k] = vid[g.tet_edges[6 * (int64_t)t + k]];
+    const int64_t f0 = (nt == 1) ? (int64_t)(b1 + p1) : (int64_t)N1 + 2 * (int64_t)(b2 + p2);
+    for (int f = 0; f < nt; ++f) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int ei = c_tri_table[idx][f * 3 + k];
+        int v = 0;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) v = (ei == q) ? ev[q] : v;
+        mfaces[(f0 + f) * 3 + k] = (int64_t)v;
+      }
+      if (mftet) mftet[f0 + f] = (int64_t)t;
+    }
+  }
+}
+
+static inline int mt_chunks(int32_t n) { return (n + MT_THREADS - 1) / MT_THREADS; }
+
+extern "C" int64_t md_marching_tets_workspace_bytes(int32_t n_meshes, int32_t n_edges, int32_t n_tets) {
+  if (n_meshes <= 0 || n_edges <= 0 || n_tets <= 0) return MD_ERR_BAD_ARG;
+  return (int64_t)n_meshes * ((int64_t)n_edges + mt_chunks(n_edges) + 2 * mt_chunks(n_tets)) * 4;
 }
 
 extern "C" int md_marching_tets(const float* pos, const float* sdf, const int32_t* tets,
@@ -169,11 +237,21 @@ extern "C" int md_marching_tets(const float* pos, const float* sdf, const int32_
   if (!pos || !sdf || !tets || !edges || !tet_edges || !verts || !faces || !counts || !workspace ||
       n_meshes <= 0 || n_verts <= 0 || n_edges <= 0 || n_tets <= 0)
     return MD_ERR_BAD_ARG;
-  if (workspace_bytes < md_marching_tets_workspace_bytes(n_meshes, n_edges)) return MD_ERR_BAD_ARG;
+  if (workspace_bytes < md_marching_tets_workspace_bytes(n_meshes, n_edges, n_tets)) return MD_ERR_BAD_ARG;
+  if (n_meshes > 65535) return MD_ERR_UNSUPPORTED;             // gridDim.y
+  if (((uintptr_t)tets & 15) || ((uintptr_t)edges & 7)) return MD_ERR_BAD_ARG;   // read as int4 / int2 rows
+  MtArgs g;
+  g.pos = pos; g.sdf = sdf; g.tets = tets; g.edges = edges; g.tet_edges = tet_edges;
+  g.n_verts = n_verts; g.n_edges = n_edges; g.n_tets = n_tets; g.ce = mt_chunks(n_edges); g.ct = mt_chunks(n_tets);
+  g.verts = verts; g.faces = faces; g.face_tet = face_tet; g.counts = counts;
+  g.vid = (int32_t*)workspace;
+  g.chunk = g.vid + (int64_t)n_meshes * n_edges;
+  const hipStream_t st = (hipStream_t)stream;
   MD_HIP_CLEAR_ERROR();
-  hipLaunchKernelGGL(md_marching_tets_kernel, dim3((unsigned)n_meshes), dim3(MT_THREADS), 0,
-                     (hipStream_t)stream, pos, sdf, tets, edges, tet_edges, n_verts, n_edges, n_tets,
-                     verts, faces, face_tet, counts, (int32_t*)workspace);
+  hipLaunchKernelGGL(md_mt_count_kernel, dim3((unsigned)(g.ce + g.ct), (unsigned)n_meshes), dim3(MT_THREADS), 0, st, g);
+  hipLaunchKernelGGL(md_mt_scan_kernel, dim3((unsigned)n_meshes), dim3(MT_THREADS), 0, st, g);
+  hipLaunchKernelGGL(md_mt_verts_kernel, dim3((unsigned)g.ce, (unsigned)n_meshes), dim3(MT_THREADS), 0, st, g);
+  hipLaunchKernelGGL(md_mt_faces_kernel, dim3((unsigned)g.ct, (unsigned)n_meshes), dim3(MT_THREADS), 0, st, g);
   MD_HIP_CHECK_LAUNCH();
   return MD_OK;
 }

@@ -6,7 +6,7 @@ nvdiffrec/eval.py:389-419 / `get_deformed` dmtet.py:293-304 and the grid-mask co
 data/get_tet_mask.py:9-37.
 
 Static preprocessing (once per tet grid, torch ops): the lexicographically sorted unique edge list
-of ALL tets and the [T,6] tet->edge-id table.  Per call: ONE kernel launch for M meshes.
+of ALL tets and the [T,6] tet->edge-id table.  Per call: four launches (chunked over edges / tets) for M meshes.
 """
 import ctypes as C
 
@@ -49,7 +49,7 @@ def marching_tets_batch(pos, sdf, tables):
     faces = torch.empty((M, 2 * T, 3), dtype=torch.int64, device=dev)
     face_tet = torch.empty((M, 2 * T), dtype=torch.int64, device=dev)
     counts = torch.empty((M, 4), dtype=torch.int32, device=dev)
-    ws_bytes = lib.md_marching_tets_workspace_bytes(M, E)
+    ws_bytes = lib.md_marching_tets_workspace_bytes(M, E, T)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     _lib.check(lib.md_marching_tets(_ptr(pos), _ptr(sdf), _ptr(tables.tets), _ptr(tables.edges),
                                     _ptr(tables.tet_edges), M, N, E, T, _ptr(verts), _ptr(faces),

@@ -102,3 +102,39 @@ def test_tiled_weight_packer_covers_every_item_once():
             hit[base] += 1
             hit[base + nt] += 1
     assert hit.min() == 1 and hit.max() == 1
+
+
+def test_attention_v_image_matches_the_p_key_order():
+    """csrc/attention.hip: thread c stores, for key step ks, plane p and lane half h, the 16-byte item [ks][p][h][c] =
+    {group 2ks half h, group 2ks + 1 half h} of the tile's V items [kg][p][c] (8 keys each: half 0 = keys 0..3, half 1 =
+    keys 4..7); lane (j, h) of row tile rt reads item [ks][p][h][32 rt + j] and must find the keys of MFMA k-slots
+    (h, i) = 16 ks + 8 (i / 4) + 4 h + i % 4 (the order the S^T accumulator rows hand P over in).  One ds_read_b128 lane
+    group = 16 consecutive 16-byte items."""
+    C = 256
+
+    def item(ks, p, h, c):
+        return ((ks * 2 + p) * 2 + h) * C + c
+
+    written = {}
+    for c in range(C):
+        for ks in range(2):
+            for p in range(2):
+                for h in range(2):
+                    keys = [8 * (2 * ks) + 4 * h + e for e in range(4)] + [8 * (2 * ks + 1) + 4 * h + e for e in range(4)]
+                    assert item(ks, p, h, c) not in written
+                    written[item(ks, p, h, c)] = (p, c, keys)
+    assert sorted(written) == list(range(2 * 2 * 2 * C))            # the 32 KB image is covered exactly once
+    lanes = np.arange(64)
+    j, h = lanes & 31, lanes >> 5
+    for rt in range(C // 32):
+        for ks in range(2):
+            for p in range(2):
+                slots = [item(ks, p, int(hh), rt * 32 + int(jj)) for jj, hh in zip(j, h)]
+                for ln, s in enumerate(slots):
+                    pp, cc, keys = written[s]
+                    assert pp == p and cc == rt * 32 + (ln & 31)
+                    assert keys == [16 * ks + 8 * (i // 4) + 4 * (ln >> 5) + i % 4 for i in range(8)]
+                for grp in ([0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27],
+                            [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31]):
+                    for half in (0, 32):
+                        assert _bank_groups_distinct([slots[half + g] for g in grp])

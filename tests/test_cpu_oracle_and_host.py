@@ -131,7 +131,9 @@ def test_bad_arguments_are_rejected_without_a_gpu(hip_lib):
     a = MdGemmConvArgs()
     assert hip_lib.md_gemm_conv(ctypes.byref(a), None) == -1
     assert hip_lib.md_packed_weight_bytes(128, 128, 27, 128, 32) == 128 * 128 * 27 * 4
-    assert hip_lib.md_marching_tets_workspace_bytes(0, 5) < 0
+    assert hip_lib.md_marching_tets_workspace_bytes(0, 5, 5) < 0
+    # edge -> vertex table + one counter per 1024-edge chunk + two per 1024-tet chunk, per mesh
+    assert hip_lib.md_marching_tets_workspace_bytes(32, 195331, 159330) == 32 * (195331 + 191 + 2 * 156) * 4
     # Winograd path: operand T = 8 bytes per input element, weight tiles = 36/27 of the fp32 weight; shapes it does not take
     assert hip_lib.md_wino_operand_bytes(8, 128, 64, 64, 64) == 8 * 128 * 64 ** 3 * 8
     assert hip_lib.md_wino_weight_bytes(128, 256) == 128 * 256 * 36 * 4

@@ -47,6 +47,48 @@ def conv_f16f8(t, g, sw=None):
     return F.conv3d(th, gh) + cross * 2.0 ** -(11 + sw)
 
 
+# ---- "f16f6" study (not built): the cross terms in an MX block-scaled 6-bit format, which v_mfma_scale_f32_32x32x64_f8f6f4 runs at
+# twice the e4m3 rate (32 cycles per K = 64).  A lane's K block is 32 values = [16 channels x (a, a_lo 2^11)] of one position (weights:
+# one output row x 16 input channels x (g_lo, g)); the block shares ONE power-of-two scale (E8M0).
+def q6(x, fmt):
+    """Round to e2m3 (max 7.5) or e3m2 (max 28), nearest even, saturating; x is already divided by the block scale."""
+    mbits, emin, vmax = (3, 0, 7.5) if fmt == "e2m3" else (2, -2, 28.0)
+    ax = x.abs().clamp_min(1e-30)
+    e = torch.floor(torch.log2(ax)).clamp_min(emin)
+    step = torch.exp2(e - mbits)
+    return (torch.round(x / step) * step).clamp(-vmax, vmax)
+
+
+def block_scale(amax, fmt):
+    emax = 2 if fmt == "e2m3" else 4
+    return torch.exp2(torch.floor(torch.log2(amax.clamp_min(1e-30))) - emax)
+
+
+def q6_act(t, tl11, fmt):
+    """t, tl11: [B][C][...]: blocks of 16 channels per position, scale shared by the value and its scaled remainder."""
+    B, C = t.shape[:2]
+    sh = (B, C // 16, 16) + tuple(t.shape[2:])
+    a, b = t.reshape(sh), tl11.reshape(sh)
+    s = block_scale(torch.maximum(a.abs().amax(2, keepdim=True), b.abs().amax(2, keepdim=True)), fmt)
+    return (q6(a / s, fmt) * s).reshape(t.shape), (q6(b / s, fmt) * s).reshape(t.shape)
+
+
+def q6_wt(g, gl11, fmt):
+    """g, gl11: [Co][Ci][3][3][1]: blocks of 16 input channels per (row, tap)."""
+    Co, Ci = g.shape[:2]
+    sh = (Co, Ci // 16, 16) + tuple(g.shape[2:])
+    a, b = g.reshape(sh), gl11.reshape(sh)
+    s = block_scale(torch.maximum(a.abs().amax(2, keepdim=True), b.abs().amax(2, keepdim=True)), fmt)
+    return (q6(a / s, fmt) * s).reshape(g.shape), (q6(b / s, fmt) * s).reshape(g.shape)
+
+
+def conv_f16f6(t, g, fmt="e2m3"):
+    th, gh = t.half().float(), g.half().float()
+    tq, tlq = q6_act(t, (t - th) * 2.0 ** 11, fmt)
+    gq, glq = q6_wt(g, (g - gh) * 2.0 ** 11, fmt)
+    return F.conv3d(th, gh) + (F.conv3d(tq, glq) + F.conv3d(tlq, gq)) * 2.0 ** -11
+
+
 def wino_conv(x, w, conv):
     """3x3x3 pad-1 conv as F(2,3) along w with `conv` for the four (3,3,1) frequency contractions."""
     B, Ci, D, H, W = x.shape
@@ -73,6 +115,8 @@ def one_conv():
     print("  Winograd fp32        %.3e" % rel(wino_conv(x, w, F.conv3d), ref))
     print("  Winograd bf16x3      %.3e" % rel(wino_conv(x, w, conv_bf16x3), ref))
     print("  Winograd f16f8       %.3e" % rel(wino_conv(x, w, conv_f16f8), ref))
+    print("  Winograd f16 + MX e2m3 cross terms (study)  %.3e" % rel(wino_conv(x, w, lambda t, g: conv_f16f6(t, g, "e2m3")), ref))
+    print("  Winograd f16 + MX e3m2 cross terms (study)  %.3e" % rel(wino_conv(x, w, lambda t, g: conv_f16f6(t, g, "e3m2")), ref))
     for sw in (0, 3, 12):
         print("  Winograd f16f8, weight pre-scale 2^%-2d (auto: 2^%d)  %.3e" % (sw, weight_exp(w), rel(wino_conv(x, w, lambda t, g: conv_f16f8(t, g, sw)), ref)))
 
@@ -114,7 +158,9 @@ def unet(seeds):
             F.conv3d = patched
             try:
                 out = {}
-                for name, m in (("fp32", None), ("bf16x3 (Winograd convs)", conv_bf16x3), ("f16f8  (Winograd convs)", conv_f16f8)):
+                for name, m in (("fp32", None), ("bf16x3 (Winograd convs)", conv_bf16x3), ("f16f8  (Winograd convs)", conv_f16f8),
+                                ("f16 + MX e2m3 (study)", lambda t, g: conv_f16f6(t, g, "e2m3")),
+                                ("f16 + MX e3m2 (study)", lambda t, g: conv_f16f6(t, g, "e3m2"))):
                     mode["m"] = m
                     out[name] = rel(uo.unet_res64_forward(sd, ocfg, x, lab), ref)
             finally:
