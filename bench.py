@@ -54,9 +54,9 @@ def parse():
     ap.add_argument("--batch", type=int, default=8, help="samples per GPU (configs[1]: 8)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
-    ap.add_argument("--precision", default="f16f8", choices=["bf16x3", "fp16x2", "f16f8"],
-                    help="arithmetic of the hot conv kernel for the headline number (DESIGN.md section 3): f16f8 = the package default "
-                         "(config.model.hip_precision), bf16x3 = the round-1..3 arithmetic")
+    ap.add_argument("--precision", default="f16f6", choices=["bf16x3", "fp16x2", "f16f8", "f16f6"],
+                    help="arithmetic of the hot conv kernel for the headline number (DESIGN.md section 3): f16f6 = the package default "
+                         "(config.model.hip_precision), f16f8 = its e4m3 form, bf16x3 = the round-1..3 arithmetic")
     ap.add_argument("--no-fast-mode", action="store_true", help="skip the second measurement in the other arithmetic (bf16x3_mode)")
     ap.add_argument("--no-train-step", action="store_true", help="skip the configs[2] training-step measurement")
     ap.add_argument("--train-steps", type=int, default=3)
@@ -189,7 +189,7 @@ def main():
             events, hip_ops.PROFILE = hip_ops.PROFILE, None
             # the same convolutions through the DIRECT 27-tap kernel (fused operand loader, no Winograd transform), 2 steps:
             # the r02 mid-round build, measured in the same process on the same box
-            if hip_ops.WINO and a.precision in ("bf16x3", "f16f8"):
+            if hip_ops.WINO and a.precision in ("bf16x3", "f16f8", "f16f6"):
                 hip_ops.WINO = False
                 x2, _ = run.step(model_fn, x, it)                     # packs the direct kernel's weight tiles (untimed)
                 hip_ops.PROFILE = []
@@ -201,7 +201,7 @@ def main():
 
     # ---- second measurement on the same workload, same process: the round-1..3 arithmetic (bf16x3 in the Winograd convs too) ----
     fast = None
-    if a.precision == "f16f8" and not a.no_fast_mode and world == 1:
+    if a.precision in ("f16f8", "f16f6") and not a.no_fast_mode and world == 1:
         model.module.hip_precision = "bf16x3"
         with torch.no_grad():
             xf = stepper.prior()
@@ -219,7 +219,7 @@ def main():
                              "arithmetic of rounds 1-3, measured here in the same process on the same box",
                 "value": round(B * a.steps / wf, 3), "unit": "sample-steps/s", "ms_per_step": round(wf / a.steps * 1e3, 3),
                 "parity": "per U-Net evaluation 1.2-2.2e-5, 999-step sampled grids 8.4-8.6e-6 rel-L2 vs the fp32 oracle (profiles/r02_*, r03_longrun_*); "
-                          "f16f8 (the headline): 4e-5 per evaluation (tools/f16f8_numerics.py), long-run record in profiles/r04_longrun_*"}
+                          "f16f8 / f16f6: 4e-5 / 5e-5 per evaluation (tools/f16f8_numerics.py), long-run records in profiles/r04_longrun_*"}
         del xf, xmf
     # ---- BASELINE configs[0] on the GPU: res64, batch 1 (single-sample latency), same weights ----
     b1 = None
@@ -311,7 +311,9 @@ def main():
             "dtype": {"bf16x3": "bf16x3 (split-bf16 MFMA operands, fp32 accumulate/IO)",
                                             "fp16x2": "fp16x2 (weights split fp16, activations fp16, fp32 accumulate/IO)",
                                             "f16f8": "f16f8 in the Winograd convs (fp16 hi*hi MFMA + e4m3 cross terms in a K-concatenated scaled fp8 "
-                                                     "MFMA: 2 matrix-core units per product), bf16x3 elsewhere; fp32 accumulate/IO"}[a.precision],
+                                                     "MFMA: 2 matrix-core units per product), bf16x3 elsewhere; fp32 accumulate/IO",
+                                            "f16f6": "f16f6 in the Winograd convs (fp16 hi*hi MFMA + MX block-scaled e2m3 cross terms in a K-concatenated "
+                                                     "scaled MFMA at twice the e4m3 rate), bf16x3 elsewhere; fp32 accumulate/IO"}[a.precision],
             "data": "synthetic (seeded prior noise, sensitised random-init res64 weights, synthetic grid mask)",
             "config": {"workload": "BASELINE configs[1]: res64 4-ch grid DDPM ancestral sampling steps, batch=8 per GPU",
                        "batch_per_gpu": B, "grid": [cfg.data.num_channels, R, R, R],
@@ -370,9 +372,14 @@ def roofline(events, hip_ops, a, B, wall_prof):
             traffic_src = f"profiles/conv_traffic.json has no entry for kernel build {key} (batch {B}, {a.precision}): re-profile"
     except OSError:
         traffic_src = "profiles/conv_traffic.json missing"
-    fused = bool(hip_ops.FUSE_GN_APPLY and a.precision in ("bf16x3", "f16f8"))
+    fused = bool(hip_ops.FUSE_GN_APPLY and a.precision in ("bf16x3", "f16f8", "f16f6"))
     f8 = wino and a.precision == "f16f8"
-    if f8:
+    f6 = wino and a.precision == "f16f6"
+    if f6:
+        kname = ("md_conv3_wino_kernel<0, true, true> (md_conv3_wino_f6: 3x3x3 conv as Winograd F(2,3) along w, 9 taps x 4 frequencies, one "
+                 "frequency per wave; f16f6 arithmetic: per two steps and accumulator tile two v_mfma_f32_32x32x16_f16 + one K-concatenated "
+                 "v_mfma_scale_f32_32x32x64_f8f6f4 on MX block-scaled e2m3 cross terms; operand prepared by md_wino_prep_f6)")
+    elif f8:
         kname = ("md_conv3_wino_kernel<0, true> (md_conv3_wino_f8: 3x3x3 conv as Winograd F(2,3) along w, 9 taps x 4 frequencies, one frequency "
                  "per wave; f16f8 arithmetic: per two steps and accumulator tile two v_mfma_f32_32x32x16_f16 + one K-concatenated "
                  "v_mfma_scale_f32_32x32x64_f8f6f4 (e4m3 cross terms); operand prepared by md_wino_prep_f8)")
@@ -402,13 +409,15 @@ def roofline(events, hip_ops, a, B, wall_prof):
                               "conv_plus_prep_tflops": round(tot_f / (tot_t + prep_t) / 1e12, 2),
                               "conv_plus_prep_frac": round(tot_f / (tot_t + prep_t) / 1e12 / PEAK_BF16_TFLOPS, 4)} if wino and prep_t > 0 else None),
             "per_shape": per_shape,
-            "issued_matrix_core_frac": round(ach * (4.0 / 3.0 if f8 else 2.0) / PEAK_BF16_TFLOPS, 4) if wino else None,
+            "issued_matrix_core_frac": round(ach * (1.0 if f6 else (4.0 / 3.0 if f8 else 2.0)) / PEAK_BF16_TFLOPS, 4) if wino else None,
             "note": "achieved = algorithmic 2*27*Cin*Cout*P flops of the convolution (1x: not the matrix-core units issued per product, "
                     "and not reduced by the Winograd factor 2/3) / HIP-event time of every launch of this kernel in an untimed "
                     "pass right after the timed region (the timed region itself carries no events); the kernel ISSUES "
                     + ("achieved * 2 * 2/3 = 4/3 * achieved of 32-cycle matrix-core units (one fp16 MFMA + half an fp8 K = 64 MFMA per "
                        "product; issued_matrix_core_frac prices them at the bf16 peak)" if f8 else
-                       "achieved * 3 * 2/3 = 2 * achieved of bf16 MFMA work")}
+                       ("achieved * 1.5 * 2/3 = achieved of 32-cycle matrix-core units at the instructions' nominal rates (one fp16 MFMA + half an "
+                        "e2m3 K = 64 MFMA of 32 cycles per product; measured in the fp16 mix the e2m3 form costs 1.4 units: "
+                        "tools/probes/f6_probe.hip)" if f6 else "achieved * 3 * 2/3 = 2 * achieved of bf16 MFMA work"))}
 
 
 def train_step_bench(a, cfg, model, rank, world, dev, dist, barrier):

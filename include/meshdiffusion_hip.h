@@ -41,7 +41,7 @@ extern "C" {
 #define MD_ERR_UNSUPPORTED (-2)
 #define MD_ERR_NO_DEVICE (-3)
 
-#define MD_ABI_VERSION 12
+#define MD_ABI_VERSION 13
 
 /* ---- tile configurations of md_gemm_conv (compile-time instantiations) ---- */
 enum {
@@ -295,6 +295,21 @@ int md_wino_prep_f8(const float* x1, const float* x2, int32_t c1, int32_t c2, co
 int64_t md_wino_weight_bytes_f8(int32_t cout, int32_t cin);
 int md_wino_pack_weights_f8(const float* w, void* wpk, int32_t cout, int32_t cin, int64_t s_row, int64_t s_k, void* stream);
 int md_conv3_wino_f8(const void* t_in, const void* wpk, float* out, const float* bias, int64_t bias_bstride,
+                     const float* residual, int64_t res_bstride, double* stats, int32_t batch, int32_t cin, int32_t cout,
+                     int32_t D, int32_t H, int32_t W, void* stream);
+
+/*
+ * The same convolution in the "f16f6" arithmetic: as f16f8, the two cross terms from MX block-scaled OCP e2m3 images (a K block = 16
+ * channels x (value, (value - fp16(value)) 2^11) with one power-of-two scale), which the same K = 64 MFMA executes at twice its e4m3
+ * rate (format code 2; measured 0.85 of the f16f8 pair-step in the fp16 mix, tools/probes/f6_probe.hip).  Error of one conv vs fp64
+ * 1.7e-5 (tools/f16f8_numerics.py).  Buffers, sizes and arguments as the _f8 calls; plane 1 of T / pieces 2-3 of the weight
+ * fragments hold the 32-byte record [6 dwords of codes | E8M0 byte | 0] of a block, split over its two 8-channel items.
+ * md_wino_prep_f6 needs c1 and c2 to be multiples of 16 (whole K blocks per part).
+ */
+int md_wino_prep_f6(const float* x1, const float* x2, int32_t c1, int32_t c2, const float* ac, int32_t silu, int32_t ups,
+                    void* t_out, int32_t batch, int32_t D, int32_t H, int32_t W, void* stream);
+int md_wino_pack_weights_f6(const float* w, void* wpk, int32_t cout, int32_t cin, int64_t s_row, int64_t s_k, void* stream);
+int md_conv3_wino_f6(const void* t_in, const void* wpk, float* out, const float* bias, int64_t bias_bstride,
                      const float* residual, int64_t res_bstride, double* stats, int32_t batch, int32_t cin, int32_t cout,
                      int32_t D, int32_t H, int32_t W, void* stream);
 

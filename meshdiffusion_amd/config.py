@@ -104,7 +104,7 @@ def get_config_res64():
     c.model.update(name="ddpm_res64", scale_by_sigma=False, num_scales=1000, ema_rate=0.9999,
                    normalization="GroupNorm", nonlinearity="swish", nf=128, ch_mult=(1, 1, 2, 4, 4),
                    num_res_blocks_first=2, num_res_blocks=3, attn_resolutions=(16,), resamp_with_conv=True,
-                   conditional=True, dropout=0.1, hip_precision="f16f8")
+                   conditional=True, dropout=0.1, hip_precision="f16f6")
     c.optim.lr = 2e-5
     c.eval.batch_size = 4
     c.eval.eval_dir = "PLACEHOLDER"

@@ -170,6 +170,20 @@ __global__ __launch_bounds__(256) void md_wino_pack_weights_f8_kernel(const floa
   wpk[id] = md_pack_wino_f8_item(w, cout, cin, s_row, s_k, wscale, id);
 }
 
+__global__ __launch_bounds__(256) void md_wino_pack_weights_f6_kernel(const float* __restrict__ w, uint4* __restrict__ wpk, int cout, int cin,
+                                                                      int64_t s_row, int64_t s_k, uint32_t* __restrict__ hdr) {
+  const int64_t n = (int64_t)cout * cin * 9;
+  const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const float wscale = md_wino_f8_wscale(__uint_as_float(hdr[0]));
+  if (id == 0) {
+    hdr[1] = (uint32_t)ilogbf(wscale);
+    hdr[2] = __float_as_uint(1.0f / wscale);
+    hdr[3] = 6u;                                          // the cross-term format of this buffer (md_conv3_wino_f6 checks nothing: host-side type)
+  }
+  if (id >= n) return;
+  wpk[id] = md_pack_wino_f6_item(w, cout, cin, s_row, s_k, wscale, id);
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // md_conv3_wino
 // ------------------------------------------------------------------------------------------------------------------
@@ -201,7 +215,12 @@ struct WnArgs {
 typedef int wn_i32x8 __attribute__((ext_vector_type(8)));
 typedef int wn_i32x4 __attribute__((ext_vector_type(4)));
 
-template <int ABL, bool F8 = false>
+// F6 (with F8) = the "f16f6" arithmetic (md_common.h md_split_f16f6; operand from md_wino_prep_f6, weights from md_wino_pack_weights_f6): the
+// cross terms as MX block-scaled e2m3 x e2m3 (format code 2), which the same K = 64 MFMA executes at twice its e4m3 rate (measured
+// in the fp16 mix, tools/probes/f6_probe.hip: 0.85 of the f16f8 pair-step on random data).  Same geometry, loads, LDS image and
+// schedule: the 32-byte fragment a lane assembles from its two 16-byte items is [6 registers of codes | the block's E8M0 scale |
+// 0], and register 6 of either fragment is that MFMA's per-lane scale operand.
+template <int ABL, bool F8 = false, bool F6 = false>
 __global__ __launch_bounds__(WN_THREADS) void md_conv3_wino_kernel(const WnArgs A) {
   __shared__ __attribute__((aligned(16))) unsigned char wn_smem[WN_LDS_BYTES];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -314,11 +333,27 @@ __global__ __launch_bounds__(WN_THREADS) void md_conv3_wino_kernel(const WnArgs 
     //     prefetch of pair-step 4's fragments in the last group of pair-step 3, issued after that group's store;
     //     chunk c0 + 2 (buffer 0, free after pair-step 4): requested at 3, 4, 5, 6, stored at 5, 6, 7, 8.
     // A body has an odd number of pair-steps, so two bodies (PB = 0 / 1: which weight set holds pair-step 0) are unrolled.
+    // W8_HG: the halo request schedule of the pair-step loop.  A wave's loads return in order and it can only keep as many requests
+    // in flight as it has registers for them: with 8 pieces (two groups of four, requested two pair-steps before their store) the loop
+    // measured 86.7 k cycles per workgroup against 75.2 k with the same requests served from a resident kilobyte (s_memtime stamps,
+    // profiles/r04_f8_halo_latency.txt) -- a latency x parallelism limit, not a placement one (1 and 2 below measured neutral):
+    //   0: requests 2 + 2 in groups 2 and 3, entry q stored by group q, two pair-steps later
+    //   1: all 16 weight requests in group 0, the four halo requests in group 1, entries 0 1 | 2 3 stored by groups 0 | 1
+    //   2: weights in groups 0 1, the four halo requests in group 2, entries 0 | 1 | 2 3 stored by groups 0 | 1 | 2
+    //   3: as 2 with THREE groups in flight, requested three pair-steps before their store (12 pieces = 12 KB per wave, +16 registers)
+    // (a store of entry q always precedes the request that refills it: pass 0 of a group runs before its pass 1)
+#ifndef W8_HG
+#define W8_HG 3
+#endif
+    // W8_HG = 3, slots by interval colouring over a body's 9 pair-steps (request u_r -> store u_s, ' = next body): slot 0: 0 -> 3, 3 -> 6,
+    // 6 -> 0'; slot 1: 2 -> 5, 5 -> 8, 8 -> 2'; slot 2: 4 -> 7, 7 -> 1'
+    auto slot3_of_store = [](int u) constexpr -> int { return (u == 0 || u == 3 || u == 6) ? 0 : ((u == 2 || u == 5 || u == 8) ? 1 : 2); };
+    auto slot3_of_request = [](int u) constexpr -> int { return (u == 0 || u == 3 || u == 6) ? 0 : ((u == 2 || u == 5 || u == 8) ? 1 : 2); };
     const int npairs = nsteps >> 1;
     const uint4* wbase8 = A.wpk + (((int64_t)rtb * npairs) * 4 + wid) * 1024 + lane;       // + p * 4096 + piece * 64
     // weights [set][row tile]: the two fp16 fragments (step 2p, 2p+1) and the 32-byte fp8 fragment (8 consecutive registers: its two
     // 16-byte loads write the halves directly); halo fragments of one group [group parity] likewise; halo pieces in flight [slot][group]
-    uint4 A8h[2][4][2], B8h[2][2], hs8[2][4];
+    uint4 A8h[2][4][2], B8h[2][2], hs8[W8_HG == 3 ? 3 : 2][4];
     wn_i32x8 A8f[2][4], B8f[2];
     // The source offsets of the 15 halo pieces (loop-invariant, ~45 VALU each to recompute, 15 registers to keep) live in a
     // 3.75 KB table per wave behind the halo buffers (the epilogue's exchange area reuses the space): one ds_read_b32 per request.
@@ -350,8 +385,11 @@ __global__ __launch_bounds__(WN_THREADS) void md_conv3_wino_kernel(const WnArgs 
       dh[1] = *(const uint4*)(vBh + o1);
       df = cat8(*(const uint4*)(v8 + o0), *(const uint4*)(v8 + o0 + 2 * WN_TPOS * 16));
     };
+#ifndef W8_ABL
+#define W8_ABL 0      // timing-only A/B builds of the f16f8 loop (results invalid): 1 weights always those of pair-step 0, 2 halo requests from one
+#endif                // resident 1 KB per wave, 4 no halo stores in the loop, 8 no fragment reads in the loop (tools/ab_f8_sched.sh)
     auto load_A8 = [&](int p, int set, int rt0, int nrt) {      // row tiles rt0 .. rt0 + nrt - 1 of pair-step p
-      const uint4* wp = wbase8 + (int64_t)p * 4096;
+      const uint4* wp = wbase8 + (int64_t)((W8_ABL & 1) ? 0 : p) * 4096;
 #pragma unroll
       for (int rt = 0; rt < 4; ++rt)
         if (rt >= rt0 && rt < rt0 + nrt) {
@@ -376,7 +414,18 @@ __global__ __launch_bounds__(WN_THREADS) void md_conv3_wino_kernel(const WnArgs 
         live_mask |= (dk >= 0 ? 1u : 0u) << k;
         otab[k * 64] = o;
         h0[k] = wn_gload16(tbase + o);
-        if (k < 8) hs8[k >> 2][k & 3] = wn_gload16(tbase + (int64_t)16 * Ph + o);
+#ifndef W8_PRO_SPLIT
+#define W8_PRO_SPLIT 1      // A/B: 0 = chunk 1's first pieces requested interleaved with chunk 0's (the wait for chunk 0 then covers them: loads return in order)
+#endif
+        // chunk 1's first groups of four (stored by pair-steps 0, 1 (, 2)): slots as the loop's store side expects them
+        if constexpr (!W8_PRO_SPLIT)
+          if (k < (W8_HG == 3 ? 12 : 8)) hs8[W8_HG == 3 ? slot3_of_store(k >> 2) : (k >> 2)][k & 3] = wn_gload16(tbase + (int64_t)16 * Ph + o);
+        if constexpr (W8_PRO_FENCE) __builtin_amdgcn_sched_barrier(0);
+      }
+      if constexpr (W8_PRO_SPLIT) {      // behind ALL of chunk 0 in the memory queue; the offsets come back out of the table
+#pragma unroll
+        for (int k = 0; k < (W8_HG == 3 ? 12 : 8); ++k)
+          hs8[W8_HG == 3 ? slot3_of_store(k >> 2) : (k >> 2)][k & 3] = wn_gload16(tbase + (int64_t)16 * Ph + otab[k * 64]);
         if constexpr (W8_PRO_FENCE) __builtin_amdgcn_sched_barrier(0);
       }
       if constexpr (W8_PRO_FENCE) zero_acc();
@@ -390,8 +439,12 @@ __global__ __launch_bounds__(WN_THREADS) void md_conv3_wino_kernel(const WnArgs 
     const int scale_a = 127 - 11, scale_b = 127;       // E8M0: the fp8 products carry 2^-11
     // first of the (up to) four halo pieces pair-step u requests, two in group 2 and two in group 3 (99 = none): pieces 8..14 of
     // chunk c0 + 1 at pair-steps 0, 1; all of c0 + 2 at 3..6; 0..7 of c0 + 3 at 7, 8
-    auto base_of = [](int u) constexpr -> int { return u == 0 ? 8 : (u == 1 ? 12 : (u >= 3 && u <= 6 ? (u - 3) * 4 : (u >= 7 ? (u - 7) * 4 : 99))); };
-    uint32_t off_next[2] = {0u, 0u};                     // source offsets of the next group's requests, read one group ahead
+    auto base_of = [](int u) constexpr -> int {
+      if (W8_HG == 3)      // three pair-steps ahead: piece 12.. of c0 + 1 at pair-step 0; all of c0 + 2 at 2..5; 0..11 of c0 + 3 at 6, 7, 8
+        return u == 0 ? 12 : (u >= 2 && u <= 5 ? (u - 2) * 4 : (u >= 6 ? (u - 6) * 4 : 99));
+      return u == 0 ? 8 : (u == 1 ? 12 : (u >= 3 && u <= 6 ? (u - 3) * 4 : (u >= 7 ? (u - 7) * 4 : 99)));
+    };
+    uint32_t off_next[4] = {0u, 0u, 0u, 0u};             // source offsets of the next group's requests, read one group ahead
     auto body = [&](auto pbc, int c0) {
       constexpr int PB = decltype(pbc)::value;
       const int p0 = (c0 * 9) >> 1;
@@ -404,16 +457,27 @@ __global__ __launch_bounds__(WN_THREADS) void md_conv3_wino_kernel(const WnArgs 
         // back to back -- a dependent chain with hazard nops between the fp16 and the fp8 form -- and clumps the memory operations):
         // -- pass 0 (fp16, step 2u): the halo piece requested two pair-steps ago goes to LDS, then the next group's fragments are
         //    read (LDS executes a wave's accesses in order: the first reader of a refilled buffer is issued behind its last store)
-        constexpr int st_piece = u <= 3 ? u * 4 + ct : (u >= 5 ? (u - 5) * 4 + ct : 99);
-        constexpr int st_slot = u <= 3 ? (u & 1) : ((u - 5) & 1);
-        if constexpr (st_piece < WN_NDMA) halo_store8(u <= 3 ? 1 : 0, st_piece, hs8[st_slot][ct]);
-        read_B8(std::integral_constant<int, un>{}, std::integral_constant<int, ctn>{}, B8h[bset ^ 1], B8f[bset ^ 1]);
+        // W8_HG (defined above): where a pair-step's four halo requests and stores sit, and how many request groups are in flight
+        constexpr int HG = W8_HG, RG = HG == 1 ? 1 : 2;
+        constexpr int sq_lo = HG == 0 ? ct : (HG == 1 ? (ct < 2 ? 2 * ct : 4) : (ct < 2 ? ct : (ct == 2 ? 2 : 4)));
+        constexpr int sq_hi = HG == 0 ? ct + 1 : (HG == 1 ? (ct < 2 ? 2 * ct + 2 : 4) : (ct < 2 ? ct + 1 : 4));
+        constexpr int st_base = u <= 3 ? u * 4 : (u >= 5 ? (u - 5) * 4 : 99);
+        constexpr int st_slot = HG == 3 ? slot3_of_store(u) : (u <= 3 ? (u & 1) : ((u - 5) & 1));
+        constexpr int n_st = (sq_lo < sq_hi && st_base + sq_lo < WN_NDMA) + (sq_lo + 1 < sq_hi && st_base + sq_lo + 1 < WN_NDMA);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (q >= sq_lo && q < sq_hi && st_base + q < WN_NDMA) {
+            if constexpr (W8_ABL & 4) asm volatile("" :: "v"(hs8[st_slot][q].x), "v"(hs8[st_slot][q].w));
+            else halo_store8(u <= 3 ? 1 : 0, st_base + q, hs8[st_slot][q]);
+          }
+        if constexpr (!(W8_ABL & 8)) read_B8(std::integral_constant<int, un>{}, std::integral_constant<int, ctn>{}, B8h[bset ^ 1], B8f[bset ^ 1]);
+        else asm volatile("" : "+v"(B8h[bset ^ 1][0]), "+v"(B8h[bset ^ 1][1]), "+v"(B8f[bset ^ 1]));
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt)
           acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A8h[aset][rt][0]), __builtin_bit_cast(f16x8, B8h[bset][0]),
                                                                acc[rt][ct], 0, 0, 0);
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        if constexpr (st_piece < WN_NDMA) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        if constexpr (n_st > 0 && !(W8_ABL & 4)) __builtin_amdgcn_sched_group_barrier(0x200, n_st, 0);
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
@@ -426,41 +490,53 @@ __global__ __launch_bounds__(WN_THREADS) void md_conv3_wino_kernel(const WnArgs 
         //    the table one group earlier -- BEHIND the weight loads of groups 0 and 1 in the memory queue: loads return in order,
         //    and the wait for the weights at the next pair-step must not cover a halo request (an HBM access) issued just before them
         constexpr int ld_base = base_of(u), ldn_base = base_of(un);
-        constexpr int ld_slot = u == 0 ? 0 : (u == 1 ? 1 : ((u - 3) & 1));      // alternates over the eight requesting pair-steps 0 1 3 4 5 6 7 8
-        constexpr int q0 = 2 * (ct - 2), qn = 2 * (ctn - 2);
-        constexpr int n_ld = ct < 2 ? 0 : ((ld_base + q0 < WN_NDMA) + (ld_base + q0 + 1 < WN_NDMA));
-        constexpr int n_rd = ctn < 2 ? 0 : ((ldn_base + qn < WN_NDMA) + (ldn_base + qn + 1 < WN_NDMA));
+        constexpr int ld_slot = HG == 3 ? slot3_of_request(u) : (u == 0 ? 0 : (u == 1 ? 1 : ((u - 3) & 1)));      // HG < 3: alternates over the eight requesting pair-steps 0 1 3 4 5 6 7 8
+        // entries [rq_lo, rq_hi) are requested by this group, [rn_lo, rn_hi) by the next one (its offsets are read out of the table now)
+        constexpr int rq_lo = HG == 0 ? (ct >= 2 ? 2 * (ct - 2) : 4) : (ct == RG ? 0 : 4), rq_hi = HG == 0 ? (ct >= 2 ? 2 * (ct - 2) + 2 : 4) : 4;
+        constexpr int rn_lo = HG == 0 ? (ctn >= 2 ? 2 * (ctn - 2) : 4) : (ctn == RG ? 0 : 4), rn_hi = HG == 0 ? (ctn >= 2 ? 2 * (ctn - 2) + 2 : 4) : 4;
+        constexpr int n_ld = (rq_lo < rq_hi ? ((ld_base + rq_lo < WN_NDMA) + (ld_base + rq_lo + 1 < WN_NDMA && rq_lo + 1 < rq_hi) +
+                                               (ld_base + rq_lo + 2 < WN_NDMA && rq_lo + 2 < rq_hi) + (ld_base + rq_lo + 3 < WN_NDMA && rq_lo + 3 < rq_hi)) : 0);
+        constexpr int n_rd = (rn_lo < rn_hi ? ((ldn_base + rn_lo < WN_NDMA) + (ldn_base + rn_lo + 1 < WN_NDMA && rn_lo + 1 < rn_hi) +
+                                               (ldn_base + rn_lo + 2 < WN_NDMA && rn_lo + 2 < rn_hi) + (ldn_base + rn_lo + 3 < WN_NDMA && rn_lo + 3 < rn_hi)) : 0);
         if constexpr (n_ld > 0) {
-          const uint4* cb = tbase + (int64_t)(u <= 1 ? cn1 : (u <= 6 ? cn2 : cn3)) * 16 * Ph;
-          hs8[ld_slot][q0] = wn_gload16(cb + off_next[0]);
-          if constexpr (n_ld > 1) hs8[ld_slot][q0 + 1] = wn_gload16(cb + off_next[1]);
+          const uint4* cb = tbase + (int64_t)(HG == 3 ? (u == 0 ? cn1 : (u <= 5 ? cn2 : cn3)) : (u <= 1 ? cn1 : (u <= 6 ? cn2 : cn3))) * 16 * Ph;
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (i < n_ld) hs8[ld_slot][rq_lo + i] = wn_gload16((W8_ABL & 2) ? tbase + lane : cb + off_next[i]);
         }
-        if constexpr (n_rd > 0) off_next[0] = otab[(ldn_base + qn) * 64];
-        if constexpr (n_rd > 1) off_next[1] = otab[(ldn_base + qn + 1) * 64];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (i < n_rd) off_next[i] = otab[(ldn_base + rn_lo + i) * 64];
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt)
           acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A8h[aset][rt][1]), __builtin_bit_cast(f16x8, B8h[bset][1]),
                                                                acc[rt][ct], 0, 0, 0);
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         if constexpr (n_rd > 0) __builtin_amdgcn_sched_group_barrier(0x100, n_rd, 0);
+        if constexpr (n_ld > 2) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         if constexpr (n_ld > 0) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         if constexpr (n_ld > 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if constexpr (n_ld > 3) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
         __builtin_amdgcn_sched_barrier(0);
         // -- pass 2 (fp8, both steps; 64 cycles per MFMA): in the first two groups the 16 weight pieces of the next pair-step
 #ifndef W8_NA
 #define W8_NA 2
 #endif
-        constexpr int NA = W8_NA;            // groups that carry the 16 weight loads (A/B: 1 = all in group 0)
+        constexpr int NA = HG == 1 ? 1 : W8_NA;      // groups that carry the 16 weight loads (1 = all in group 0)
         if constexpr (ct < NA) {
           const int pn = p0 + u + 1 < npairs ? p0 + u + 1 : npairs - 1;      // clamped: the redundant tail request is never used
           load_A8(pn, aset ^ 1, ct * (4 / NA), 4 / NA);
         }
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt)
-          acc[rt][ct] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A8f[aset][rt], B8f[bset], acc[rt][ct], 0, 0, 0, scale_a, 0, scale_b);
+          if constexpr (F6)
+            acc[rt][ct] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A8f[aset][rt], B8f[bset], acc[rt][ct], 2, 2, 0, A8f[aset][rt][6], 0,
+                                                                          B8f[bset][6]);
+          else
+            acc[rt][ct] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A8f[aset][rt], B8f[bset], acc[rt][ct], 0, 0, 0, scale_a, 0, scale_b);
         if constexpr (ct < NA) {
 #pragma unroll
           for (int i_ = 0; i_ < 4; ++i_) {
@@ -775,7 +851,7 @@ extern "C" int64_t md_wino_weight_bytes_f8(int32_t cout, int32_t cin) {
   return (int64_t)cout * cin * 36 * 4 + 256;             // fragments + header
 }
 
-extern "C" int md_wino_pack_weights_f8(const float* w, void* wpk, int32_t cout, int32_t cin, int64_t s_row, int64_t s_k, void* stream) {
+static int md_wino_pack_weights_f8_launch(bool f6, const float* w, void* wpk, int32_t cout, int32_t cin, int64_t s_row, int64_t s_k, void* stream) {
   if (!w || !wpk || cout <= 0 || cin <= 0 || (cout % 128) || (cin % 32)) return MD_ERR_BAD_ARG;
   const int64_t n = (int64_t)cout * cin * 9;
   uint32_t* hdr = (uint32_t*)((unsigned char*)wpk + n * 16);
@@ -787,15 +863,27 @@ extern "C" int md_wino_pack_weights_f8(const float* w, void* wpk, int32_t cout, 
   if (ab > 1024) ab = 1024;
   hipLaunchKernelGGL(md_wino_amax_kernel, dim3((unsigned)ab), dim3(256), 0, (hipStream_t)stream, w, cout, cin, s_row, s_k, hdr);
   MD_HIP_CHECK_LAUNCH();
-  hipLaunchKernelGGL(md_wino_pack_weights_f8_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, (uint4*)wpk,
-                     cout, cin, s_row, s_k, hdr);
+  if (f6)
+    hipLaunchKernelGGL(md_wino_pack_weights_f6_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, (uint4*)wpk,
+                       cout, cin, s_row, s_k, hdr);
+  else
+    hipLaunchKernelGGL(md_wino_pack_weights_f8_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, (uint4*)wpk,
+                       cout, cin, s_row, s_k, hdr);
   MD_HIP_CHECK_LAUNCH();
   return MD_OK;
 }
 
-extern "C" int md_conv3_wino_f8(const void* t_in, const void* wpk, float* out, const float* bias, int64_t bias_bstride,
-                                const float* residual, int64_t res_bstride, double* stats, int32_t batch, int32_t cin,
-                                int32_t cout, int32_t D, int32_t H, int32_t W, void* stream) {
+extern "C" int md_wino_pack_weights_f8(const float* w, void* wpk, int32_t cout, int32_t cin, int64_t s_row, int64_t s_k, void* stream) {
+  return md_wino_pack_weights_f8_launch(false, w, wpk, cout, cin, s_row, s_k, stream);
+}
+
+extern "C" int md_wino_pack_weights_f6(const float* w, void* wpk, int32_t cout, int32_t cin, int64_t s_row, int64_t s_k, void* stream) {
+  return md_wino_pack_weights_f8_launch(true, w, wpk, cout, cin, s_row, s_k, stream);
+}
+
+static int md_conv3_wino_f8_launch(bool f6, const void* t_in, const void* wpk, float* out, const float* bias, int64_t bias_bstride,
+                                   const float* residual, int64_t res_bstride, double* stats, int32_t batch, int32_t cin,
+                                   int32_t cout, int32_t D, int32_t H, int32_t W, void* stream) {
   if (!t_in || !wpk || !out || batch <= 0) return MD_ERR_BAD_ARG;
   if (cin <= 0 || cout <= 0 || (cin % 32) || (cout % 128)) return MD_ERR_UNSUPPORTED;
   if (D <= 0 || H <= 0 || W <= 0 || (D % WN_TZ) || (H % WN_TY) || (W % WN_TX)) return MD_ERR_UNSUPPORTED;
@@ -806,16 +894,29 @@ extern "C" int md_conv3_wino_f8(const void* t_in, const void* wpk, float* out, c
   a.bias_bstride = bias_bstride; a.res_bstride = res_bstride;
   a.batch = batch; a.cin = cin; a.cout = cout; a.D = D; a.H = H; a.W = W;
   const int tiles = (D / WN_TZ) * (H / WN_TY) * (W / WN_TX);
+  const dim3 grid((unsigned)(tiles * batch), (unsigned)(cout / 128));
   MD_HIP_CLEAR_ERROR();
 #ifdef W8_STAMPS      // A/B build only (tools/bench_wino.py --f8 --stamps): `stats` receives the per-wave s_memtime stamps, no statistics
-  hipLaunchKernelGGL((md_conv3_wino_kernel<128, true>), dim3((unsigned)(tiles * batch), (unsigned)(cout / 128)), dim3(WN_THREADS), 0,
-                     (hipStream_t)stream, a);
+  if (f6) hipLaunchKernelGGL((md_conv3_wino_kernel<128, true, true>), grid, dim3(WN_THREADS), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((md_conv3_wino_kernel<128, true>), grid, dim3(WN_THREADS), 0, (hipStream_t)stream, a);
 #else
-  hipLaunchKernelGGL((md_conv3_wino_kernel<0, true>), dim3((unsigned)(tiles * batch), (unsigned)(cout / 128)), dim3(WN_THREADS), 0,
-                     (hipStream_t)stream, a);
+  if (f6) hipLaunchKernelGGL((md_conv3_wino_kernel<0, true, true>), grid, dim3(WN_THREADS), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((md_conv3_wino_kernel<0, true>), grid, dim3(WN_THREADS), 0, (hipStream_t)stream, a);
 #endif
   MD_HIP_CHECK_LAUNCH();
   return MD_OK;
+}
+
+extern "C" int md_conv3_wino_f8(const void* t_in, const void* wpk, float* out, const float* bias, int64_t bias_bstride,
+                                const float* residual, int64_t res_bstride, double* stats, int32_t batch, int32_t cin,
+                                int32_t cout, int32_t D, int32_t H, int32_t W, void* stream) {
+  return md_conv3_wino_f8_launch(false, t_in, wpk, out, bias, bias_bstride, residual, res_bstride, stats, batch, cin, cout, D, H, W, stream);
+}
+
+extern "C" int md_conv3_wino_f6(const void* t_in, const void* wpk, float* out, const float* bias, int64_t bias_bstride,
+                                const float* residual, int64_t res_bstride, double* stats, int32_t batch, int32_t cin,
+                                int32_t cout, int32_t D, int32_t H, int32_t W, void* stream) {
+  return md_conv3_wino_f8_launch(true, t_in, wpk, out, bias, bias_bstride, residual, res_bstride, stats, batch, cin, cout, D, H, W, stream);
 }
 
 extern "C" int md_conv3_wino(const void* t_in, const void* wpk, float* out, const float* bias, int64_t bias_bstride,

@@ -86,6 +86,50 @@ __device__ __forceinline__ void md_split_f16f8(const float (&t)[8], uint4& hi, u
   ql[1] = md_e4m3x4(l[4], l[5], l[6], l[7]);
 }
 
+// "f16f6" split (the Winograd conv's third arithmetic, conv3_wino.hip F6 path): as f16f8, but the two cross terms are computed from MX
+// block-scaled e2m3 images (OCP fp6: 2 exponent + 3 mantissa bits, max 7.5), which v_mfma_scale_f32_32x32x64_f8f6f4 multiplies at
+// twice its e4m3 rate.  A K block = the 32 values a lane feeds to that MFMA = 16 channels x (value, scaled remainder); the block
+// shares ONE power-of-two scale (its E8M0 byte travels in the 7th dword of the 32-byte record and is handed to the MFMA as the
+// lane's scale operand).  tools/probes/f6_probe.hip pins: v_cvt_scalef32_2xpk16_fp6_f32 = RNE onto e2m3, saturating, the two
+// sources INTERLEAVED (position 2i = src0[i], 2i + 1 = src1[i]); format code 2; every lane's own byte 0 scales its own block.
+// hipcc (ROCm 7.2) lets that instruction's destination overlap its sources although it reads them while writing (the probe's
+// first run lost two values): the wrapper marks the destination early-clobber.
+typedef float md_f32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t md_u32x6 __attribute__((ext_vector_type(6)));
+__device__ __forceinline__ md_u32x6 md_cvt_2xpk16_fp6(md_f32x16 a, md_f32x16 b) {
+  md_u32x6 r;
+  asm("v_cvt_scalef32_2xpk16_fp6_f32 %0, %1, %2, 1.0" : "=&v"(r) : "v"(a), "v"(b));
+  return r;
+}
+// 16 values -> hi0 / hi1: their fp16 images (channels 0-7 / 8-15); r0 / r1: the 32-byte record [6 dwords of e2m3 codes | E8M0 byte
+// + scale_bias | 0] split in two 16-byte items.  Source order of the codes: activations (t, remainder), weights -- lo_first --
+// (remainder, t): position 2i of a weight block meets position 2i of an activation block, so the MFMA sums t_w rem_a + rem_w t_a.
+__device__ __forceinline__ void md_split_f16f6(const float (&t)[16], bool lo_first, int scale_bias, uint4& hi0, uint4& hi1, uint4& r0,
+                                               uint4& r1) {
+  float l[16];
+  uint32_t hw[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) hw[i] = md_f16f8_pair(t[2 * i], t[2 * i + 1], l[2 * i], l[2 * i + 1]);
+  hi0 = make_uint4(hw[0], hw[1], hw[2], hw[3]);
+  hi1 = make_uint4(hw[4], hw[5], hw[6], hw[7]);
+  float m = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) m = fmaxf(m, fmaxf(fabsf(t[i]), fabsf(l[i])));
+  // block exponent e = floor(log2 m) - 2: the scaled values lie in (-8, 8), the top sixteenth of the binade saturates at 7.5
+  int eb = (int)(__float_as_uint(m) >> 23);                 // biased exponent of m >= 0
+  eb = eb < 20 ? 20 : eb;                                   // an all-zero / denormal block: any scale, the codes are zero
+  const float inv = __uint_as_float((uint32_t)(256 - eb) << 23);      // 2^-(eb - 127 - 2)
+  md_f32x16 a, b;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    a[i] = (lo_first ? l[i] : t[i]) * inv;
+    b[i] = (lo_first ? t[i] : l[i]) * inv;
+  }
+  const md_u32x6 c = md_cvt_2xpk16_fp6(a, b);
+  r0 = make_uint4(c[0], c[1], c[2], c[3]);
+  r1 = make_uint4(c[4], c[5], (uint32_t)(eb - 2 + scale_bias), 0u);
+}
+
 // Counter-based dropout mask (training).  One 64-bit hash per 4 consecutive channels of one position gives four
 // 16-bit uniforms; element e is kept when its field >= thr16 = round(p * 65536).  `q` = ((b * c_total + first channel
 // of the quad) / 4) * P + pos identifies the quad, so the forward, the backward and md_dropout_scale regenerate the

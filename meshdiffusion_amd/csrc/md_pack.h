@@ -111,3 +111,35 @@ __device__ __forceinline__ uint4 md_pack_wino_f8_item(const float* __restrict__ 
   (void)cout;
   return piece < 2 ? hi : make_uint4(ql[0], ql[1], q[0], q[1]);
 }
+
+// "f16f6" weight fragments (md_conv3_wino_f6; md_split_f16f6 in md_common.h): the layout of md_pack_wino_f8_item, pieces 2 / 3 =
+// the two halves of the lane's 32-byte MX record: lane (row, h) belongs to step 2p + h and its K block is the 16 input channels of
+// that step's chunk: [e2m3 codes of (lo(G') 2^11, G') x 16, interleaved | E8M0 byte of the block, 2^-11 folded in | 0].
+__device__ __forceinline__ uint4 md_pack_wino_f6_item(const float* __restrict__ w, int cout, int cin, int64_t s_row, int64_t s_k, float wscale,
+                                                      int64_t id) {
+  const int piece = (int)((id / 64) % 4);
+  if (piece < 2) return md_pack_wino_f8_item(w, cout, cin, s_row, s_k, wscale, id);      // the fp16 fragments are the same
+  int64_t r = id;
+  const int lane = (int)(r % 64); r /= 64;
+  r /= 4;
+  const int rtile = (int)(r % 4); r /= 4;
+  const int f = (int)(r % 4); r /= 4;
+  const int npairs = (cin / 16) * 9 / 2;
+  const int p = (int)(r % npairs); r /= npairs;
+  const int rtb = (int)r;
+  const int row = lane & 31, h = lane >> 5;
+  const int co = (rtb * 4 + rtile) * 32 + row;
+  const int step = 2 * p + h;
+  const int chunk = step / 9, tap = step % 9;
+  float g16[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const float* g = w + (int64_t)co * s_row + (int64_t)(chunk * 16 + e) * s_k + tap * 3;
+    const float g0 = g[0], g1 = g[1], g2 = g[2];
+    const float G = f == 0 ? g0 : f == 1 ? (g0 + g1 + g2) * 0.5f : f == 2 ? (g0 - g1 + g2) * 0.5f : g2;
+    g16[e] = G * wscale;
+  }
+  uint4 h0, h1, r0, r1;
+  md_split_f16f6(g16, true, -11, h0, h1, r0, r1);
+  return piece == 2 ? r0 : r1;
+}

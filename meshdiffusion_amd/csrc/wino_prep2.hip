@@ -170,6 +170,107 @@ __global__ __launch_bounds__(256) void md_wino_prep2_kernel(const float* __restr
   }
 }
 
+// md_wino_prep_f6: T in the "f16f6" operand format of md_conv3_wino_f6 -- the geometry of the f16f8 operand, plane 0 = 8 fp16 (hi) per
+// channel group, plane 1 = the 32-byte MX record of a 16-channel K block ([e2m3 codes of (t, (t - hi) 2^11) x 16 | E8M0 scale | 0],
+// md_split_f16f6) split over the block's two channel groups.  The block scale couples two channel groups, so a workgroup takes
+// BOTH of them (16 channels x 256 positions): phase 1 activates every position once per group (2 x 32 bytes per thread), phase 2
+// owns a (pair, frequency half) with all 16 channels.
+__global__ __launch_bounds__(256) void md_wino_prep2_f6_kernel(const float* __restrict__ x1, const float* __restrict__ x2, int c1, int c2,
+                                                               const float* __restrict__ ac, int silu, int ups, uint4* __restrict__ T, int batch,
+                                                               int D, int H, int W) {
+  __shared__ __attribute__((aligned(16))) float act[2 * P2_POS * P2_STRIDE];
+  const int tid = threadIdx.x;
+  const int Wp = W >> 1;
+  const int64_t P = (int64_t)D * H * W, Ph = P >> 1;
+  const int CG = (c1 + c2) >> 3, CGP = CG >> 1;
+  const int nblk = (int)(P / P2_POS);
+  const int blk = blockIdx.x % nblk;
+  const int cgp = (blockIdx.x / nblk) % CGP;
+  const int b = blockIdx.x / (nblk * CGP);
+  int Di = D, Hi = H, Wi = W;
+  if (ups) { Di >>= 1; Hi >>= 1; Wi >>= 1; }
+  const int64_t Pin = (int64_t)Di * Hi * Wi;
+  // ---- phase 1 ----
+  {
+    const int64_t p = (int64_t)blk * P2_POS + tid;
+    const int x = (int)(p % W), y = (int)((p / W) % H), z = (int)(p / ((int64_t)W * H));
+    const int64_t spos = ups ? ((int64_t)(z >> 1) * Hi + (y >> 1)) * Wi + (x >> 1) : p;
+#pragma unroll
+    for (int g2 = 0; g2 < 2; ++g2) {
+      const int cg = 2 * cgp + g2;
+      const float* src = (cg * 8 < c1) ? x1 + ((int64_t)b * (c1 >> 3) + cg) * Pin * 8
+                                       : x2 + ((int64_t)b * (c2 >> 3) + (cg - (c1 >> 3))) * Pin * 8;
+      const f32x4* sp = (const f32x4*)(src + spos * 8);
+      const f32x4 v0 = sp[0], v1 = sp[1];
+      float a[8], c[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { a[e] = 1.f; c[e] = 0.f; }
+      if (ac != nullptr) {
+        const f32x4* ap = (const f32x4*)(ac + ((int64_t)b * (c1 + c2) + cg * 8) * 2);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 v = ap[q];
+          a[2 * q] = v[0]; c[2 * q] = v[1]; a[2 * q + 1] = v[2]; c[2 * q + 1] = v[3];
+        }
+      }
+      float yv[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float t = e < 4 ? v0[e] : v1[e - 4];
+        if (ac != nullptr) {
+          t = t * a[e] + c[e];
+          if (silu) t = t * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t * -1.4426950408889634f));
+        }
+        yv[e] = t;
+      }
+      float* dst = act + (g2 * P2_POS + tid) * P2_STRIDE;
+      *(f32x4*)dst = f32x4{yv[0], yv[1], yv[2], yv[3]};
+      *(f32x4*)(dst + 4) = f32x4{yv[4], yv[5], yv[6], yv[7]};
+    }
+  }
+  __syncthreads();
+  // ---- phase 2 ----
+  {
+    const int pi = tid & 127, fh = tid >> 7;
+    const int lp = 2 * pi;
+    const int x = lp % W;
+    float d[4][16];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const bool need = fh == 0 ? k < 3 : k > 0;
+      const int xx = x - 1 + k;
+      const bool live = need && xx >= 0 && xx < W;
+#pragma unroll
+      for (int g2 = 0; g2 < 2; ++g2) {
+        f32x4 u0 = {0.f, 0.f, 0.f, 0.f}, u1 = u0;
+        if (live) {
+          const float* sv = act + (g2 * P2_POS + lp - 1 + k) * P2_STRIDE;
+          u0 = *(const f32x4*)sv; u1 = *(const f32x4*)(sv + 4);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) d[k][g2 * 8 + e] = e < 4 ? u0[e] : u1[e - 4];
+      }
+    }
+    const int64_t pos2 = ((int64_t)blk * P2_POS >> 1) + pi;
+    uint4* out0 = T + ((int64_t)b * CG + 2 * cgp) * 8 * Ph + pos2;        // channel group 2 cgp: [f][plane][Ph] items of 16 B
+    uint4* out1 = out0 + 8 * Ph;                                          // channel group 2 cgp + 1
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      const int f = 2 * fh + g;
+      float t[16];
+#pragma unroll
+      for (int e = 0; e < 16; ++e)
+        t[e] = f == 0 ? d[0][e] - d[2][e] : f == 1 ? d[1][e] + d[2][e] : f == 2 ? d[2][e] - d[1][e] : d[1][e] - d[3][e];
+      uint4 h0, h1, r0, r1;
+      md_split_f16f6(t, false, 0, h0, h1, r0, r1);
+      out0[(int64_t)(f * 2) * Ph] = h0;
+      out1[(int64_t)(f * 2) * Ph] = h1;
+      out0[(int64_t)(f * 2 + 1) * Ph] = r0;
+      out1[(int64_t)(f * 2 + 1) * Ph] = r1;
+    }
+  }
+}
+
 static int md_wino_prep2_launch(const float* x1, const float* x2, int32_t c1, int32_t c2, const float* ac, int32_t silu,
                                 int32_t ups, void* t_out, void* u_out, float* sums, int32_t batch, int32_t D, int32_t H, int32_t W, float drop_p,
                                 uint64_t drop_seed, void* stream, bool f8 = false) {
@@ -215,4 +316,20 @@ extern "C" int md_wino_prep_dual(const float* x1, const float* x2, int32_t c1, i
 extern "C" int md_wino_prep_f8(const float* x1, const float* x2, int32_t c1, int32_t c2, const float* ac, int32_t silu,
                                int32_t ups, void* t_out, int32_t batch, int32_t D, int32_t H, int32_t W, void* stream) {
   return md_wino_prep2_launch(x1, x2, c1, c2, ac, silu, ups, t_out, nullptr, nullptr, batch, D, H, W, 0.f, 0, stream, true);
+}
+
+extern "C" int md_wino_prep_f6(const float* x1, const float* x2, int32_t c1, int32_t c2, const float* ac, int32_t silu,
+                               int32_t ups, void* t_out, int32_t batch, int32_t D, int32_t H, int32_t W, void* stream) {
+  if (!x1 || !t_out || batch <= 0 || c1 <= 0 || c2 < 0 || (c1 & 15) || (c2 & 15) || (c2 > 0 && !x2)) return MD_ERR_BAD_ARG;   // whole 16-channel blocks per part
+  if (silu && !ac) return MD_ERR_BAD_ARG;
+  if (D <= 0 || H <= 0 || W <= 0 || (W & 1) || (ups && ((D | H | W) & 1))) return MD_ERR_BAD_ARG;
+  const int64_t P = (int64_t)D * H * W;
+  if ((P2_POS % W) || (P % P2_POS)) return MD_ERR_UNSUPPORTED;
+  const int64_t blocks = (int64_t)batch * ((c1 + c2) / 16) * (P / P2_POS);
+  if (blocks > 0x7fffffff) return MD_ERR_UNSUPPORTED;
+  MD_HIP_CLEAR_ERROR();
+  hipLaunchKernelGGL(md_wino_prep2_f6_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x1, x2, c1, c2, ac, silu, ups,
+                     (uint4*)t_out, batch, D, H, W);
+  MD_HIP_CHECK_LAUNCH();
+  return MD_OK;
 }

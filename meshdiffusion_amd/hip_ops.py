@@ -28,9 +28,11 @@ PRECISION = os.environ.get("MD_PRECISION", "bf16x3")
 # fp16(a) fp16(b) + [e4m3(a) e4m3(b_lo 2^11) + e4m3(a_lo 2^11) e4m3(b)] 2^-11 -- one fp16 MFMA + half a K-concatenated scaled fp8
 # MFMA = 2 matrix-core units per product instead of 3 (1.3e-5 per conv against bf16x3's 5.5e-6: tools/f16f8_numerics.py).
 # Training keeps bf16x3 (the backward reads the forward's bf16 T, and gradients need bf16's exponent range).
-WINO_F8 = False
-if PRECISION == "f16f8":
-    PRECISION, WINO_F8 = "bf16x3", True
+# "f16f6": as f16f8, the cross terms from MX block-scaled e2m3 images (md_wino_prep_f6 + md_conv3_wino_f6): the K = 64 MFMA runs them
+# at twice its e4m3 rate (1.7e-5 per conv).
+WINO_F8 = False          # False | "f8" | "f6": cross-term format of the inference Winograd convs
+if PRECISION in ("f16f8", "f16f6"):
+    PRECISION, WINO_F8 = "bf16x3", PRECISION[3:]
 
 
 FORCE_PRECISION = os.environ.get("MD_FORCE_PRECISION")      # A/B runs of the test suite / CLI: wins over config.model.hip_precision
@@ -39,13 +41,13 @@ FORCE_PRECISION = os.environ.get("MD_FORCE_PRECISION")      # A/B runs of the te
 def set_precision(mode):
     global PRECISION, WINO_F8
     mode = FORCE_PRECISION or mode
-    if mode not in ("bf16x3", "fp16x2", "f16f8"):
+    if mode not in ("bf16x3", "fp16x2", "f16f8", "f16f6"):
         raise ValueError(f"unknown precision mode {mode!r}")
-    PRECISION, WINO_F8 = ("bf16x3", True) if mode == "f16f8" else (mode, False)
+    PRECISION, WINO_F8 = ("bf16x3", mode[3:]) if mode in ("f16f8", "f16f6") else (mode, False)
 
 
 def precision_name():
-    return "f16f8" if (WINO_F8 and PRECISION == "bf16x3") else PRECISION
+    return ("f16" + WINO_F8) if (WINO_F8 and PRECISION == "bf16x3") else PRECISION
 
 
 def fast_prec(cfg):
@@ -408,18 +410,18 @@ class WinoWeightF8:
     """Conv3d weight [Co][Ci][3][3][3] -> the "f16f8" fragments of md_conv3_wino_f8 (md_wino_pack_weights_f8: fp16 hi fragments +
     K-concatenated e4m3 fragments of the power-of-two pre-scaled G-transformed weights, header with the scale).  Inference only."""
 
-    def __init__(self, w, device):
+    def __init__(self, w, device, fmt="f8"):
         lib = _lib.load()
         w = w.detach().to(device=device, dtype=torch.float32).contiguous()
         _require_cuda(w, "weight")
-        assert w.dim() == 5 and tuple(w.shape[2:]) == (3, 3, 3)
-        self.rows, self.kdim = w.shape[0], w.shape[1]
+        assert w.dim() == 5 and tuple(w.shape[2:]) == (3, 3, 3) and fmt in ("f8", "f6")
+        self.rows, self.kdim, self.fmt = w.shape[0], w.shape[1], fmt      # fmt "f6": md_wino_pack_weights_f6 (MX e2m3 cross terms)
         nbytes = lib.md_wino_weight_bytes_f8(self.rows, self.kdim)
         if nbytes <= 0:
             raise _lib.MeshDiffusionHipError("md_wino_weight_bytes_f8: unsupported weight shape")
         self.data = torch.empty(nbytes // 2, dtype=torch.bfloat16, device=device)
-        check(lib.md_wino_pack_weights_f8(_ptr(w), _ptr(self.data), self.rows, self.kdim, self.kdim * 27, 27, _stream()),
-              "md_wino_pack_weights_f8")
+        pack = lib.md_wino_pack_weights_f6 if fmt == "f6" else lib.md_wino_pack_weights_f8
+        check(pack(_ptr(w), _ptr(self.data), self.rows, self.kdim, self.kdim * 27, 27, _stream()), "md_wino_pack_weights_" + fmt)
 
 
 WINO_MIN_WGS = int(os.environ.get("MD_WINO_MIN_WGS", "256"))   # fewest workgroups the Winograd kernel is launched with
@@ -475,10 +477,15 @@ def release_scratch():
     _WINO_SCRATCH.clear()
 
 
-def wino_f8_ok(S, drop=None, keep=False):
-    """The f16f8 arithmetic of the Winograd path: inference launches (no dropout, T not kept for a backward) on grids the
-    two-phase operand pass takes."""
-    return WINO_F8 and PRECISION == "bf16x3" and not drop and not keep and 256 % S == 0
+def wino_f8_ok(S, drop=None, keep=False, parts=None):
+    """The f16f8 / f16f6 arithmetic of the Winograd path: inference launches (no dropout, T not kept for a backward) on grids the
+    two-phase operand pass takes.  Returns False or the cross-term format ("f8" / "f6"; f6 needs whole 16-channel blocks per
+    part and falls back to f8 otherwise)."""
+    if not (WINO_F8 and PRECISION == "bf16x3" and not drop and not keep and 256 % S == 0):
+        return False
+    if WINO_F8 == "f6" and parts is not None and any(c % 16 for _, c in parts):
+        return "f8"
+    return WINO_F8
 
 
 def wino_prep(parts, ac, silu, ups, B, S, drop=None, keep=False, dual=False, sums=None, f8=False):
@@ -501,8 +508,11 @@ def wino_prep(parts, ac, silu, ups, B, S, drop=None, keep=False, dual=False, sum
     args = (_ptr(parts[0][0]), _ptr(x2), parts[0][1], c2, _ptr(ac), 1 if silu else 0, 1 if ups else 0)
     tail = (B, S, S, S, drop[0] if drop else 0.0, drop[1] if drop else 0, _stream())
     if f8:
-        assert not (dual or keep or drop), "the f16f8 operand is an inference format"
-        check(lib.md_wino_prep_f8(*args, _ptr(t), B, S, S, S, _stream()), "md_wino_prep_f8")
+        assert not (dual or keep or drop), "the f16f8 / f16f6 operand is an inference format"
+        if f8 == "f6":
+            check(lib.md_wino_prep_f6(*args, _ptr(t), B, S, S, S, _stream()), "md_wino_prep_f6")
+        else:
+            check(lib.md_wino_prep_f8(*args, _ptr(t), B, S, S, S, _stream()), "md_wino_prep_f8")
     elif dual:
         if 256 % S:
             raise _lib.MeshDiffusionHipError("md_wino_prep_dual needs W | 256")
@@ -512,7 +522,7 @@ def wino_prep(parts, ac, silu, ups, B, S, drop=None, keep=False, dual=False, sum
         fn = lib.md_wino_prep_v2 if (WINO_PREP_V2 and 256 % S == 0) else lib.md_wino_prep
         check(fn(*args, _ptr(t), *tail), "md_wino_prep")
     _prof_end(ev, "wino_prep", 0.0, 4.0 * B * cin * (S ** 3 // (8 if ups else 1)) + (16.0 if dual else 8.0) * B * cin * S ** 3,   # fp32 in, 2 x bf16 x 2 out
-              f"{cin}@{S}x{S}x{S}" + ("/ups" if ups else "") + ("/dual" if dual else "") + ("/f8" if f8 else ""))
+              f"{cin}@{S}x{S}x{S}" + ("/ups" if ups else "") + ("/dual" if dual else "") + (("/f6" if f8 == "f6" else "/f8") if f8 else ""))
     return (t, u) if dual else t
 
 
@@ -552,8 +562,9 @@ def conv3_wino(ww, t, B, S, *, bias=None, bias_bstride=0, residual=None, res_bst
     ev = _prof_begin()
     f8 = isinstance(ww, WinoWeightF8)        # the weight object fixes the arithmetic; `t` must come from wino_prep(f8=...) accordingly
     if f8:
-        check(lib.md_conv3_wino_f8(_ptr(t), _ptr(ww.data), _ptr(out), _ptr(bias), bias_bstride, _ptr(residual), res_bstride,
-                                   _ptr(stats), B, ww.kdim, ww.rows, S, S, S, _stream()), "md_conv3_wino_f8")
+        fn = lib.md_conv3_wino_f6 if ww.fmt == "f6" else lib.md_conv3_wino_f8
+        check(fn(_ptr(t), _ptr(ww.data), _ptr(out), _ptr(bias), bias_bstride, _ptr(residual), res_bstride,
+                 _ptr(stats), B, ww.kdim, ww.rows, S, S, S, _stream()), "md_conv3_wino_" + ww.fmt)
     else:
         check(lib.md_conv3_wino(_ptr(t), _ptr(ww.data), _ptr(out), _ptr(bias), bias_bstride, _ptr(residual), res_bstride,
                                 _ptr(stats), B, ww.kdim, ww.rows, S, S, S, WINO_VARIANT if variant is None else variant, _stream()),
@@ -561,7 +572,7 @@ def conv3_wino(ww, t, B, S, *, bias=None, bias_bstride=0, residual=None, res_bst
     _prof_end(ev, "wino", 2.0 * B * ww.rows * ww.kdim * 27 * P,
               4.0 * (2 * B * ww.kdim * P + ww.rows * ww.kdim * 36 + B * ww.rows * P * (2 if residual is not None else 1)),
               f"{ww.kdim}->{ww.rows}@{S}x{S}x{S}" + ("/res" if residual is not None else "") + ("/stats" if stats is not None else "")
-              + ("/f8" if f8 else ""))
+              + (("/" + ww.fmt) if f8 else ""))
     return out
 
 

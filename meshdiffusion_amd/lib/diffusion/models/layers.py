@@ -117,7 +117,8 @@ def conv3_wino_packed(layer, name, conv):
     f16f8 arithmetic (hip_ops.WinoWeightF8, inference)."""
     def build(f8=False):
         if f8:
-            return layer._cached(f"{name}/wino_f8", [conv.weight], lambda: ops.WinoWeightF8(conv.weight, conv.weight.device))
+            fmt = "f6" if f8 == "f6" else "f8"
+            return layer._cached(f"{name}/wino_{fmt}", [conv.weight], lambda: ops.WinoWeightF8(conv.weight, conv.weight.device, fmt))
         return layer._cached(f"{name}/wino", [conv.weight], lambda: ops.WinoWeight(conv.weight, conv.weight.device))
     return build
 
@@ -153,7 +154,7 @@ def run_conv3(pw, act_s16, B, S_out, *, bias=None, bias_bstride=0, residual=None
     if (b_f32 is not None and wino is not None and out_mode == ops.OUT_F32B and rows_alloc == pw.rows
             and pw.prec == ops.PREC_BF16X3 and ops.wino_ok(pw.rows, pw.kdim, S_out, B)):
         stats = ops.stats_zeros(B, rows_alloc, dev) if want_stats and ops.FUSE_GN_STATS else None
-        f8 = ops.wino_f8_ok(S_out, drop=b_f32.get("drop"), keep=bool(b_f32.get("keep"))) and not b_f32.get("wino_only")
+        f8 = (not b_f32.get("wino_only")) and ops.wino_f8_ok(S_out, drop=b_f32.get("drop"), keep=bool(b_f32.get("keep")), parts=b_f32["parts"])
         t = ops.wino_prep(b_f32["parts"], b_f32.get("ac"), b_f32.get("silu"), ups, B, S_out, drop=b_f32.get("drop"),
                           keep=bool(b_f32.get("keep")), f8=f8)
         if b_f32.get("keep"):

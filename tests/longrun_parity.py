@@ -40,7 +40,7 @@ def main():
                     help="oracle: the fp32 PyTorch restatement on the same GPU (default); direct: the HIP path with the direct 27-tap "
                          "kernels (MD_WINO=0) -- the build whose 999-step parity vs the oracle is on record -- so that a B = 8 run "
                          "of the full schedule costs minutes instead of half an hour of fp32 torch convolutions")
-    ap.add_argument("--precision", default=None, help="config.model.hip_precision of the HIP path (default: the config's: f16f8)")
+    ap.add_argument("--precision", default=None, help="config.model.hip_precision of the HIP path (default: the config's: f16f6)")
     ap.add_argument("--oracle-samples", default=None,
                     help="comma-separated sample indices: the HIP path runs the whole batch (the graded B = 8 launches), the fp32 oracle "
                          "only these samples of it on the same noise (samples are independent: GroupNorm is per sample) -- a 999-step "

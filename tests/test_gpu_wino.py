@@ -468,8 +468,51 @@ def _conv_f16f8_reference(ref_in, w):
     return torch.stack([y0, y1], -1).reshape(B, cout, S, S, S) * 2.0 ** -sw
 
 
+def _q6_e2m3(x):
+    """RNE onto OCP e2m3 (steps 1/8 below 2, 1/4 below 4, 1/2 below 8), saturating at 7.5 -- what v_cvt_scalef32_2xpk16_fp6_f32 does
+    (tools/probes/f6_probe.hip: 0 of 1984 random values differ)."""
+    e = torch.floor(torch.log2(x.abs().clamp_min(1e-30))).clamp(0, 2)
+    step = torch.exp2(e - 3)
+    return (torch.round(x / step) * step).clamp(-7.5, 7.5)
+
+
+def _f16f6_images(x, ch_dim):
+    """hi (fp16) and the MX e2m3 images of (x, (x - hi) 2^11) with one power-of-two scale per block of 16 along `ch_dim`
+    (md_split_f16f6: scale = 2^(floor(log2 amax) - 2) from the block's max over both sequences)."""
+    hi = x.clamp(-65504, 65504).half()
+    lo = (x - hi.float()) * 2048.0
+    xs, ls = x.movedim(ch_dim, -1), lo.movedim(ch_dim, -1)
+    shp = xs.shape
+    xb, lb = xs.reshape(shp[:-1] + (shp[-1] // 16, 16)), ls.reshape(shp[:-1] + (shp[-1] // 16, 16))
+    amax = torch.maximum(xb.abs().amax(-1, keepdim=True), lb.abs().amax(-1, keepdim=True)).float().contiguous()
+    eb = ((amax.view(torch.int32) >> 23) & 0xff).clamp_min(20)
+    scale = torch.exp2((eb - 129).float())
+    q = (_q6_e2m3(xb / scale) * scale).reshape(shp).movedim(-1, ch_dim)
+    ql = (_q6_e2m3(lb / scale) * scale).reshape(shp).movedim(-1, ch_dim)
+    return hi, q, ql
+
+
+def _conv_f16f6_reference(ref_in, w):
+    """The f16f6 Winograd conv restated in torch (blocks of 16 input channels per position / per weight row and tap)."""
+    B, _, S = ref_in.shape[:3]
+    cout = w.shape[0]
+    amax = float(w.abs().max())
+    sw = 7 - int(np.floor(np.log2(1.5 * np.float32(amax))))
+    T = _wino_T(F.pad(ref_in, (0, 0, 1, 1, 1, 1)))
+    G = [g * (2.0 ** sw) for g in _wino_G(w)]
+    m = []
+    for f in range(4):
+        th, tq, tl = _f16f6_images(T[f], 1)
+        gh, gq, gl = _f16f6_images(G[f][..., None], 1)
+        cross = F.conv3d(tq.float(), gl.float()) + F.conv3d(tl.float(), gq.float())
+        m.append(F.conv3d(th.float(), gh.float()) + cross * 2.0 ** -11)
+    y0, y1 = (m[0] + m[1]) + m[2], (m[1] - m[2]) - m[3]
+    return torch.stack([y0, y1], -1).reshape(B, cout, S, S, S) * 2.0 ** -sw
+
+
+@pytest.mark.parametrize("fmt", ["f8", "f6"])
 @pytest.mark.parametrize("case", ["plain_128", "two_parts_gn_silu_res_stats", "ups_256rows", "k64_32cube"])
-def test_conv3_wino_f8_vs_torch(ops, case):
+def test_conv3_wino_f8_vs_torch(ops, case, fmt):
     """md_conv3_wino_f8 against torch fp32 (budget: 3e-5, measured ~1.3e-5 = the arithmetic's own error), against the torch
     restatement of the SAME arithmetic (only the fp32 accumulation order differs: < 2e-6) and bit-identical between launches.
     Shapes: one / several chunk pairs (cin 32: a single body, 64: both unrolled bodies, 128: the loop), two row blocks, two
@@ -498,11 +541,11 @@ def test_conv3_wino_f8_vs_torch(ops, case):
         ref_in = F.silu(ref_in) if c["silu"] else ref_in
     if c["ups"]:
         ref_in = F.interpolate(ref_in, scale_factor=2, mode="nearest")
-    ww = ops.WinoWeightF8(w.cuda(), "cuda")
+    ww = ops.WinoWeightF8(w.cuda(), "cuda", fmt)
     res_f = ops.ncdhw_to_f32b(res.cuda()) if res is not None else None
     outs = []
     for _ in range(2):
-        t = ops.wino_prep(parts, ac, c["silu"], c["ups"], B, S, f8=True)
+        t = ops.wino_prep(parts, ac, c["silu"], c["ups"], B, S, f8=fmt)
         stats = torch.zeros((B, cout, 2), dtype=torch.float64, device="cuda") if c["stats"] else None
         outs.append(ops.conv3_wino(ww, t, B, S, bias=bias.cuda(), bias_bstride=cout, residual=res_f,
                                    res_bstride=cout * S ** 3 if res is not None else 0, stats=stats).clone())
@@ -513,11 +556,13 @@ def test_conv3_wino_f8_vs_torch(ops, case):
     e = rel_l2(y, ref)
     # the restatement needs the kernel's own activated operand for a tight comparison only up to the activation's rounding
     # (v_exp / v_rcp in the operand pass): 1e-6-level differences in t, far below the arithmetic's 1e-5
-    emu = _conv_f16f8_reference(ref_in, w) + extra
+    emu = (_conv_f16f6_reference if fmt == "f6" else _conv_f16f8_reference)(ref_in, w) + extra
     e_emu = rel_l2(y, emu)
-    print(f"f16f8 wino conv ({case}): vs torch fp64 {e:.2e}, vs the torch restatement of the arithmetic {e_emu:.2e}")
-    assert e < TOL_MFMA
-    assert e_emu < (4e-6 if c["gn"] else 2e-6)
+    print(f"f16{fmt} wino conv ({case}): vs torch fp64 {e:.2e}, vs the torch restatement of the arithmetic {e_emu:.2e}")
+    assert e < (4e-5 if fmt == "f6" else TOL_MFMA)      # f16f6: 1.7e-5 on the CPU model (tools/f16f8_numerics.py)
+    # f16f6: an activation that differs in its last bits (v_exp / v_rcp) can move a block maximum across a binade or a value across
+    # an e2m3 rounding boundary (steps of 1/16 of the block maximum): rarer, larger differences than with e4m3
+    assert e_emu < ((8e-6 if c["gn"] else 2e-6) if fmt == "f6" else (4e-6 if c["gn"] else 2e-6))
     if c["stats"]:
         st, yd = stats.cpu(), y.double()
         assert rel_l2(st[..., 0], yd.sum(dim=(2, 3, 4))) < 1e-6
@@ -546,3 +591,12 @@ def test_conv3_wino_f8_against_bf16x3_on_full_tiles(ops):
     e = rel_l2(outs[0].cpu(), yb.cpu())
     print(f"f16f8 vs bf16x3 Winograd conv: {e:.2e}")
     assert e < 3e-5
+    w6 = ops.WinoWeightF8(w.cuda(), "cuda", "f6")
+    outs6 = []
+    for _ in range(2):
+        t = ops.wino_prep(parts, ac, True, False, B, S, f8="f6")
+        outs6.append(ops.conv3_wino(w6, t, B, S, bias=bias.cuda(), bias_bstride=cout).clone())
+    assert torch.equal(outs6[0], outs6[1])
+    e6 = rel_l2(outs6[0].cpu(), yb.cpu())
+    print(f"f16f6 vs bf16x3 Winograd conv: {e6:.2e}")
+    assert e6 < 4e-5

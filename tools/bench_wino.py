@@ -82,7 +82,7 @@ def main():
                 print(json.dumps(rows[-1]), flush=True)
             t = ops.wino_prep([(x, cin)], ac, True, False, B, S)      # the two paths share one scratch buffer: restore T
         if a.f8 and 256 % S == 0:
-            ww8 = ops.WinoWeightF8(w, dev)
+            ww8, ww6 = ops.WinoWeightF8(w, dev), ops.WinoWeightF8(w, dev, "f6")
             kw = dict(bias=bias, bias_bstride=cout, residual=None if a.no_res else res, res_bstride=0 if a.no_res else cout * S ** 3,
                       stats=None if a.no_stats else stats, out=out)
             for rep in range(3):           # a, b, a, b, a, b
@@ -93,9 +93,13 @@ def main():
                 t8 = ops.wino_prep([(x, cin)], ac, True, False, B, S, f8=True)
                 ms_p8 = timed(lambda: ops.wino_prep([(x, cin)], ac, True, False, B, S, f8=True))
                 ms_b = timed(lambda: ops.conv3_wino(ww8, t8, B, S, **kw))
+                t6 = ops.wino_prep([(x, cin)], ac, True, False, B, S, f8="f6")      # the f16f6 operand (same scratch buffer)
+                ms_p6 = timed(lambda: ops.wino_prep([(x, cin)], ac, True, False, B, S, f8="f6"))
+                ms_c = timed(lambda: ops.conv3_wino(ww6, t6, B, S, **kw))
                 ops.WINO_PREP_V2 = False
                 rows.append(dict(shape=sh, kernel="A/B bf16x3 vs f16f8", rep=rep, bf16x3_ms=round(ms_a, 4), f16f8_ms=round(ms_b, 4),
-                                 ratio=round(ms_b / ms_a, 4), prep_ms=round(ms_p, 4), prep_f8_ms=round(ms_p8, 4),
+                                 ratio=round(ms_b / ms_a, 4), f16f6_ms=round(ms_c, 4), f6_over_f8=round(ms_c / ms_b, 4),
+                                 prep_ms=round(ms_p, 4), prep_f8_ms=round(ms_p8, 4), prep_f6_ms=round(ms_p6, 4),
                                  bf16x3_tflops_alg=round(flops / ms_a / 1e9, 1), f16f8_tflops_alg=round(flops / ms_b / 1e9, 1)))
                 print(json.dumps(rows[-1]), flush=True)
             t = ops.wino_prep([(x, cin)], ac, True, False, B, S)      # restore the bf16 operand in the shared scratch buffer

@@ -22,6 +22,14 @@ typedef int i32x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x6 __attribute__((ext_vector_type(6)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
+// hipcc (ROCm 7.2) lets the destination of v_cvt_scalef32_2xpk16_fp6_f32 overlap its sources (first run of this probe: dst v[32:37] on
+// src1 v[18:33] -- the last two values of source 1 came out as +-7.5); the instruction reads its sources while it writes: early clobber.
+__device__ __forceinline__ u32x6 cvt_2xpk16_fp6(f32x16 a, f32x16 b, float scale) {
+  u32x6 r;
+  asm volatile("v_cvt_scalef32_2xpk16_fp6_f32 %0, %1, %2, %3" : "=&v"(r) : "v"(a), "v"(b), "v"(scale));
+  return r;
+}
+
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 
 static double e2m3_round(double x) {      // nearest (ties to even) representable e2m3 value, saturating at +-7.5
@@ -38,7 +46,7 @@ __global__ void enc_dec_kernel(const float* x, float* y, unsigned* codes, float 
   const int l = threadIdx.x;
   f32x16 s0, s1;
   for (int i = 0; i < 16; ++i) { s0[i] = x[l * 32 + i]; s1[i] = x[l * 32 + 16 + i]; }
-  const u32x6 c = __builtin_amdgcn_cvt_scalef32_2xpk16_fp6_f32(s0, s1, enc_scale);
+  const u32x6 c = cvt_2xpk16_fp6(s0, s1, enc_scale);
   for (int q = 0; q < 6; ++q) codes[l * 6 + q] = c[q];
   const f32x32 d = __builtin_amdgcn_cvt_scalef32_pk32_f32_fp6(c, dec_scale);
   for (int i = 0; i < 32; ++i) y[l * 32 + i] = d[i];
@@ -53,8 +61,8 @@ __global__ void sem_kernel(const float* A, const float* Bt, const int* sa, const
     a0[m] = A[i * 64 + kb * 32 + m]; a1[m] = A[i * 64 + kb * 32 + 16 + m];
     b0[m] = Bt[i * 64 + kb * 32 + m]; b1[m] = Bt[i * 64 + kb * 32 + 16 + m];
   }
-  const u32x6 ca = __builtin_amdgcn_cvt_scalef32_2xpk16_fp6_f32(a0, a1, 1.0f);
-  const u32x6 cb = __builtin_amdgcn_cvt_scalef32_2xpk16_fp6_f32(b0, b1, 1.0f);
+  const u32x6 ca = cvt_2xpk16_fp6(a0, a1, 1.0f);
+  const u32x6 cb = cvt_2xpk16_fp6(b0, b1, 1.0f);
   i32x8 a, b;
   for (int q = 0; q < 6; ++q) { a[q] = (int)ca[q]; b[q] = (int)cb[q]; }
   a[6] = sa[l]; a[7] = 0x55555555; b[6] = sb[l]; b[7] = 0x2a2a2a2a;      // the record layout of the conv kernel: scale in element 6, junk in 7
