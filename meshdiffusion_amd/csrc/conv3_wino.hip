@@ -315,7 +315,7 @@ __global__ __launch_bounds__(WN_THREADS) void md_conv3_wino_kernel(const WnArgs 
 #ifndef W8_PRO_FENCE
 #define W8_PRO_FENCE 1      // A/B: 0 = the prologue order hipcc chooses by itself (accumulators zeroed and all offsets computed before the first request)
 #endif
-  if constexpr (!F8 || !W8_PRO_FENCE) zero_acc();
+  if constexpr (!W8_PRO_FENCE) zero_acc();
   float descale = 1.f;
   if constexpr (F8) {
     static_assert(ABL == 0 || ABL == 128, "timing ablations exist for the bf16x3 loop only");
@@ -567,13 +567,27 @@ __global__ __launch_bounds__(WN_THREADS) void md_conv3_wino_kernel(const WnArgs 
     bf16x8 Bf[2][8];      // halo     [step parity][ct * 2 + plane]
     uint4 hst[2][3];      // halo pieces on their way from global memory to LDS: [tap parity][piece of the step]
   
-    // ---- prologue: chunk 0 of the halo (15 pieces, all requested before the first is stored), weights of steps 0 and 1 ----
+    // ---- prologue: chunk 0 of the halo (15 pieces, all requested before the first is stored), weights of steps 0 and 1; as in the
+    // f16f8 prologue the order is fenced: weight requests, offset k -> request k, the accumulators zeroed while the requests fly ----
     {
       uint4 h0[WN_NDMA];
+      if constexpr (W8_PRO_FENCE) {
+        load_A(0, Ar[0]);
+        load_A(nsteps > 1 ? 1 : 0, Ar[1]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
   #pragma unroll
-      for (int k = 0; k < WN_NDMA; ++k) h0[k] = halo_load(0, k);
-      load_A(0, Ar[0]);
-      load_A(nsteps > 1 ? 1 : 0, Ar[1]);
+      for (int k = 0; k < WN_NDMA; ++k) {
+        h0[k] = halo_load(0, k);
+        if constexpr (W8_PRO_FENCE) __builtin_amdgcn_sched_barrier(0);
+      }
+      if constexpr (W8_PRO_FENCE) {
+        zero_acc();
+        __builtin_amdgcn_sched_barrier(0);
+      } else {
+        load_A(0, Ar[0]);
+        load_A(nsteps > 1 ? 1 : 0, Ar[1]);
+      }
       if constexpr (ABL & 4) load_A(nsteps > 2 ? 2 : 0, Ar[2]);      // timing only: three real weight sets, reused for every step
   #pragma unroll
       for (int k = 0; k < WN_NDMA; ++k) halo_store(0, k, h0[k]);

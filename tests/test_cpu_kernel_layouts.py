@@ -138,3 +138,39 @@ def test_attention_v_image_matches_the_p_key_order():
                             [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31]):
                     for half in (0, 32):
                         assert _bank_groups_distinct([slots[half + g] for g in grp])
+
+
+def test_winograd_f8_halo_request_schedule_three_groups_in_flight():
+    """csrc/conv3_wino.hip, pair-step loop with W8_HG = 3: a body = 9 pair-steps over two chunks; pair-step u stores the group of four
+    halo pieces st_base(u) .. + 3 of chunk c0 + 1 (u <= 3, buffer 1) or c0 + 2 (u >= 5, buffer 0) out of slot slot3(u), and requests
+    the group base_of(u) .. + 3 of chunk c0 + 1 / + 2 / + 3 into slot slot3(u).  Replayed over several bodies: every stored group was
+    requested exactly three pair-steps earlier, for the chunk and the pieces the store expects, into the slot it is read from, no slot
+    is refilled while it still holds an unstored group, at most three groups are in flight, and every chunk's 15 pieces reach LDS."""
+    slot3 = lambda u: 0 if u in (0, 3, 6) else (1 if u in (2, 5, 8) else 2)          # noqa: E731
+    base_of = lambda u: 12 if u == 0 else ((u - 2) * 4 if 2 <= u <= 5 else ((u - 6) * 4 if u >= 6 else None))   # noqa: E731
+    req_chunk = lambda u, c0: c0 + 1 if u == 0 else (c0 + 2 if u <= 5 else c0 + 3)  # noqa: E731
+    st_base = lambda u: u * 4 if u <= 3 else ((u - 5) * 4 if u >= 5 else None)       # noqa: E731
+    st_chunk = lambda u, c0: c0 + 1 if u <= 3 else c0 + 2                            # noqa: E731
+    nbodies = 5
+    # prologue: chunk 0 whole into buffer 0; chunk 1's pieces 0..11 requested into the slots of the stores at pair-steps 0, 1, 2
+    slots = {slot3(g): dict(chunk=1, pieces=list(range(4 * g, 4 * g + 4)), t=-3 + g) for g in range(3)}
+    stored = {0: set(range(15))}
+    t = 0
+    for body in range(nbodies):
+        c0 = 2 * body
+        for u in range(9):
+            sb = st_base(u)
+            if sb is not None:                       # pass 0 of groups 0..2: the stores
+                ent = slots.pop(slot3(u))
+                want = [p for p in range(sb, sb + 4) if p < 15]
+                assert ent["chunk"] == st_chunk(u, c0) and [p for p in ent["pieces"] if p < 15] == want, (body, u, ent)
+                assert t - ent["t"] == 3, (body, u)
+                stored.setdefault(ent["chunk"], set()).update(want)
+            lb = base_of(u)
+            if lb is not None:                       # pass 1 of group 2: the requests
+                assert slot3(u) not in slots, (body, u)          # the slot was emptied by this pair-step's stores (or earlier)
+                slots[slot3(u)] = dict(chunk=req_chunk(u, c0), pieces=list(range(lb, lb + 4)), t=t)
+            assert len(slots) <= 3
+            t += 1
+        # the chunks this body's MFMAs read next are complete: c0 + 1 from pair-step 4 on, c0 + 2 at the start of the next body
+        assert stored[c0 + 1] == set(range(15)) and stored[c0 + 2] == set(range(15))
