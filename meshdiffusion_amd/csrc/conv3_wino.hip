@@ -449,6 +449,13 @@ __global__ __launch_bounds__(WN_THREADS) void md_conv3_wino_kernel(const WnArgs 
       constexpr int PB = decltype(pbc)::value;
       const int p0 = (c0 * 9) >> 1;
       const int cn1 = c0 + 1, cn2 = c0 + 2 < nchunk ? c0 + 2 : nchunk - 1, cn3 = c0 + 3 < nchunk ? c0 + 3 : nchunk - 1;
+      // the last body's requests for chunks that do not exist keep the loop one basic block; W8_TAIL_RES = 1 points them all at ONE resident
+      // line (entry 0 of the last chunk: the offsets are masked to zero) instead of re-reading that chunk's halo: with 8 chunks they are a
+      // fifth of all halo requests, and the weight waits behind them cover their latency like any other's
+#ifndef W8_TAIL_RES
+#define W8_TAIL_RES 1
+#endif
+      const uint32_t m2 = (!W8_TAIL_RES || c0 + 2 < nchunk) ? ~0u : 0u, m3 = (!W8_TAIL_RES || c0 + 3 < nchunk) ? ~0u : 0u;      // wave-uniform offset masks
       auto group = [&](auto uc, auto ctc) {
         constexpr int u = decltype(uc)::value, ct = decltype(ctc)::value;
         constexpr int aset = (PB + u) & 1, bset = ct & 1;
@@ -499,10 +506,12 @@ __global__ __launch_bounds__(WN_THREADS) void md_conv3_wino_kernel(const WnArgs 
         constexpr int n_rd = (rn_lo < rn_hi ? ((ldn_base + rn_lo < WN_NDMA) + (ldn_base + rn_lo + 1 < WN_NDMA && rn_lo + 1 < rn_hi) +
                                                (ldn_base + rn_lo + 2 < WN_NDMA && rn_lo + 2 < rn_hi) + (ldn_base + rn_lo + 3 < WN_NDMA && rn_lo + 3 < rn_hi)) : 0);
         if constexpr (n_ld > 0) {
-          const uint4* cb = tbase + (int64_t)(HG == 3 ? (u == 0 ? cn1 : (u <= 5 ? cn2 : cn3)) : (u <= 1 ? cn1 : (u <= 6 ? cn2 : cn3))) * 16 * Ph;
+          constexpr int which = HG == 3 ? (u == 0 ? 1 : (u <= 5 ? 2 : 3)) : (u <= 1 ? 1 : (u <= 6 ? 2 : 3));
+          const uint4* cb = tbase + (int64_t)(which == 1 ? cn1 : (which == 2 ? cn2 : cn3)) * 16 * Ph;
+          const uint32_t om = which == 1 ? ~0u : (which == 2 ? m2 : m3);      // 0: every lane reads entry 0 of the (clamped) chunk -- one resident line
 #pragma unroll
           for (int i = 0; i < 4; ++i)
-            if (i < n_ld) hs8[ld_slot][rq_lo + i] = wn_gload16((W8_ABL & 2) ? tbase + lane : cb + off_next[i]);
+            if (i < n_ld) hs8[ld_slot][rq_lo + i] = wn_gload16((W8_ABL & 2) ? tbase + lane : cb + (off_next[i] & om));
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -809,8 +818,14 @@ __global__ __launch_bounds__(WN_THREADS) void md_conv3_wino_kernel(const WnArgs 
   }
   if constexpr (ABL & 128) {      // stamps [workgroup][wave][10] of the first 1024 workgroups (dispatch order)
     const unsigned lin = blockIdx.x + gridDim.x * blockIdx.y;
-    if (lin < 1024u && lane == 0) {
-      uint64_t* dst = (uint64_t*)A.stats + ((size_t)lin * 4 + wid) * 10;
+#ifdef W8_STAMPS_LATE      // the LAST 1024 workgroups in dispatch order (steady state) instead of the cold first generation
+    const unsigned total = gridDim.x * gridDim.y;
+    const unsigned lin0 = total > 1024u ? total - 1024u : 0u;
+#else
+    const unsigned lin0 = 0u;
+#endif
+    if (lin >= lin0 && lin - lin0 < 1024u && lane == 0) {
+      uint64_t* dst = (uint64_t*)A.stats + ((size_t)(lin - lin0) * 4 + wid) * 10;
       // the stores are waited for by the end of the kernel, so the last stamp is taken before them
       stamp[8] = __builtin_amdgcn_s_memtime();
       stamp[9] = (uint64_t)(uint32_t)__builtin_amdgcn_s_getreg((31 << 11) | 4) |                 // HW_REG_HW_ID (CU / SE of the wave)

@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--kernel", default=KERNEL, help="substring of the kernel name in the summaries")
     ap.add_argument("--source", default="conv3_wino.hip", help="source file whose sha keys the entry")
+    ap.add_argument("--precision", default="f16f6", help="hip_precision of the profiled run (bench.py reports the entry only for the same one)")
     a = ap.parse_args()
     KERNEL = a.kernel
     fetch_kib, write_kib = counter(a.fetch, "FETCH_SIZE"), counter(a.write, "WRITE_SIZE")
@@ -45,7 +46,7 @@ def main():
     except OSError:
         tr = {}
     key = bench.conv_source_key(a.source)
-    tr[key] = {"kernel": f"{KERNEL} (the build bench.py runs by default)", "hbm_bytes_per_launch": round(nbytes), "batch": a.batch,
+    tr[key] = {"kernel": f"{KERNEL} (the build bench.py runs by default)", "hbm_bytes_per_launch": round(nbytes), "batch": a.batch, "precision": a.precision,
                "fetch_size_kib": fetch_kib, "write_size_kib": write_kib,
                "formula": "(2*FETCH_SIZE + WRITE_SIZE) KiB, mean over the launches of `python bench.py`",
                "source": f"{os.path.relpath(a.fetch, ROOT)} + {os.path.relpath(a.write, ROOT)}"}
