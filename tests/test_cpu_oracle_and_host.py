@@ -518,3 +518,39 @@ def test_ddim_oracle_and_schedule_vs_reference_golden():
         xin = x if n == 0 else x.double() * 0.7
         xn, x0p = uo.ddim_step(xin, eps, torch.ones(2) * ts[i], torch.ones(2) * ts[i - 1])
         assert np.array_equal(xn.numpy(), gold[f"step{n}_x_new"]) and np.array_equal(x0p.numpy(), gold[f"step{n}_x0_pred"])
+
+
+def test_round4_entry_points_reject_bad_arguments_without_a_gpu(hip_lib):
+    """The f16f8 / f16f6 entry points (md_wino_prep_f8 / _f6, md_wino_pack_weights_f8 / _f6, md_conv3_wino_f8 / _f6) check their
+    arguments before any launch; the f6 operand pass needs whole 16-channel blocks per part; precision names map to the
+    cross-term formats on the host."""
+    from meshdiffusion_amd import hip_ops
+    buf = ctypes.create_string_buffer(64)
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    for prep in (hip_lib.md_wino_prep_f8, hip_lib.md_wino_prep_f6):
+        assert prep(None, None, 16, 0, None, 0, 0, p, 1, 8, 8, 8, None) == -1            # no input
+        assert prep(p, None, 16, 0, None, 1, 0, p, 1, 8, 8, 8, None) == -1               # SiLU without the folded affine
+        assert prep(p, None, 16, 0, None, 0, 0, p, 1, 8, 8, 7, None) == -1               # odd W
+        assert prep(p, None, 16, 0, None, 0, 0, p, 1, 8, 8, 24, None) == -2              # W does not divide 256
+    assert hip_lib.md_wino_prep_f6(p, None, 24, 0, None, 0, 0, p, 1, 8, 8, 8, None) == -1        # 24 channels: not whole K blocks
+    assert hip_lib.md_wino_prep_f6(p, p, 32, 8, None, 0, 0, p, 1, 8, 8, 8, None) == -1           # second part of 8 channels
+    assert hip_lib.md_wino_weight_bytes_f8(128, 64) == 128 * 64 * 36 * 4 + 256 and hip_lib.md_wino_weight_bytes_f8(128, 48) < 0
+    for pack in (hip_lib.md_wino_pack_weights_f8, hip_lib.md_wino_pack_weights_f6):
+        assert pack(None, p, 128, 64, 64 * 27, 27, None) == -1 and pack(p, p, 96, 64, 64 * 27, 27, None) == -1
+    for conv in (hip_lib.md_conv3_wino_f8, hip_lib.md_conv3_wino_f6):
+        assert conv(None, p, p, None, 0, None, 0, None, 1, 32, 128, 8, 8, 8, None) == -1
+        assert conv(p, p, p, None, 0, None, 0, None, 1, 48, 128, 8, 8, 8, None) == -2    # cin % 32
+        assert conv(p, p, p, None, 0, None, 0, None, 1, 32, 128, 6, 8, 8, None) == -2    # D % 4
+    old = (hip_ops.PRECISION, hip_ops.WINO_F8)
+    try:
+        for mode, fmt in (("bf16x3", False), ("f16f8", "f8"), ("f16f6", "f6")):
+            if hip_ops.FORCE_PRECISION:
+                break
+            hip_ops.set_precision(mode)
+            assert hip_ops.precision_name() == mode and hip_ops.WINO_F8 == fmt
+            assert hip_ops.wino_f8_ok(64) == fmt and hip_ops.wino_f8_ok(64, drop=(0.1, 1)) is False and hip_ops.wino_f8_ok(24) is False
+        if not hip_ops.FORCE_PRECISION:
+            hip_ops.set_precision("f16f6")
+            assert hip_ops.wino_f8_ok(64, parts=[(None, 24), (None, 8)]) == "f8"       # parts that are not whole 16-channel blocks fall back
+    finally:
+        hip_ops.PRECISION, hip_ops.WINO_F8 = old
