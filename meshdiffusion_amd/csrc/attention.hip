@@ -13,8 +13,8 @@
 //                    accumulator registers: MFMA k-slot (h, i) of key step ks is key 16 ks + 8 (i / 4) + 4 h + i % 4, and
 //                    the V fragment is read from LDS in that same key order (two 8-byte pieces), so no cross-lane traffic.
 // One workgroup = 128 queries (4 waves x 32), one wave per SIMD (512 registers: 128 O accumulators in AGPRs + the wave's
-// whole Q operand, 128 VGPRs, stay resident); K and V stream through LDS in 32-key tiles (32 KB each, double buffered,
-// next tile prefetched into registers behind the 96 MFMAs of the current one, one barrier per tile).
+// whole Q operand, 128 VGPRs, stay resident); K and V stream through LDS in 32-key tiles (32 KB each, double buffered;
+// the next tile's K is prefetched into registers behind the S^T MFMAs, its V behind the softmax and the PV MFMAs, one barrier per tile).
 #include "md_common.h"
 
 namespace {
@@ -61,59 +61,74 @@ __global__ __launch_bounds__(AT_THREADS) void md_attn_fwd_kernel(const uint4* __
     for (int r = 0; r < 16; ++r) oacc[rt][r] = 0.f;
   float m_run = -1e30f, l_run = 0.f;       // running max (log2 domain) and this lane's partial denominator
 
-  // ---- tile prefetch: global -> registers -> LDS ----
-  uint4 pfk[AT_PF], pfv[AT_PF];
+  // ---- tile prefetch: global -> registers -> LDS, in two halves that share ONE set of 8 registers x 4: the K items are requested at the
+  // start of a tile and stored behind its S^T MFMAs, the V items are requested then and stored at the end of the tile.  With both
+  // sets live (64 registers) the kernel needed 510 registers and hipcc serialised half of the requests with their stores ("global_load;
+  // s_waitcnt vmcnt(0); ds_write" eight times per tile: 0.81 ms per launch; this form 0.47).
+  // Addresses: one 32-bit lane offset + a wave-uniform base per item (64-bit per-lane pointers cost 32 registers).
+  uint4 pf[AT_PF];
   const uint4* kpart = qkb + (int64_t)AT_CG * 2 * N;                 // k = channels C .. 2C-1 of the fused q|k tensor
-  auto issue = [&](int t) {
-    const int k0 = t * AT_TK;
+  const uint32_t k_lane = (uint32_t)(tid >> 5) * (uint32_t)N + (uint32_t)(tid & 31);      // item (g*2+plane) = tid / 32 + 8 i, key = tid % 32
+  auto issue_k = [&](int t) {
+    const uint4* base = kpart + t * AT_TK;
 #pragma unroll
-    for (int i = 0; i < AT_PF; ++i) {
-      const int idx = tid + i * AT_THREADS;
-      pfk[i] = kpart[(int64_t)(idx / AT_TK) * N + k0 + (idx % AT_TK)];            // (g*2+plane) = idx / 32, key = idx % 32
-      pfv[i] = vb[((int64_t)(k0 / 8) * 2) * AT_C + idx];                          // ((kg*2+plane) * C + c) = idx
-    }
+    for (int i = 0; i < AT_PF; ++i) pf[i] = (base + (int64_t)i * 8 * N)[k_lane];
   };
-  auto commit = [&](int buf) {
-    unsigned char* base = lds + buf * AT_BUF_BYTES;
+  auto issue_v = [&](int t) {
+    const uint4* base = vb + (int64_t)t * (AT_TK / 8) * 2 * AT_C;      // ((kg*2+plane) * C + c) = tid + 256 i
 #pragma unroll
-    for (int i = 0; i < AT_PF; ++i) {
-      const int idx = tid + i * AT_THREADS;
-      *(uint4*)(base + idx * 16) = pfk[i];
-    }
+    for (int i = 0; i < AT_PF; ++i) pf[i] = (base + i * AT_THREADS)[tid];
+  };
+  auto commit_k = [&](int buf) {
+    unsigned char* base = lds + buf * AT_BUF_BYTES + tid * 16;
+#pragma unroll
+    for (int i = 0; i < AT_PF; ++i) *(uint4*)(base + i * AT_THREADS * 16) = pf[i];
+  };
+  auto commit_v = [&](int buf) {
     // V: thread tid holds channel c = tid of all 8 (key group, plane) items of the tile.  The MFMA wants, per key step ks and
     // lane half h, keys 16ks + 4h + {0..3} (group 2ks, half h) followed by 16ks + 8 + 4h + {0..3} (group 2ks + 1, half h):
     // those 16 bytes are assembled here and stored as ONE item [ks][plane][h][c], so that a half-wave reads 32 consecutive
-    // 16-byte items with one ds_read_b128 (the 8-byte pieces compiled to ds_read2_b64: half the LDS rate and, per
-    // SQ_LDS_BANK_CONFLICT, a conflict cycle for every cycle of data -- profiles/r03_final_pmc_sq.summary.txt).
+    // 16-byte items with one ds_read_b128 (the 8-byte pieces compiled to ds_read2_b64: half the LDS rate).
     static_assert(AT_PF == 8 && AT_THREADS == AT_C, "one thread = one channel of all 4 key groups x 2 planes");
-    unsigned char* vbase = base + AT_K_ITEMS * 16 + tid * 16;
+    unsigned char* vbase = lds + buf * AT_BUF_BYTES + AT_K_ITEMS * 16 + tid * 16;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
       for (int p = 0; p < 2; ++p) {
-        const uint4 g0 = pfv[(2 * ks) * 2 + p], g1 = pfv[(2 * ks + 1) * 2 + p];
+        const uint4 g0 = pf[(2 * ks) * 2 + p], g1 = pf[(2 * ks + 1) * 2 + p];
         *(uint4*)(vbase + (((ks * 2 + p) * 2 + 0) * AT_C) * 16) = make_uint4(g0.x, g0.y, g1.x, g1.y);
         *(uint4*)(vbase + (((ks * 2 + p) * 2 + 1) * AT_C) * 16) = make_uint4(g0.z, g0.w, g1.z, g1.w);
       }
   };
 
   const int ntiles = N / AT_TK;
-  issue(0);
-  commit(0);
+  issue_k(0);
+  commit_k(0);
+  issue_v(0);
+  commit_v(0);
   __syncthreads();
   for (int t = 0; t < ntiles; ++t) {
     const unsigned char* kb = lds + (t & 1) * AT_BUF_BYTES;
     const unsigned char* vbuf = kb + AT_K_ITEMS * 16;
-    if (t + 1 < ntiles) issue(t + 1);
+    const bool more = t + 1 < ntiles;
+    if (more) issue_k(t + 1);
     // ---- S^T tile: 32 keys x 32 queries, K = 256 channels; two accumulators (even / odd channel steps) ----
     f32x16 s0, s1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
+    // K fragments one channel step ahead, in two register sets, the order pinned by scheduling groups (hipcc otherwise issues every
+    // ds_read_b128 directly in front of the MFMA that needs it: 0.50 -> 0.475 ms per launch)
+    bf16x8 kf[2][2];
+    kf[0][0] = *(const bf16x8*)(kb + (((0 + h) * 2 + 0) * AT_TK + j) * 16);
+    kf[0][1] = *(const bf16x8*)(kb + (((0 + h) * 2 + 1) * AT_TK + j) * 16);
 #pragma unroll
     for (int ks = 0; ks < AT_C / 16; ++ks) {
-      const int g = 2 * ks + h;
-      const bf16x8 khi = *(const bf16x8*)(kb + ((g * 2 + 0) * AT_TK + j) * 16);
-      const bf16x8 klo = *(const bf16x8*)(kb + ((g * 2 + 1) * AT_TK + j) * 16);
+      if (ks + 1 < AT_C / 16) {
+        const int g = 2 * (ks + 1) + h;
+        kf[(ks + 1) & 1][0] = *(const bf16x8*)(kb + ((g * 2 + 0) * AT_TK + j) * 16);
+        kf[(ks + 1) & 1][1] = *(const bf16x8*)(kb + ((g * 2 + 1) * AT_TK + j) * 16);
+      }
+      const bf16x8 khi = kf[ks & 1][0], klo = kf[ks & 1][1];
       if (ks & 1) {
         s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(klo, qhi[ks], s1, 0, 0, 0);
         s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(khi, qlo[ks], s1, 0, 0, 0);
@@ -123,7 +138,11 @@ __global__ __launch_bounds__(AT_THREADS) void md_attn_fwd_kernel(const uint4* __
         s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(khi, qlo[ks], s0, 0, 0, 0);
         s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(khi, qhi[ks], s0, 0, 0, 0);
       }
+      if (ks + 1 < AT_C / 16) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
     }
+    // the other buffer's last readers (tile t - 1) are behind the previous barrier: K of tile t + 1 goes in now, its V is requested
+    if (more) { commit_k((t + 1) & 1); issue_v(t + 1); }
     // ---- online softmax of this query column (log2 domain: exp(x) = 2^(x log2 e), the 1/sqrt(C) scale folded in) ----
     float tv[16];
     float mloc = -1e30f;
@@ -173,7 +192,7 @@ __global__ __launch_bounds__(AT_THREADS) void md_attn_fwd_kernel(const uint4* __
         oacc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vhi, pbh[ks], oacc[rt], 0, 0, 0);
       }
     }
-    if (t + 1 < ntiles) commit((t + 1) & 1);     // its last readers (tile t-1) are behind the previous barrier
+    if (more) commit_v((t + 1) & 1);
     __syncthreads();
   }
 
