@@ -201,26 +201,27 @@ def main():
 
     # ---- second measurement on the same workload, same process: the round-1..3 arithmetic (bf16x3 in the Winograd convs too) ----
     fast = None
-    if a.precision in ("f16f8", "f16f6") and not a.no_fast_mode and world == 1:
-        model.module.hip_precision = "bf16x3"
-        with torch.no_grad():
-            xf = stepper.prior()
-            for k in range(max(a.warmup, 2)):      # packs the bf16x3 Winograd fragments (untimed)
-                xf, _ = stepper.step(model_fn, xf, k)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for k in range(a.steps):
-                xf, xmf = stepper.step(model_fn, xf, a.warmup + k)
-            torch.cuda.synchronize()
-            wf = time.perf_counter() - t1
-        model.module.hip_precision = a.precision
-        hip_ops.set_precision(a.precision)
+    if a.precision in ("f16f8", "f16f6") and not a.no_fast_mode and world == 1 and a.steps > 0:
+        model.module.hip_precision = "bf16x3"      # the arithmetic is a property of the model call (hip_ops.precision_scope): nothing global to restore
+        try:
+            with torch.no_grad():
+                xf = stepper.prior()
+                for k in range(max(a.warmup, 2)):      # packs the bf16x3 Winograd fragments (untimed)
+                    xf, _ = stepper.step(model_fn, xf, k)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for k in range(a.steps):
+                    xf, _ = stepper.step(model_fn, xf, a.warmup + k)
+                torch.cuda.synchronize()
+                wf = time.perf_counter() - t1
+        finally:
+            model.module.hip_precision = a.precision
+        del xf
         fast = {"precision": "bf16x3 everywhere (three bf16 MFMAs per product; config.model.hip_precision = \"bf16x3\"): the headline "
                              "arithmetic of rounds 1-3, measured here in the same process on the same box",
                 "value": round(B * a.steps / wf, 3), "unit": "sample-steps/s", "ms_per_step": round(wf / a.steps * 1e3, 3),
                 "parity": "per U-Net evaluation 1.2-2.2e-5, 999-step sampled grids 8.4-8.6e-6 rel-L2 vs the fp32 oracle (profiles/r02_*, r03_longrun_*); "
                           "f16f8 / f16f6: 4e-5 / 5e-5 per evaluation (tools/f16f8_numerics.py), long-run records in profiles/r04_longrun_*"}
-        del xf, xmf
     # ---- BASELINE configs[0] on the GPU: res64, batch 1 (single-sample latency), same weights ----
     b1 = None
     if world == 1 and B != 1 and not a.no_res128:
@@ -236,6 +237,7 @@ def main():
             torch.cuda.synchronize()
             d1 = (time.perf_counter() - t1) / 10
         b1 = {"workload": "BASELINE configs[0] on the GPU: res64 4-ch grid, batch=1, DDPM ancestral sampling steps",
+              "dtype": launch_arithmetic(hip_ops, lambda: st1.step(model_fn, x1, 13), model.module.hip_precision),
               "ms_per_step": round(d1 * 1e3, 2), "sample_steps_per_s": round(1.0 / d1, 3), "steps": 10,
               "mfma_frac_step": round(FLOPS_PER_SAMPLE_STEP / d1 / (PEAK_BF16_TFLOPS * 1e12), 4)}
         del st1, x1, xm1
@@ -310,10 +312,13 @@ def main():
                       "DESIGN.md section 5 (target 1e-3 rel-L2)",
             "dtype": {"bf16x3": "bf16x3 (split-bf16 MFMA operands, fp32 accumulate/IO)",
                                             "fp16x2": "fp16x2 (weights split fp16, activations fp16, fp32 accumulate/IO)",
-                                            "f16f8": "f16f8 in the Winograd convs (fp16 hi*hi MFMA + e4m3 cross terms in a K-concatenated scaled fp8 "
-                                                     "MFMA: 2 matrix-core units per product), bf16x3 elsewhere; fp32 accumulate/IO",
-                                            "f16f6": "f16f6 in the Winograd convs (fp16 hi*hi MFMA + MX block-scaled e2m3 cross terms in a K-concatenated "
-                                                     "scaled MFMA at twice the e4m3 rate), bf16x3 elsewhere; fp32 accumulate/IO"}[a.precision],
+                                            "f16f8": "f16f8 in the Winograd convs behind a GroupNorm (fp16 hi*hi MFMA + e4m3 cross terms in a K-concatenated scaled "
+                                                     "fp8 MFMA: 2 matrix-core units per product; operands and weights equalised per input channel by a static "
+                                                     "power of two, md_wino_equaliser), bf16x3 elsewhere; fp32 accumulate/IO",
+                                            "f16f6": "f16f6 in the Winograd convs behind a GroupNorm (fp16 hi*hi MFMA + MX block-scaled e2m3 cross terms in a "
+                                                     "K-concatenated scaled MFMA at twice the e4m3 rate; operands and weights equalised per input channel by a "
+                                                     "static power of two, md_wino_equaliser), bf16x3 elsewhere (incl. the Upsample convs on the raw residual "
+                                                     "stream); fp32 accumulate/IO"}[a.precision],
             "data": "synthetic (seeded prior noise, sensitised random-init res64 weights, synthetic grid mask)",
             "config": {"workload": "BASELINE configs[1]: res64 4-ch grid DDPM ancestral sampling steps, batch=8 per GPU",
                        "batch_per_gpu": B, "grid": [cfg.data.num_channels, R, R, R],
@@ -327,6 +332,24 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def launch_arithmetic(hip_ops, step, configured):
+    """What one more (untimed) call of `step` actually launched: the model's configured arithmetic and the formats of its Winograd
+    conv launches counted from the launch tags (f16f8 / f16f6 apply behind a GroupNorm; raw-operand convs and everything outside the
+    Winograd path run bf16x3)."""
+    assert hip_ops.PROFILE is None
+    hip_ops.PROFILE = []
+    try:
+        with torch.no_grad():
+            step()
+        torch.cuda.synchronize()
+        tags = [r[5] for r in hip_ops.PROFILE if r[0] == "wino"]
+    finally:
+        hip_ops.PROFILE = None
+    n = {"f8": sum(t.endswith("/f8") for t in tags), "f6": sum(t.endswith("/f6") for t in tags)}
+    return {"configured": configured, "wino_conv_launches": {"f16f6": n["f6"], "f16f8": n["f8"], "bf16x3": len(tags) - n["f6"] - n["f8"]},
+            "elsewhere": "bf16x3"}
 
 
 def conv_source_key(src="conv3_wino.hip"):
@@ -472,6 +495,8 @@ def train_step_bench(a, cfg, model, rank, world, dev, dist, barrier):
                         f"batch {B} per GPU, dropout {cfg.model.dropout}",
             "value": round(world * B / s_per_step, 3), "unit": "samples/s", "n_gpus": world, "steps": a.train_steps,
             "ms_per_step": round(s_per_step * 1e3, 2),
+            "dtype": "bf16x3 (training forward, backward and weight gradients: hip_ops.precision_scope(training=True), whatever the model's "
+                     "inference hip_precision is)",
             "mfma_frac_step": round(3 * FLOPS_PER_SAMPLE_STEP * B / s_per_step / (PEAK_BF16_TFLOPS * 1e12), 4),
             "split_ms": {k: round(v, 2) for k, v in split.items()},
             "exchange": {"collective": "RCCL all-reduce (AVG) of fp32 gradients, in place on the flat gradient buffer"
@@ -508,7 +533,9 @@ def res128_step(dev, steps=3, warmup=2):
             x, xm = st.step(fn, x, warmup + i)
         torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
     assert bool(torch.isfinite(xm).all())
+    from meshdiffusion_amd import hip_ops
     out = {"workload": "BASELINE configs[3]: res128 4-ch grid, batch=2, DDPM ancestral sampling steps (synthetic mask)",
+           "dtype": launch_arithmetic(hip_ops, lambda: st.step(fn, x, warmup + steps), model.module.hip_precision),
            "ms_per_step": round(dt * 1e3, 2), "sample_steps_per_s": round(B / dt, 3), "steps": steps,
            "mfma_frac_step": round(B * FLOPS_PER_SAMPLE_STEP_RES128 / dt / (PEAK_BF16_TFLOPS * 1e12), 4),
            "peak_hbm_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}
@@ -585,6 +612,7 @@ def cond_gen_bench(dev, model, cfg, B=32, iters=3):
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / iters
     assert bool(torch.isfinite(out).all())
     return {"workload": f"BASELINE configs[4]: cond_gen partial-grid inpainting sampler (pc, blend + re-noise), res64, batch {B}",
+            "dtype": f"{model.module.hip_precision} (the model's config.model.hip_precision; see res64_b1.dtype for the launch formats)",
             "ms_per_iteration": round(dt * 1e3, 1), "sample_steps_per_s": round(B / dt, 2), "iterations": iters,
             "mfma_frac_step": round(B * FLOPS_PER_SAMPLE_STEP / dt / (PEAK_BF16_TFLOPS * 1e12), 4),
             "peak_hbm_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}

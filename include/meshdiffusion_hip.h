@@ -41,7 +41,7 @@ extern "C" {
 #define MD_ERR_UNSUPPORTED (-2)
 #define MD_ERR_NO_DEVICE (-3)
 
-#define MD_ABI_VERSION 13
+#define MD_ABI_VERSION 14
 
 /* ---- tile configurations of md_gemm_conv (compile-time instantiations) ---- */
 enum {
@@ -289,11 +289,22 @@ int md_conv3_wino(const void* t_in, const void* wpk, float* out, const float* bi
  *   [Cout/128][Cin*9/32 step pairs][4][row tile 4][piece 4][lane 64][16 B] + a 256-byte header {max |w|, sw, 2^-sw};
  *   size: md_wino_weight_bytes_f8.  Forward orientation only (s_row = Cin*27, s_k = 27 for [Cout][Cin][3][3][3]).
  * md_conv3_wino_f8: arguments, supported shapes and outputs as md_conv3_wino with T / wpk from the two calls above.
+ * eq (md_wino_prep_f8 / _f6 and md_wino_pack_weights_f8 / _f6; may be NULL = none): float [Cin], the static per-input-channel
+ *   power-of-two equaliser written by md_wino_equaliser.  The operand pass multiplies the activated value of channel c by eq[c], the
+ *   weight fragments hold w[:, c] / eq[c] (both exact): the convolution is unchanged, but the channels of a K block reach the
+ *   4-bit-significand cross-term images at comparable magnitudes whatever the GroupNorm affine in front of the conv is.  The SAME
+ *   vector must be given to the operand pass and to the weight packing of a layer.
+ * md_wino_equaliser (csrc/wino_eq.hip): eq[c] = 2^round(log2(g_c / a_c) / 2), clamped to 2^+-14, with a_c = rms of
+ *   silu(gamma_c z + beta_c) over z ~ N(0, 1) (64-point midpoint rule on [-6, 6]) -- what nn.GroupNorm + nn.SiLU
+ *   (layers.py:652,660,676-681) hand the conv, per channel -- and g_c = rms of w[:, c, :, :, :]; w element (co, ci, t27) at
+ *   w[co * s_row + ci * s_k + t27].  gamma / beta: the GroupNorm affine over the (concatenated) Cin input channels.
  */
+int md_wino_equaliser(const float* gamma, const float* beta, const float* w, int32_t cout, int32_t cin, int64_t s_row, int64_t s_k,
+                      float* eq, void* stream);
 int md_wino_prep_f8(const float* x1, const float* x2, int32_t c1, int32_t c2, const float* ac, int32_t silu, int32_t ups,
-                    void* t_out, int32_t batch, int32_t D, int32_t H, int32_t W, void* stream);
+                    const float* eq, void* t_out, int32_t batch, int32_t D, int32_t H, int32_t W, void* stream);
 int64_t md_wino_weight_bytes_f8(int32_t cout, int32_t cin);
-int md_wino_pack_weights_f8(const float* w, void* wpk, int32_t cout, int32_t cin, int64_t s_row, int64_t s_k, void* stream);
+int md_wino_pack_weights_f8(const float* w, const float* eq, void* wpk, int32_t cout, int32_t cin, int64_t s_row, int64_t s_k, void* stream);
 int md_conv3_wino_f8(const void* t_in, const void* wpk, float* out, const float* bias, int64_t bias_bstride,
                      const float* residual, int64_t res_bstride, double* stats, int32_t batch, int32_t cin, int32_t cout,
                      int32_t D, int32_t H, int32_t W, void* stream);
@@ -307,8 +318,8 @@ int md_conv3_wino_f8(const void* t_in, const void* wpk, float* out, const float*
  * md_wino_prep_f6 needs c1 and c2 to be multiples of 16 (whole K blocks per part).
  */
 int md_wino_prep_f6(const float* x1, const float* x2, int32_t c1, int32_t c2, const float* ac, int32_t silu, int32_t ups,
-                    void* t_out, int32_t batch, int32_t D, int32_t H, int32_t W, void* stream);
-int md_wino_pack_weights_f6(const float* w, void* wpk, int32_t cout, int32_t cin, int64_t s_row, int64_t s_k, void* stream);
+                    const float* eq, void* t_out, int32_t batch, int32_t D, int32_t H, int32_t W, void* stream);
+int md_wino_pack_weights_f6(const float* w, const float* eq, void* wpk, int32_t cout, int32_t cin, int64_t s_row, int64_t s_k, void* stream);
 int md_conv3_wino_f6(const void* t_in, const void* wpk, float* out, const float* bias, int64_t bias_bstride,
                      const float* residual, int64_t res_bstride, double* stats, int32_t batch, int32_t cin, int32_t cout,
                      int32_t D, int32_t H, int32_t W, void* stream);

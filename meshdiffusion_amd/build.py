@@ -17,7 +17,7 @@ _SUFFIX = os.environ.get("MD_LIB_SUFFIX", "")
 OBJDIR = os.path.join(CSRC, "build" + _SUFFIX)
 LIB_PATH = os.path.join(HERE, f"libmeshdiffusion_hip{_SUFFIX}.so")
 ARCH = "gfx950"
-SOURCES = ["capi.hip", "gemm_conv.hip", "conv3_main.hip", "conv3_wino.hip", "conv3_s2.hip", "conv3_head.hip", "conv3_stem.hip", "pack_batch.hip", "wino_prep2.hip", "norm.hip", "elementwise.hip", "attention.hip", "nin_stream.hip", "train.hip", "backward.hip", "wgrad.hip", "wgrad_wino.hip", "dmtet.hip"]
+SOURCES = ["capi.hip", "gemm_conv.hip", "conv3_main.hip", "conv3_wino.hip", "conv3_s2.hip", "conv3_head.hip", "conv3_stem.hip", "pack_batch.hip", "wino_prep2.hip", "wino_eq.hip", "norm.hip", "elementwise.hip", "attention.hip", "nin_stream.hip", "train.hip", "backward.hip", "wgrad.hip", "wgrad_wino.hip", "dmtet.hip"]
 # default-off experiments (MD_BUILD_EXPERIMENTAL=1): declared in include/meshdiffusion_hip_experimental.h, bound lazily by _lib.py
 EXPERIMENTAL_SOURCES = ["experimental/conv3_wino43.hip"]
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", f"-I{INCLUDE}", f"-I{CSRC}",

@@ -123,7 +123,7 @@ def get_config_res128():
     c.model.update(name="ddpm_res128", scale_by_sigma=False, num_scales=1000, ema_rate=0.9999,
                    normalization="GroupNorm", nonlinearity="swish", nf=128, ch_mult=(1, 1, 2, 4, 4, 4), num_res_blocks_first=2,
                    num_res_blocks=2, attn_resolutions=(16,), resamp_with_conv=True, conditional=True,
-                   dropout=0.1)
+                   dropout=0.1, hip_precision="f16f6")
     c.optim.lr = 2e-5
     c.eval.batch_size = 7
     c.eval.eval_dir = "PLACEHOLDER"

@@ -143,13 +143,14 @@ __global__ __launch_bounds__(256) void md_wino_pack_weights_kernel(const float* 
 // f16f8 weights: max |w| of the tensor (the pre-scale 2^sw is derived from it on the device: no host round trip), then the
 // fragments; header behind the fragments: {max |w| (float bits), sw (int), 2^-sw (float), 0}
 __global__ __launch_bounds__(256) void md_wino_amax_kernel(const float* __restrict__ w, int cout, int cin, int64_t s_row, int64_t s_k,
-                                                           uint32_t* __restrict__ hdr) {
+                                                           uint32_t* __restrict__ hdr, const float* __restrict__ eq) {
   const int64_t n = (int64_t)cout * cin * 27;
   float m = 0.f;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     const int t = (int)(i % 27);
     const int64_t r = i / 27;
-    const float v = fabsf(w[(r / cin) * s_row + (r % cin) * s_k + t]);
+    float v = fabsf(w[(r / cin) * s_row + (r % cin) * s_k + t]);
+    if (eq) v /= eq[r % cin];                // the equalised weights are what gets packed (md_wino_equaliser; powers of two: exact)
     m = v > m ? v : m;                       // NaN never wins: a non-finite weight tensor packs with sw = 0
   }
   m = md_wave_max(m);
@@ -157,7 +158,8 @@ __global__ __launch_bounds__(256) void md_wino_amax_kernel(const float* __restri
 }
 
 __global__ __launch_bounds__(256) void md_wino_pack_weights_f8_kernel(const float* __restrict__ w, uint4* __restrict__ wpk, int cout, int cin,
-                                                                      int64_t s_row, int64_t s_k, uint32_t* __restrict__ hdr) {
+                                                                      int64_t s_row, int64_t s_k, uint32_t* __restrict__ hdr,
+                                                                      const float* __restrict__ eq) {
   const int64_t n = (int64_t)cout * cin * 9;             // 16-byte items: cout * cin * 36 values * 4 B / 16
   const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const float wscale = md_wino_f8_wscale(__uint_as_float(hdr[0]));
@@ -167,11 +169,12 @@ __global__ __launch_bounds__(256) void md_wino_pack_weights_f8_kernel(const floa
     hdr[3] = 0u;
   }
   if (id >= n) return;
-  wpk[id] = md_pack_wino_f8_item(w, cout, cin, s_row, s_k, wscale, id);
+  wpk[id] = md_pack_wino_f8_item(w, cout, cin, s_row, s_k, wscale, id, eq);
 }
 
 __global__ __launch_bounds__(256) void md_wino_pack_weights_f6_kernel(const float* __restrict__ w, uint4* __restrict__ wpk, int cout, int cin,
-                                                                      int64_t s_row, int64_t s_k, uint32_t* __restrict__ hdr) {
+                                                                      int64_t s_row, int64_t s_k, uint32_t* __restrict__ hdr,
+                                                                      const float* __restrict__ eq) {
   const int64_t n = (int64_t)cout * cin * 9;
   const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const float wscale = md_wino_f8_wscale(__uint_as_float(hdr[0]));
@@ -181,7 +184,7 @@ __global__ __launch_bounds__(256) void md_wino_pack_weights_f6_kernel(const floa
     hdr[3] = 6u;                                          // the cross-term format of this buffer (md_conv3_wino_f6 checks nothing: host-side type)
   }
   if (id >= n) return;
-  wpk[id] = md_pack_wino_f6_item(w, cout, cin, s_row, s_k, wscale, id);
+  wpk[id] = md_pack_wino_f6_item(w, cout, cin, s_row, s_k, wscale, id, eq);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -880,7 +883,8 @@ extern "C" int64_t md_wino_weight_bytes_f8(int32_t cout, int32_t cin) {
   return (int64_t)cout * cin * 36 * 4 + 256;             // fragments + header
 }
 
-static int md_wino_pack_weights_f8_launch(bool f6, const float* w, void* wpk, int32_t cout, int32_t cin, int64_t s_row, int64_t s_k, void* stream) {
+static int md_wino_pack_weights_f8_launch(bool f6, const float* w, const float* eq, void* wpk, int32_t cout, int32_t cin, int64_t s_row, int64_t s_k,
+                                          void* stream) {
   if (!w || !wpk || cout <= 0 || cin <= 0 || (cout % 128) || (cin % 32)) return MD_ERR_BAD_ARG;
   const int64_t n = (int64_t)cout * cin * 9;
   uint32_t* hdr = (uint32_t*)((unsigned char*)wpk + n * 16);
@@ -890,24 +894,24 @@ static int md_wino_pack_weights_f8_launch(bool f6, const float* w, void* wpk, in
   const int64_t nel = (int64_t)cout * cin * 27;
   int ab = (int)((nel + 255) / 256);
   if (ab > 1024) ab = 1024;
-  hipLaunchKernelGGL(md_wino_amax_kernel, dim3((unsigned)ab), dim3(256), 0, (hipStream_t)stream, w, cout, cin, s_row, s_k, hdr);
+  hipLaunchKernelGGL(md_wino_amax_kernel, dim3((unsigned)ab), dim3(256), 0, (hipStream_t)stream, w, cout, cin, s_row, s_k, hdr, eq);
   MD_HIP_CHECK_LAUNCH();
   if (f6)
     hipLaunchKernelGGL(md_wino_pack_weights_f6_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, (uint4*)wpk,
-                       cout, cin, s_row, s_k, hdr);
+                       cout, cin, s_row, s_k, hdr, eq);
   else
     hipLaunchKernelGGL(md_wino_pack_weights_f8_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, (uint4*)wpk,
-                       cout, cin, s_row, s_k, hdr);
+                       cout, cin, s_row, s_k, hdr, eq);
   MD_HIP_CHECK_LAUNCH();
   return MD_OK;
 }
 
-extern "C" int md_wino_pack_weights_f8(const float* w, void* wpk, int32_t cout, int32_t cin, int64_t s_row, int64_t s_k, void* stream) {
-  return md_wino_pack_weights_f8_launch(false, w, wpk, cout, cin, s_row, s_k, stream);
+extern "C" int md_wino_pack_weights_f8(const float* w, const float* eq, void* wpk, int32_t cout, int32_t cin, int64_t s_row, int64_t s_k, void* stream) {
+  return md_wino_pack_weights_f8_launch(false, w, eq, wpk, cout, cin, s_row, s_k, stream);
 }
 
-extern "C" int md_wino_pack_weights_f6(const float* w, void* wpk, int32_t cout, int32_t cin, int64_t s_row, int64_t s_k, void* stream) {
-  return md_wino_pack_weights_f8_launch(true, w, wpk, cout, cin, s_row, s_k, stream);
+extern "C" int md_wino_pack_weights_f6(const float* w, const float* eq, void* wpk, int32_t cout, int32_t cin, int64_t s_row, int64_t s_k, void* stream) {
+  return md_wino_pack_weights_f8_launch(true, w, eq, wpk, cout, cin, s_row, s_k, stream);
 }
 
 static int md_conv3_wino_f8_launch(bool f6, const void* t_in, const void* wpk, float* out, const float* bias, int64_t bias_bstride,

@@ -82,8 +82,9 @@ __device__ __forceinline__ float md_wino_f8_wscale(float amax) {       // 2^sw; 
   sw = sw < -100 ? -100 : (sw > 100 ? 100 : sw);
   return ldexpf(1.f, sw);
 }
+// eq (may be null): the per-input-channel equaliser of md_wino_equaliser; the fragments hold G' / eq[ci] (eq is a power of two: exact).
 __device__ __forceinline__ uint4 md_pack_wino_f8_item(const float* __restrict__ w, int cout, int cin, int64_t s_row, int64_t s_k, float wscale,
-                                                      int64_t id) {
+                                                      int64_t id, const float* __restrict__ eq = nullptr) {
   int64_t r = id;
   const int lane = (int)(r % 64); r /= 64;
   const int piece = (int)(r % 4); r /= 4;
@@ -103,7 +104,7 @@ __device__ __forceinline__ uint4 md_pack_wino_f8_item(const float* __restrict__ 
     const float* g = w + (int64_t)co * s_row + (int64_t)(ci0 + e) * s_k + tap * 3;
     const float g0 = g[0], g1 = g[1], g2 = g[2];
     const float G = f == 0 ? g0 : f == 1 ? (g0 + g1 + g2) * 0.5f : f == 2 ? (g0 - g1 + g2) * 0.5f : g2;
-    g8[e] = G * wscale;
+    g8[e] = G * (eq ? wscale / eq[ci0 + e] : wscale);
   }
   uint4 hi;
   uint32_t q[2], ql[2];
@@ -116,9 +117,9 @@ __device__ __forceinline__ uint4 md_pack_wino_f8_item(const float* __restrict__ 
 // the two halves of the lane's 32-byte MX record: lane (row, h) belongs to step 2p + h and its K block is the 16 input channels of
 // that step's chunk: [e2m3 codes of (lo(G') 2^11, G') x 16, interleaved | E8M0 byte of the block, 2^-11 folded in | 0].
 __device__ __forceinline__ uint4 md_pack_wino_f6_item(const float* __restrict__ w, int cout, int cin, int64_t s_row, int64_t s_k, float wscale,
-                                                      int64_t id) {
+                                                      int64_t id, const float* __restrict__ eq = nullptr) {
   const int piece = (int)((id / 64) % 4);
-  if (piece < 2) return md_pack_wino_f8_item(w, cout, cin, s_row, s_k, wscale, id);      // the fp16 fragments are the same
+  if (piece < 2) return md_pack_wino_f8_item(w, cout, cin, s_row, s_k, wscale, id, eq);      // the fp16 fragments are the same
   int64_t r = id;
   const int lane = (int)(r % 64); r /= 64;
   r /= 4;
@@ -137,7 +138,7 @@ __device__ __forceinline__ uint4 md_pack_wino_f6_item(const float* __restrict__ 
     const float* g = w + (int64_t)co * s_row + (int64_t)(chunk * 16 + e) * s_k + tap * 3;
     const float g0 = g[0], g1 = g[1], g2 = g[2];
     const float G = f == 0 ? g0 : f == 1 ? (g0 + g1 + g2) * 0.5f : f == 2 ? (g0 - g1 + g2) * 0.5f : g2;
-    g16[e] = G * wscale;
+    g16[e] = G * (eq ? wscale / eq[chunk * 16 + e] : wscale);
   }
   uint4 h0, h1, r0, r1;
   md_split_f16f6(g16, true, -11, h0, h1, r0, r1);

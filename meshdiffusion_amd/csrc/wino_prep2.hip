@@ -20,12 +20,15 @@ constexpr int P2_STRIDE = 12;             // floats per position in LDS (8 + pad
 //   the Winograd weight gradient (csrc/wgrad_wino.hip) when the tensor is an output gradient.
 // F8 (md_wino_prep_f8): T in the "f16f8" operand format of md_conv3_wino_f8 -- same geometry, plane 0 = 8 fp16 (hi), plane 1 =
 //   [e4m3(t) x 8 | e4m3((t - hi) 2^11) x 8] (md_split_f16f8) instead of the bf16 hi / lo planes.
+// eq (F8 / f6 only, may be null): the static per-input-channel power-of-two equaliser s_c of md_wino_equaliser, [c1 + c2] floats; the
+//   activated value is multiplied by it (exact) and the packed weights carry 1 / s_c, so that the channels of a 16-channel K block
+//   reach the 4-bit-significand cross-term images with comparable magnitudes whatever the GroupNorm gammas in front are.
 template <bool DUAL, bool F8 = false>
 __global__ __launch_bounds__(256) void md_wino_prep2_kernel(const float* __restrict__ x1, const float* __restrict__ x2,
                                                             int c1, int c2, const float* __restrict__ ac, int silu, int ups,
                                                             uint4* __restrict__ T, uint4* __restrict__ U, float* __restrict__ sums,
                                                             int batch, int D, int H, int W, uint32_t thr16, float drop_scale,
-                                                            uint64_t seed) {
+                                                            uint64_t seed, const float* __restrict__ eq) {
   __shared__ __attribute__((aligned(16))) float act[P2_POS * P2_STRIDE];
   __shared__ float wsum[32];                       // DUAL with sums: [wave][channel]
   float psum[8];                                   // this thread's (activated) values, for the channel sums
@@ -76,6 +79,14 @@ __global__ __launch_bounds__(256) void md_wino_prep2_kernel(const float* __restr
       }
       if (thr16) t = md_drop_keep(bits[e >> 2], e & 3, thr16) ? t * drop_scale : 0.f;
       yv[e] = t;
+    }
+    if constexpr (F8) {
+      if (eq != nullptr) {
+        const f32x4* ep = (const f32x4*)(eq + cg * 8);
+        const f32x4 e0 = ep[0], e1 = ep[1];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) yv[e] *= e < 4 ? e0[e] : e1[e - 4];
+      }
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) psum[e] = yv[e];
@@ -177,7 +188,7 @@ __global__ __launch_bounds__(256) void md_wino_prep2_kernel(const float* __restr
 // owns a (pair, frequency half) with all 16 channels.
 __global__ __launch_bounds__(256) void md_wino_prep2_f6_kernel(const float* __restrict__ x1, const float* __restrict__ x2, int c1, int c2,
                                                                const float* __restrict__ ac, int silu, int ups, uint4* __restrict__ T, int batch,
-                                                               int D, int H, int W) {
+                                                               int D, int H, int W, const float* __restrict__ eq) {
   __shared__ __attribute__((aligned(16))) float act[2 * P2_POS * P2_STRIDE];
   const int tid = threadIdx.x;
   const int Wp = W >> 1;
@@ -222,6 +233,12 @@ __global__ __launch_bounds__(256) void md_wino_prep2_f6_kernel(const float* __re
           if (silu) t = t * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t * -1.4426950408889634f));
         }
         yv[e] = t;
+      }
+      if (eq != nullptr) {
+        const f32x4* ep = (const f32x4*)(eq + cg * 8);
+        const f32x4 e0 = ep[0], e1 = ep[1];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) yv[e] *= e < 4 ? e0[e] : e1[e - 4];
       }
       float* dst = act + (g2 * P2_POS + tid) * P2_STRIDE;
       *(f32x4*)dst = f32x4{yv[0], yv[1], yv[2], yv[3]};
@@ -273,7 +290,7 @@ __global__ __launch_bounds__(256) void md_wino_prep2_f6_kernel(const float* __re
 
 static int md_wino_prep2_launch(const float* x1, const float* x2, int32_t c1, int32_t c2, const float* ac, int32_t silu,
                                 int32_t ups, void* t_out, void* u_out, float* sums, int32_t batch, int32_t D, int32_t H, int32_t W, float drop_p,
-                                uint64_t drop_seed, void* stream, bool f8 = false) {
+                                uint64_t drop_seed, void* stream, bool f8 = false, const float* eq = nullptr) {
   if (!x1 || !t_out || batch <= 0 || c1 <= 0 || c2 < 0 || (c1 & 7) || (c2 & 7) || (c2 > 0 && !x2)) return MD_ERR_BAD_ARG;
   if (silu && !ac) return MD_ERR_BAD_ARG;      // SiLU is applied together with the folded GroupNorm affine only
   if (D <= 0 || H <= 0 || W <= 0 || (W & 1) || (ups && ((D | H | W) & 1))) return MD_ERR_BAD_ARG;
@@ -286,15 +303,15 @@ static int md_wino_prep2_launch(const float* x1, const float* x2, int32_t c1, in
   if (f8)
     hipLaunchKernelGGL((md_wino_prep2_kernel<false, true>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x1, x2, c1, c2, ac,
                        silu, ups, (uint4*)t_out, (uint4*)nullptr, (float*)nullptr, batch, D, H, W, md_drop_thr16(drop_p),
-                       1.0f / (1.0f - drop_p), drop_seed);
+                       1.0f / (1.0f - drop_p), drop_seed, eq);
   else if (u_out)
     hipLaunchKernelGGL((md_wino_prep2_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x1, x2, c1, c2, ac,
                        silu, ups, (uint4*)t_out, (uint4*)u_out, sums, batch, D, H, W, md_drop_thr16(drop_p), 1.0f / (1.0f - drop_p),
-                       drop_seed);
+                       drop_seed, (const float*)nullptr);
   else
     hipLaunchKernelGGL((md_wino_prep2_kernel<false>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x1, x2, c1, c2, ac,
                        silu, ups, (uint4*)t_out, (uint4*)nullptr, (float*)nullptr, batch, D, H, W, md_drop_thr16(drop_p),
-                       1.0f / (1.0f - drop_p), drop_seed);
+                       1.0f / (1.0f - drop_p), drop_seed, (const float*)nullptr);
   MD_HIP_CHECK_LAUNCH();
   return MD_OK;
 }
@@ -314,12 +331,12 @@ extern "C" int md_wino_prep_dual(const float* x1, const float* x2, int32_t c1, i
 
 
 extern "C" int md_wino_prep_f8(const float* x1, const float* x2, int32_t c1, int32_t c2, const float* ac, int32_t silu,
-                               int32_t ups, void* t_out, int32_t batch, int32_t D, int32_t H, int32_t W, void* stream) {
-  return md_wino_prep2_launch(x1, x2, c1, c2, ac, silu, ups, t_out, nullptr, nullptr, batch, D, H, W, 0.f, 0, stream, true);
+                               int32_t ups, const float* eq, void* t_out, int32_t batch, int32_t D, int32_t H, int32_t W, void* stream) {
+  return md_wino_prep2_launch(x1, x2, c1, c2, ac, silu, ups, t_out, nullptr, nullptr, batch, D, H, W, 0.f, 0, stream, true, eq);
 }
 
 extern "C" int md_wino_prep_f6(const float* x1, const float* x2, int32_t c1, int32_t c2, const float* ac, int32_t silu,
-                               int32_t ups, void* t_out, int32_t batch, int32_t D, int32_t H, int32_t W, void* stream) {
+                               int32_t ups, const float* eq, void* t_out, int32_t batch, int32_t D, int32_t H, int32_t W, void* stream) {
   if (!x1 || !t_out || batch <= 0 || c1 <= 0 || c2 < 0 || (c1 & 15) || (c2 & 15) || (c2 > 0 && !x2)) return MD_ERR_BAD_ARG;   // whole 16-channel blocks per part
   if (silu && !ac) return MD_ERR_BAD_ARG;
   if (D <= 0 || H <= 0 || W <= 0 || (W & 1) || (ups && ((D | H | W) & 1))) return MD_ERR_BAD_ARG;
@@ -329,7 +346,7 @@ extern "C" int md_wino_prep_f6(const float* x1, const float* x2, int32_t c1, int
   if (blocks > 0x7fffffff) return MD_ERR_UNSUPPORTED;
   MD_HIP_CLEAR_ERROR();
   hipLaunchKernelGGL(md_wino_prep2_f6_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x1, x2, c1, c2, ac, silu, ups,
-                     (uint4*)t_out, batch, D, H, W);
+                     (uint4*)t_out, batch, D, H, W, eq);
   MD_HIP_CHECK_LAUNCH();
   return MD_OK;
 }

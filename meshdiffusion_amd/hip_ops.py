@@ -21,29 +21,72 @@ CFG_FAST_EC = 122   # A/B variant of the dedicated kernel (valid results): early
 # shader cycles over which the dedicated conv kernel spreads the start of each CU's first workgroup (0 = off)
 CONV_STAGGER = int(os.environ.get("MD_CONV_STAGGER", "0"))
 DEBUG_ACT_FP16 = 2 if os.environ.get("MD_DEBUG_ACT_FP16") == "1" else 0   # precision experiment only
-# Arithmetic of the dedicated 3x3x3 conv kernel: "bf16x3" (default; ~1e-5 per U-Net evaluation) or "fp16x2"
-# (weights split fp16, activations one fp16; ~1e-3 per evaluation, 7e-5 after the 999-step sampler).
-PRECISION = os.environ.get("MD_PRECISION", "bf16x3")
-# "f16f8": bf16x3 everywhere except the INFERENCE Winograd convs (md_wino_prep_f8 + md_conv3_wino_f8): a product there is
-# fp16(a) fp16(b) + [e4m3(a) e4m3(b_lo 2^11) + e4m3(a_lo 2^11) e4m3(b)] 2^-11 -- one fp16 MFMA + half a K-concatenated scaled fp8
-# MFMA = 2 matrix-core units per product instead of 3 (1.3e-5 per conv against bf16x3's 5.5e-6: tools/f16f8_numerics.py).
-# Training keeps bf16x3 (the backward reads the forward's bf16 T, and gradients need bf16's exponent range).
-# "f16f6": as f16f8, the cross terms from MX block-scaled e2m3 images (md_wino_prep_f6 + md_conv3_wino_f6): the K = 64 MFMA runs them
-# at twice its e4m3 rate (1.7e-5 per conv).
-WINO_F8 = False          # False | "f8" | "f6": cross-term format of the inference Winograd convs
-if PRECISION in ("f16f8", "f16f6"):
-    PRECISION, WINO_F8 = "bf16x3", PRECISION[3:]
+# Arithmetic of the 3x3x3 conv kernels:
+#   "bf16x3"  three bf16 MFMAs per product, fp32 range: ~1.7e-5 per U-Net evaluation.  Training always runs in it.
+#   "f16f8"   bf16x3 everywhere except the INFERENCE Winograd convs behind a GroupNorm (md_wino_prep_f8 + md_conv3_wino_f8): a product
+#             there is fp16(a) fp16(b) + [e4m3(a) e4m3(b_lo 2^11) + e4m3(a_lo 2^11) e4m3(b)] 2^-11 -- one fp16 MFMA + half a
+#             K-concatenated scaled fp8 MFMA = 2 matrix-core units per product instead of 3 (1.3e-5 per conv against 5.5e-6).
+#   "f16f6"   as f16f8, the cross terms from MX block-scaled e2m3 images (md_wino_prep_f6 + md_conv3_wino_f6): the K = 64 MFMA runs
+#             them at twice its e4m3 rate (1.8e-5 per conv).
+#   "fp16x2"  weights split fp16, activations one fp16 in the direct kernels (~1e-3 per evaluation): opt-in experiment.
+# f16f8 / f16f6 apply only where the operand comes out of GroupNorm (+ SiLU): there the static equaliser (md_wino_equaliser, WINO_EQ)
+# flattens the per-channel magnitudes the 4-bit-significand images are sensitive to.  Convs on the raw residual stream (Upsample)
+# keep bf16x3: nothing is known about their operand before the data arrives (F8_RAW=1: the round-4 behaviour, A/B only).
+#
+# The arithmetic is a property of the MODEL CALL, not of the process: DDPMUNet3D.forward / forward_train / backward enter
+# `precision_scope(config.model.hip_precision)` and leave it again, so a model never inherits what another one ran in.  Outside any
+# scope (direct hip_ops calls from tests and tools) DEFAULT_PRECISION applies (MD_PRECISION, or set_precision()).
+_MODES = ("bf16x3", "fp16x2", "f16f8", "f16f6")
+DEFAULT_PRECISION = os.environ.get("MD_PRECISION", "bf16x3")
+FORCE_PRECISION = os.environ.get("MD_FORCE_PRECISION")      # A/B runs of the test suite / CLI: wins over config.model.hip_precision in INFERENCE scopes
+WINO_EQ = os.environ.get("MD_WINO_EQ", "1") == "1"          # A/B: 0 = f16f8 / f16f6 without the static equaliser
+F8_RAW = os.environ.get("MD_F8_RAW", "0") == "1"            # A/B: 1 = f16f8 / f16f6 also on un-normalised operands (round 4)
 
 
-FORCE_PRECISION = os.environ.get("MD_FORCE_PRECISION")      # A/B runs of the test suite / CLI: wins over config.model.hip_precision
+def _decode(mode):
+    if mode not in _MODES:
+        raise ValueError(f"unknown precision mode {mode!r}")
+    return ("bf16x3", mode[3:]) if mode in ("f16f8", "f16f6") else (mode, False)
+
+
+# the CURRENT arithmetic: PRECISION = operand format of the direct kernels, WINO_F8 = False | "f8" | "f6" (cross-term format of the
+# inference Winograd convs).  Written only by set_precision (process default) and precision_scope (a model call).
+PRECISION, WINO_F8 = _decode(DEFAULT_PRECISION)
+_SCOPES = []
 
 
 def set_precision(mode):
-    global PRECISION, WINO_F8
-    mode = FORCE_PRECISION or mode
-    if mode not in ("bf16x3", "fp16x2", "f16f8", "f16f6"):
-        raise ValueError(f"unknown precision mode {mode!r}")
-    PRECISION, WINO_F8 = ("bf16x3", mode[3:]) if mode in ("f16f8", "f16f6") else (mode, False)
+    """Process default: the arithmetic of hip_ops calls made OUTSIDE a model's forward (tests, tools).  Models state their own
+    (config.model.hip_precision) and are not affected."""
+    global DEFAULT_PRECISION, PRECISION, WINO_F8
+    _decode(mode)
+    DEFAULT_PRECISION = mode
+    if not _SCOPES:
+        PRECISION, WINO_F8 = _decode(mode)
+
+
+class precision_scope:
+    """with precision_scope(mode): the arithmetic of one model call.  mode None = the process default.  training=True: the scope of
+    a training forward / backward -- always bf16x3 (the backward reads the forward's bf16 T, gradients need bf16's exponent range),
+    MD_FORCE_PRECISION does not apply."""
+
+    def __init__(self, mode, training=False):
+        if training:
+            mode = "bf16x3"
+        else:
+            mode = FORCE_PRECISION or mode or DEFAULT_PRECISION
+        self.state = _decode(mode)
+
+    def __enter__(self):
+        global PRECISION, WINO_F8
+        _SCOPES.append((PRECISION, WINO_F8))
+        PRECISION, WINO_F8 = self.state
+        return self
+
+    def __exit__(self, *exc):
+        global PRECISION, WINO_F8
+        PRECISION, WINO_F8 = _SCOPES.pop()
+        return False
 
 
 def precision_name():
@@ -410,18 +453,37 @@ class WinoWeightF8:
     """Conv3d weight [Co][Ci][3][3][3] -> the "f16f8" fragments of md_conv3_wino_f8 (md_wino_pack_weights_f8: fp16 hi fragments +
     K-concatenated e4m3 fragments of the power-of-two pre-scaled G-transformed weights, header with the scale).  Inference only."""
 
-    def __init__(self, w, device, fmt="f8"):
+    def __init__(self, w, device, fmt="f8", eq=None):
+        """eq: float [Cin] from wino_equaliser() or None; the fragments hold w[:, c] / eq[c] and the operand pass of every launch
+        with this object must be given the same vector (conv3_wino checks it)."""
         lib = _lib.load()
         w = w.detach().to(device=device, dtype=torch.float32).contiguous()
         _require_cuda(w, "weight")
         assert w.dim() == 5 and tuple(w.shape[2:]) == (3, 3, 3) and fmt in ("f8", "f6")
         self.rows, self.kdim, self.fmt = w.shape[0], w.shape[1], fmt      # fmt "f6": md_wino_pack_weights_f6 (MX e2m3 cross terms)
+        assert eq is None or (eq.is_cuda and eq.dtype == torch.float32 and eq.numel() == self.kdim and eq.is_contiguous())
+        self.eq = eq
         nbytes = lib.md_wino_weight_bytes_f8(self.rows, self.kdim)
         if nbytes <= 0:
             raise _lib.MeshDiffusionHipError("md_wino_weight_bytes_f8: unsupported weight shape")
         self.data = torch.empty(nbytes // 2, dtype=torch.bfloat16, device=device)
         pack = lib.md_wino_pack_weights_f6 if fmt == "f6" else lib.md_wino_pack_weights_f8
-        check(pack(_ptr(w), _ptr(self.data), self.rows, self.kdim, self.kdim * 27, 27, _stream()), "md_wino_pack_weights_" + fmt)
+        check(pack(_ptr(w), _ptr(eq), _ptr(self.data), self.rows, self.kdim, self.kdim * 27, 27, _stream()), "md_wino_pack_weights_" + fmt)
+
+
+def wino_equaliser(gamma, beta, w):
+    """float [Cin] on the device: the static per-input-channel power-of-two equaliser of a GroupNorm(gamma, beta) -> SiLU -> Conv3d(w)
+    pair for the f16f8 / f16f6 arithmetic (md_wino_equaliser, csrc/wino_eq.hip)."""
+    lib = _lib.load()
+    w = w.detach().to(dtype=torch.float32).contiguous()
+    _require_cuda(w, "weight")
+    cout, cin = w.shape[0], w.shape[1]
+    gamma = gamma.detach().to(device=w.device, dtype=torch.float32).contiguous()
+    beta = beta.detach().to(device=w.device, dtype=torch.float32).contiguous()
+    assert w.dim() == 5 and tuple(w.shape[2:]) == (3, 3, 3) and gamma.numel() == cin and beta.numel() == cin
+    eq = torch.empty(cin, dtype=torch.float32, device=w.device)
+    check(lib.md_wino_equaliser(_ptr(gamma), _ptr(beta), _ptr(w), cout, cin, cin * 27, 27, _ptr(eq), _stream()), "md_wino_equaliser")
+    return eq
 
 
 WINO_MIN_WGS = int(os.environ.get("MD_WINO_MIN_WGS", "256"))   # fewest workgroups the Winograd kernel is launched with
@@ -477,26 +539,29 @@ def release_scratch():
     _WINO_SCRATCH.clear()
 
 
-def wino_f8_ok(S, drop=None, keep=False, parts=None):
+def wino_f8_ok(S, drop=None, keep=False, parts=None, normalised=True):
     """The f16f8 / f16f6 arithmetic of the Winograd path: inference launches (no dropout, T not kept for a backward) on grids the
-    two-phase operand pass takes.  Returns False or the cross-term format ("f8" / "f6"; f6 needs whole 16-channel blocks per
-    part and falls back to f8 otherwise)."""
-    if not (WINO_F8 and PRECISION == "bf16x3" and not drop and not keep and 256 % S == 0):
+    two-phase operand pass takes, whose operand comes out of a GroupNorm (`normalised`: the static equaliser applies; the raw
+    residual stream in front of an Upsample conv stays in bf16x3).  Returns False or the cross-term format ("f8" / "f6"; f6 needs
+    whole 16-channel blocks per part and falls back to f8 otherwise)."""
+    if not (WINO_F8 and PRECISION == "bf16x3" and not drop and not keep and 256 % S == 0 and (normalised or F8_RAW)):
         return False
     if WINO_F8 == "f6" and parts is not None and any(c % 16 for _, c in parts):
         return "f8"
     return WINO_F8
 
 
-def wino_prep(parts, ac, silu, ups, B, S, drop=None, keep=False, dual=False, sums=None, f8=False):
+def wino_prep(parts, ac, silu, ups, B, S, drop=None, keep=False, dual=False, sums=None, f8=False, eq=None):
     """fp32 F32B parts (+ folded GroupNorm affine, SiLU, nearest-x2 upsampling) -> transformed split operand T.
     drop = (p, seed): training dropout after SiLU, the mask gn_apply(drop=...) produces for the same pair.
     keep: T goes to its own tensor instead of the shared scratch buffer (training forward: the Winograd weight gradient of the
     backward reads it again).  dual: returns (T, U) -- U = the dY operand of md_wgrad_wino (md_wino_prep_dual); sums (with dual):
-    zeroed float [B, C] receiving the per-(sample, channel) sums of the tensor in the same pass (bias gradients)."""
+    zeroed float [B, C] receiving the per-(sample, channel) sums of the tensor in the same pass (bias gradients).
+    f8: False | "f8" (True) | "f6": the operand format of md_conv3_wino_f8 / _f6; eq (with f8): the layer's equaliser (wino_equaliser)."""
     lib = _lib.load()
     cin = sum(c for _, c in parts)
     assert 1 <= len(parts) <= 2
+    assert eq is None or (f8 and eq.numel() == cin and eq.dtype == torch.float32 and eq.is_cuda), "eq belongs to the f16f8 / f16f6 operand"
     assert ac is not None or not silu, "SiLU is applied together with the folded GroupNorm affine (pass `ac`)"
     nbytes = lib.md_wino_operand_bytes(B, cin, S, S, S)
     if nbytes <= 0:
@@ -510,9 +575,9 @@ def wino_prep(parts, ac, silu, ups, B, S, drop=None, keep=False, dual=False, sum
     if f8:
         assert not (dual or keep or drop), "the f16f8 / f16f6 operand is an inference format"
         if f8 == "f6":
-            check(lib.md_wino_prep_f6(*args, _ptr(t), B, S, S, S, _stream()), "md_wino_prep_f6")
+            check(lib.md_wino_prep_f6(*args, _ptr(eq), _ptr(t), B, S, S, S, _stream()), "md_wino_prep_f6")
         else:
-            check(lib.md_wino_prep_f8(*args, _ptr(t), B, S, S, S, _stream()), "md_wino_prep_f8")
+            check(lib.md_wino_prep_f8(*args, _ptr(eq), _ptr(t), B, S, S, S, _stream()), "md_wino_prep_f8")
     elif dual:
         if 256 % S:
             raise _lib.MeshDiffusionHipError("md_wino_prep_dual needs W | 256")
@@ -523,6 +588,10 @@ def wino_prep(parts, ac, silu, ups, B, S, drop=None, keep=False, dual=False, sum
         check(fn(*args, _ptr(t), *tail), "md_wino_prep")
     _prof_end(ev, "wino_prep", 0.0, 4.0 * B * cin * (S ** 3 // (8 if ups else 1)) + (16.0 if dual else 8.0) * B * cin * S ** 3,   # fp32 in, 2 x bf16 x 2 out
               f"{cin}@{S}x{S}x{S}" + ("/ups" if ups else "") + ("/dual" if dual else "") + (("/f6" if f8 == "f6" else "/f8") if f8 else ""))
+    # what this operand is, for conv3_wino's pairing check (an f8 T under f6 weights, or a T equalised with another layer's vector,
+    # would be silently wrong: the kernel cannot tell)
+    t._md_fmt = ("f6" if f8 == "f6" else "f8") if f8 else False
+    t._md_eq = eq.data_ptr() if eq is not None else 0
     return (t, u) if dual else t
 
 
@@ -561,6 +630,11 @@ def conv3_wino(ww, t, B, S, *, bias=None, bias_bstride=0, residual=None, res_bst
         out = f32b_empty(B, ww.rows, P, t.device)
     ev = _prof_begin()
     f8 = isinstance(ww, WinoWeightF8)        # the weight object fixes the arithmetic; `t` must come from wino_prep(f8=...) accordingly
+    t_fmt = getattr(t, "_md_fmt", None)
+    if t_fmt is not None:                    # an operand that went through wino_prep: format and equaliser must be the weight object's
+        want = ww.fmt if f8 else False
+        if t_fmt != want or getattr(t, "_md_eq", 0) != ((ww.eq.data_ptr() if ww.eq is not None else 0) if f8 else 0):
+            raise _lib.MeshDiffusionHipError(f"conv3_wino: operand format {t_fmt!r} / equaliser does not belong to these weights ({want!r})")
     if f8:
         fn = lib.md_conv3_wino_f6 if ww.fmt == "f6" else lib.md_conv3_wino_f8
         check(fn(_ptr(t), _ptr(ww.data), _ptr(out), _ptr(bias), bias_bstride, _ptr(residual), res_bstride,

@@ -97,7 +97,8 @@ class DDPMUNet3D(layers.HipLayer):
         mods.append(edge_conv(in_ch, channels, init_scale=0.0))
         self.all_modules = nn.ModuleList(mods)
         self.out_channels = channels
-        # arithmetic of the hot conv kernel: "bf16x3" (default) or "fp16x2" 
+        # arithmetic of this model's inference convs: "bf16x3" | "f16f8" | "f16f6" | "fp16x2" (hip_ops); None = the
+        # process default.  It is entered as a scope by every call and left again: a property of the model, not of the process.
         self.hip_precision = m.get("hip_precision", None) if hasattr(m, "get") else None
 
     def _blocks_at(self, lvl):
@@ -151,13 +152,21 @@ class DDPMUNet3D(layers.HipLayer):
         return a
 
     def forward_train(self, x, labels):
-        """Forward pass that records what `backward` needs.  Returns (eps_hat NCDHW, ctx)."""
+        """Forward pass that records what `backward` needs.  Returns (eps_hat NCDHW, ctx).  Always bf16x3 (hip_ops.precision_scope)."""
+        with ops.precision_scope(None, training=True):
+            return self._forward_train(x, labels)
+
+    def backward(self, ctx, d_eps):
+        """Accumulate d(loss)/d(parameter) into `.grad` for every trainable parameter, given d(loss)/d(eps_hat)."""
+        with ops.precision_scope(None, training=True):
+            return self._backward(ctx, d_eps)
+
+    def _forward_train(self, x, labels):
         if self.scale_by_sigma:
             # the inference forward divides by sigma[labels] (ddpm_res64.py:196-198 of the reference); neither registered
             # config enables it, and the HIP backward does not carry the 1/sigma factor
             raise NotImplementedError("training with model.scale_by_sigma=True is not implemented on the HIP path")
         assert tuple(x.shape[1:]) == (self.out_channels, self.img_size, self.img_size, self.img_size)
-        ops.set_precision("bf16x3")
         ops.stats_arena_reset(x.device)
         ops.prewarm_packs()      # every weight changed since the last step: re-pack what that step used in one launch
         mods = self.all_modules
@@ -247,8 +256,7 @@ class DDPMUNet3D(layers.HipLayer):
                    a_final=a, foffs=foffs, ftot=ftot, fw=fw)
         return out, ctx
 
-    def backward(self, ctx, d_eps):
-        """Accumulate d(loss)/d(parameter) into `.grad` for every trainable parameter, given d(loss)/d(eps_hat)."""
+    def _backward(self, ctx, d_eps):
         from . import backward as bw
         from torch.nn import functional as F
         mods = self.all_modules
@@ -425,8 +433,10 @@ class DDPMUNet3D(layers.HipLayer):
             # training: the HIP forward records a tape and the HIP backward accumulates parameter .grad; torch
             # autograd only sees one opaque node (so `loss.backward()` of the reference's step_fn works)
             return _UNetTrainFn.apply(x, labels, self, self._autograd_anchor())
-        if self.hip_precision is not None:
-            ops.set_precision(self.hip_precision)
+        with ops.precision_scope(self.hip_precision):
+            return self._forward_eval(x, labels)
+
+    def _forward_eval(self, x, labels):
         mods = self.all_modules
         B, R = x.shape[0], self.img_size
         P = R ** 3

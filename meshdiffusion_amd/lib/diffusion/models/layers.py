@@ -112,14 +112,27 @@ def conv3_packed(layer, name, conv, cfg):
                          lambda: ops.PackedWeight(conv.weight, "conv", cfg, conv.weight.device, prec))
 
 
-def conv3_wino_packed(layer, name, conv):
+def conv3_wino_packed(layer, name, conv, gn=None):
     """Lazy builder of the Winograd-transformed weight tiles of `conv` (cached like conv3_packed); f8: the fragments of the
-    f16f8 arithmetic (hip_ops.WinoWeightF8, inference)."""
+    f16f8 / f16f6 arithmetic (hip_ops.WinoWeightF8, inference).  gn: the nn.GroupNorm whose output (through SiLU) the conv reads --
+    the f16f8 / f16f6 fragments are then packed with the pair's static equaliser (`build.eq()`: the vector the operand pass of the
+    same launch needs; hip_ops.wino_equaliser), rebuilt whenever the weight or the GroupNorm affine changes."""
+    use_eq = gn is not None and ops.WINO_EQ
+
+    def eq():
+        if not use_eq:
+            return None
+        return layer._cached(f"{name}/wino_eq", [conv.weight, gn.weight, gn.bias],
+                             lambda: ops.wino_equaliser(gn.weight, gn.bias, conv.weight))
+
     def build(f8=False):
         if f8:
             fmt = "f6" if f8 == "f6" else "f8"
-            return layer._cached(f"{name}/wino_{fmt}", [conv.weight], lambda: ops.WinoWeightF8(conv.weight, conv.weight.device, fmt))
+            deps = [conv.weight] + ([gn.weight, gn.bias] if use_eq else [])
+            return layer._cached(f"{name}/wino_{fmt}{'e' if use_eq else ''}", deps,
+                                 lambda: ops.WinoWeightF8(conv.weight, conv.weight.device, fmt, eq=eq()))
         return layer._cached(f"{name}/wino", [conv.weight], lambda: ops.WinoWeight(conv.weight, conv.weight.device))
+    build.eq = eq
     return build
 
 
@@ -154,9 +167,12 @@ def run_conv3(pw, act_s16, B, S_out, *, bias=None, bias_bstride=0, residual=None
     if (b_f32 is not None and wino is not None and out_mode == ops.OUT_F32B and rows_alloc == pw.rows
             and pw.prec == ops.PREC_BF16X3 and ops.wino_ok(pw.rows, pw.kdim, S_out, B)):
         stats = ops.stats_zeros(B, rows_alloc, dev) if want_stats and ops.FUSE_GN_STATS else None
-        f8 = (not b_f32.get("wino_only")) and ops.wino_f8_ok(S_out, drop=b_f32.get("drop"), keep=bool(b_f32.get("keep")), parts=b_f32["parts"])
+        # f16f8 / f16f6: inference operands that come out of a GroupNorm (the layer's static equaliser flattens their channels);
+        # the raw residual stream (Upsample: ac None) stays in bf16x3
+        f8 = (not b_f32.get("wino_only")) and ops.wino_f8_ok(S_out, drop=b_f32.get("drop"), keep=bool(b_f32.get("keep")), parts=b_f32["parts"],
+                                                             normalised=b_f32.get("ac") is not None)
         t = ops.wino_prep(b_f32["parts"], b_f32.get("ac"), b_f32.get("silu"), ups, B, S_out, drop=b_f32.get("drop"),
-                          keep=bool(b_f32.get("keep")), f8=f8)
+                          keep=bool(b_f32.get("keep")), f8=f8, eq=wino.eq() if f8 and hasattr(wino, "eq") else None)
         if b_f32.get("keep"):
             b_f32["t_out"] = t           # training: the Winograd weight gradient reads the operand again (tape)
         ops.conv3_wino(wino(f8) if f8 else wino(), t, B, S_out, bias=bias, bias_bstride=bias_bstride, residual=residual,
@@ -427,7 +443,7 @@ class ResnetBlockDDPM(HipLayer):
                 else:
                     bias0, bias0_stride = self.Conv_0.bias, 0
             h = run_conv3(pw0, None, B, S, bias=bias0, bias_bstride=bias0_stride, want_stats=True,
-                          b_f32=dict(parts=parts, ac=ac0, silu=True), wino=conv3_wino_packed(self, "w0", self.Conv_0))
+                          b_f32=dict(parts=parts, ac=ac0, silu=True), wino=conv3_wino_packed(self, "w0", self.Conv_0, gn=g0))
             if need_nin:
                 pwn = self.NIN_0.packed(P, hbm_bound=True)
                 if pwn.kdim == cin and ops.nin_stream_ok(parts, self.out_ch, P):   # weights resident in LDS, input streamed once
@@ -441,7 +457,7 @@ class ResnetBlockDDPM(HipLayer):
                 res = parts[0][0]
             _, ac1 = ops.gn_params([(h, self.out_ch)], g1.weight, g1.bias, B, P, eps=g1.eps, groups=g1.num_groups, want_ac=True)
             return run_conv3(pw1, None, B, S, bias=self.Conv_1.bias, residual=res, want_stats=True,
-                             b_f32=dict(parts=[(h, self.out_ch)], ac=ac1, silu=True), wino=conv3_wino_packed(self, "w1", self.Conv_1))
+                             b_f32=dict(parts=[(h, self.out_ch)], ac=ac1, silu=True), wino=conv3_wino_packed(self, "w1", self.Conv_1, gn=g1))
         # training (tape): the convs go through the Winograd path where it applies (its operand pass repeats GroupNorm + SiLU
         # + dropout from the fp32 tensors); the S16B activations are still written: the weight gradients read them
         wino_fwd = tape is not None and not f16 and ops.WINO_TRAIN_FWD

@@ -76,6 +76,47 @@ def sensitised_state_dict(template, seed=1234, grid_mask=None):
     return out
 
 
+def trained_like_state_dict(template, seed=4321, grid_mask=None, span=3.0, df=3.0):
+    """A second, ADVERSARIAL sensitisation: what a trained checkpoint can look like and i.i.d. weights never do.
+      * conv / NIN / Linear weights are heavy-tailed: Student-t(df) instead of uniform, same variance (outlier weights inside every
+        16-channel block of a row);
+      * every GroupNorm that feeds a convolution or the attention projections gets a per-channel scale s_c = 2^U(-span, span)
+        on its affine (gamma_c, beta_c) *= s_c, compensated in the consumer: W[:, c] /= s_c -- the channels of a block differ by
+        up to 2^(2 span) in magnitude while every channel keeps mattering equally (the case MX block scaling is weakest in).
+    Same keys / shapes / determinism as sensitised_state_dict (trained checkpoints are external downloads: reference README.md:35-37)."""
+    out = sensitised_state_dict(template, seed=seed, grid_mask=grid_mask)
+    for key, v in list(out.items()):
+        if v.dim() >= 2 and not key.endswith(("coords", "mask")):
+            shape, g = tuple(v.shape), _gen(seed + 1, key)
+            recept = float(np.prod(shape)) / shape[0] / shape[1]
+            std = float(np.sqrt(1.0 / ((shape[0] + shape[1]) * recept / 2.0)))
+            z = torch.randn(shape, generator=g)
+            chi = torch.randn((int(df),) + shape, generator=g).pow(2).sum(0) / float(df)
+            out[key] = z / chi.sqrt() * (std / float(np.sqrt(df / (df - 2.0))))
+    n_mod = 1 + max(int(k.split(".")[1]) for k in out if k.startswith("all_modules."))
+
+    def rescale(gn_prefix, consumers):
+        gw, gb = gn_prefix + "weight", gn_prefix + "bias"
+        s = torch.exp2((torch.rand(out[gw].shape, generator=_gen(seed + 2, gw)) * 2.0 - 1.0) * span)
+        out[gw] = out[gw] * s
+        out[gb] = out[gb] * s
+        for ck, axis in consumers:
+            w = out[ck]
+            out[ck] = w / s.view([-1 if a == axis else 1 for a in range(w.dim())])
+
+    for i in range(n_mod):
+        p = f"all_modules.{i}."
+        for j in (0, 1):
+            if p + f"GroupNorm_{j}.weight" in out and p + f"Conv_{j}.weight" in out:
+                rescale(p + f"GroupNorm_{j}.", [(p + f"Conv_{j}.weight", 1)])
+        if p + "GroupNorm_0.weight" in out and p + "NIN_2.W" in out and p + "Conv_0.weight" not in out:      # AttnBlock: q, k, v
+            rescale(p + "GroupNorm_0.", [(p + f"NIN_{j}.W", 0) for j in (0, 1, 2)])
+    fin, head = f"all_modules.{n_mod - 2}.", f"all_modules.{n_mod - 1}.weight"
+    if out[fin + "weight"].dim() == 1 and out[head].dim() == 5:
+        rescale(fin, [(head, 1)])
+    return out
+
+
 def synthetic_grid_mask(R, seed=7):
     """Binary [R,R,R] mask with ~11.6% live cells on a period-4 lattice (the
     res128 asset is missing upstream, and tests must not depend on the reference tree)."""

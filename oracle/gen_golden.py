@@ -8,6 +8,7 @@ What is recorded (all inputs are regenerated from seeds by meshdiffusion_amd.syn
 outputs are stored):
   unet_small.npz     reference DDPMRes64 (small config) eps_hat, full tensor
   unet_res64.npz     reference DDPMRes64 (res64, B=1) eps_hat: ::4 subsample + statistics
+  unet_res64_trained.npz  the same on the adversarial "trained-like" weights (--only trained): B = 2, two timesteps
   sampler_small.npz  unmodified reference pc_sampler, first K iterations, uncond + inpainting
   ddim.npz           reference discretize_ddim on seeded inputs, the quad schedule, the whole DDIM sampler (small config)
   sampler_res64.npz  BASELINE config #1: res64, B=1, first 10 of 1000 ancestral steps (live cells + statistics)
@@ -189,6 +190,33 @@ def gen_unet_and_sampler(skip_res64):
         np.savez_compressed(os.path.join(GOLD, "sampler_res64.npz"), xm_norm=float(xm.double().norm()),
                             xm_row=xm[0, :, 33, 17, :].numpy(), K=10, seed=42,
                             **sample_stats(xm, synth.synthetic_grid_mask(R), 4))
+
+
+def gen_trained_like():
+    """unet_res64_trained.npz: the unmodified reference DDPMRes64 (res64, B = 1, t = 500.3 and a late step t = 37.8) on the ADVERSARIAL
+    sensitisation synth.trained_like_state_dict (Student-t weights, GroupNorm gammas 2^U(-3, 3) compensated in the consuming conv /
+    NIN): the gate under the reduced-precision conv arithmetics of the HIP path.  A 25-step B = 8 sampler run on
+    these weights is checked against the oracle on the GPU (tests/test_gpu_graded.py); the oracle is pinned here."""
+    rsampling, rsde, rmutils = import_reference()
+    from meshdiffusion_amd.config import get_config_res64
+    from meshdiffusion_amd.lib.diffusion.models import ddpm_res64, utils as mutils  # noqa: F401
+    with torch.no_grad():
+        cfg = get_config_res64(); cfg.device = torch.device("cpu")
+        R = 64
+        tmpl = mutils.create_model(ConfigDict(cfg), use_parallel=False).state_dict()
+        sd = synth.trained_like_state_dict(tmpl, seed=4321, grid_mask=synth.synthetic_grid_mask(R))
+        del tmpl
+        model = ref_model(rmutils, cfg, sd)
+        x = synth.synthetic_inputs(2, 4, R, seed=52)
+        labels = torch.tensor([500.3, 37.8])
+        t0 = time.time(); y_ref = model(x, labels); t_ref = time.time() - t0
+        y_or = unet_oracle.unet_res64_forward(sd, synth.oracle_cfg(cfg), x, labels)
+        e = rel_l2(y_or, y_ref)
+        print(f"[res64 trained-like] oracle vs reference rel-L2 = {e:.3e}; ref {t_ref:.1f}s; std {float(y_ref.std()):.3f}", flush=True)
+        assert e < 1e-5
+        np.savez_compressed(os.path.join(GOLD, "unet_res64_trained.npz"), y_sub=y_ref[:, :, ::4, ::4, ::4].numpy(),
+                            y_norm=y_ref.double().flatten(1).norm(dim=1).numpy(), y_sum=y_ref.double().sum(dim=(2, 3, 4)).numpy(),
+                            y_row=y_ref[:, :, 31, 17, :].numpy(), labels=labels.numpy(), x_seed=52, sd_seed=4321)
 
 
 def live_cells(mask, stride):
@@ -575,7 +603,7 @@ def gen_dataset():
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-res64", action="store_true")
-    ap.add_argument("--only", choices=["unet", "dmtet", "dataset", "train", "train_b2", "graded", "ddim"], default=None)
+    ap.add_argument("--only", choices=["unet", "dmtet", "dataset", "train", "train_b2", "graded", "ddim", "trained"], default=None)
     ap.add_argument("--graded", default="config1,cond32,res128", help="which graded-size sampler fixtures to (re)generate")
     a = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
@@ -592,6 +620,8 @@ if __name__ == "__main__":
         gen_unet_and_sampler(a.skip_res64)
     if a.only in (None, "ddim"):
         gen_ddim()
+    if a.only == "trained" or (a.only is None and not a.skip_res64):
+        gen_trained_like()
     if a.only == "graded" or (a.only is None and not a.skip_res64):
         gen_graded(a.graded.split(","))
     print("golden fixtures written to", GOLD)

@@ -27,12 +27,13 @@ int main(void) {
   /* round-4 entry points: the f16f8 / f16f6 Winograd calls and the chunked mesher's workspace */
   {
     char buf[64];
-    if (md_wino_prep_f8(NULL, NULL, 16, 0, NULL, 0, 0, buf, 1, 8, 8, 8, NULL) != MD_ERR_BAD_ARG) { printf("prep_f8 null\n"); ++fails; }
-    if (md_wino_prep_f6((const float*)buf, NULL, 24, 0, NULL, 0, 0, buf, 1, 8, 8, 8, NULL) != MD_ERR_BAD_ARG) { printf("prep_f6 blocks\n"); ++fails; }
+    if (md_wino_prep_f8(NULL, NULL, 16, 0, NULL, 0, 0, NULL, buf, 1, 8, 8, 8, NULL) != MD_ERR_BAD_ARG) { printf("prep_f8 null\n"); ++fails; }
+    if (md_wino_prep_f6((const float*)buf, NULL, 24, 0, NULL, 0, 0, NULL, buf, 1, 8, 8, 8, NULL) != MD_ERR_BAD_ARG) { printf("prep_f6 blocks\n"); ++fails; }
     if (md_wino_weight_bytes_f8(128, 64) != (int64_t)128 * 64 * 36 * 4 + 256) { printf("f8 weight bytes\n"); ++fails; }
-    if (md_wino_pack_weights_f6((const float*)buf, buf, 96, 64, 64 * 27, 27, NULL) != MD_ERR_BAD_ARG) { printf("pack_f6 rows\n"); ++fails; }
+    if (md_wino_pack_weights_f6((const float*)buf, NULL, buf, 96, 64, 64 * 27, 27, NULL) != MD_ERR_BAD_ARG) { printf("pack_f6 rows\n"); ++fails; }
     if (md_conv3_wino_f6(buf, buf, (float*)buf, NULL, 0, NULL, 0, NULL, 1, 48, 128, 8, 8, 8, NULL) != MD_ERR_UNSUPPORTED) { printf("wino_f6 cin\n"); ++fails; }
     if (md_conv3_wino_f8(NULL, buf, (float*)buf, NULL, 0, NULL, 0, NULL, 1, 32, 128, 8, 8, 8, NULL) != MD_ERR_BAD_ARG) { printf("wino_f8 null\n"); ++fails; }
+    if (md_wino_equaliser(NULL, (const float*)buf, (const float*)buf, 128, 64, 64 * 27, 27, (float*)buf, NULL) != MD_ERR_BAD_ARG) { printf("equaliser null\n"); ++fails; }
     if (md_marching_tets_workspace_bytes(32, 195331, 159330) != (int64_t)32 * (195331 + 191 + 2 * 156) * 4) { printf("mt workspace\n"); ++fails; }
   }
   printf("sizeof(MdGemmConvArgs)=%zu stats@%zu %s\n", sizeof a, offsetof(MdGemmConvArgs, stats), fails ? "FAIL" : "ok");

@@ -41,6 +41,8 @@ def main():
                          "kernels (MD_WINO=0) -- the build whose 999-step parity vs the oracle is on record -- so that a B = 8 run "
                          "of the full schedule costs minutes instead of half an hour of fp32 torch convolutions")
     ap.add_argument("--precision", default=None, help="config.model.hip_precision of the HIP path (default: the config's: f16f6)")
+    ap.add_argument("--weights", default="sensitised", choices=["sensitised", "trained_like"],
+                    help="synth.sensitised_state_dict (i.i.d.) or the adversarial synth.trained_like_state_dict")
     ap.add_argument("--oracle-samples", default=None,
                     help="comma-separated sample indices: the HIP path runs the whole batch (the graded B = 8 launches), the fp32 oracle "
                          "only these samples of it on the same noise (samples are independent: GroupNorm is per sample) -- a 999-step "
@@ -51,10 +53,14 @@ def main():
     cfg.device = dev
     if a.precision:
         cfg.model.hip_precision = a.precision
+    a.hip_precision = cfg.model.hip_precision
     a.sel = [int(v) for v in a.oracle_samples.split(",")] if a.oracle_samples else None
     R = cfg.data.image_size
     model = mutils.create_model(cfg).eval()
-    sd = synth.sensitised_state_dict(model.module.state_dict(), seed=1234, grid_mask=synth.synthetic_grid_mask(R))
+    if a.weights == "trained_like":
+        sd = synth.trained_like_state_dict(model.module.state_dict(), seed=4321, grid_mask=synth.synthetic_grid_mask(R))
+    else:
+        sd = synth.sensitised_state_dict(model.module.state_dict(), seed=1234, grid_mask=synth.synthetic_grid_mask(R))
     model.module.load_state_dict(sd, strict=True)
     sd_gpu = {k: v.to(dev) for k, v in sd.items()}
     del sd
@@ -119,7 +125,7 @@ def one_seed(a, seed, st, model_fn, sd_gpu, ocfg, shape, dev, mask):
                 print(json.dumps(rec), flush=True)
     from meshdiffusion_amd import hip_ops
     return {"config": a.config, "batch": a.batch, "steps": a.steps, "seed": seed, "partner": a.partner,
-            "hip_precision": hip_ops.precision_name(), "oracle_samples": sel,
+            "hip_precision": hip_ops.FORCE_PRECISION or a.hip_precision, "weights": a.weights, "oracle_samples": sel,
             "final_x_mean_rel_l2": log[-1]["x_mean_rel_l2"],
             "target": 1e-3, "hip_s_per_step": t_h / a.steps, "oracle_gpu_s_per_step": t_o / a.steps, "trace": log}
 

@@ -528,29 +528,40 @@ def test_round4_entry_points_reject_bad_arguments_without_a_gpu(hip_lib):
     buf = ctypes.create_string_buffer(64)
     p = ctypes.cast(buf, ctypes.c_void_p)
     for prep in (hip_lib.md_wino_prep_f8, hip_lib.md_wino_prep_f6):
-        assert prep(None, None, 16, 0, None, 0, 0, p, 1, 8, 8, 8, None) == -1            # no input
-        assert prep(p, None, 16, 0, None, 1, 0, p, 1, 8, 8, 8, None) == -1               # SiLU without the folded affine
-        assert prep(p, None, 16, 0, None, 0, 0, p, 1, 8, 8, 7, None) == -1               # odd W
-        assert prep(p, None, 16, 0, None, 0, 0, p, 1, 8, 8, 24, None) == -2              # W does not divide 256
-    assert hip_lib.md_wino_prep_f6(p, None, 24, 0, None, 0, 0, p, 1, 8, 8, 8, None) == -1        # 24 channels: not whole K blocks
-    assert hip_lib.md_wino_prep_f6(p, p, 32, 8, None, 0, 0, p, 1, 8, 8, 8, None) == -1           # second part of 8 channels
+        assert prep(None, None, 16, 0, None, 0, 0, None, p, 1, 8, 8, 8, None) == -1            # no input
+        assert prep(p, None, 16, 0, None, 1, 0, None, p, 1, 8, 8, 8, None) == -1               # SiLU without the folded affine
+        assert prep(p, None, 16, 0, None, 0, 0, None, p, 1, 8, 8, 7, None) == -1               # odd W
+        assert prep(p, None, 16, 0, None, 0, 0, None, p, 1, 8, 8, 24, None) == -2              # W does not divide 256
+    assert hip_lib.md_wino_prep_f6(p, None, 24, 0, None, 0, 0, None, p, 1, 8, 8, 8, None) == -1        # 24 channels: not whole K blocks
+    assert hip_lib.md_wino_prep_f6(p, p, 32, 8, None, 0, 0, None, p, 1, 8, 8, 8, None) == -1           # second part of 8 channels
+    assert hip_lib.md_wino_equaliser(None, p, p, 128, 64, 64 * 27, 27, p, None) == -1 and hip_lib.md_wino_equaliser(p, p, p, 128, 0, 0, 27, p, None) == -1
     assert hip_lib.md_wino_weight_bytes_f8(128, 64) == 128 * 64 * 36 * 4 + 256 and hip_lib.md_wino_weight_bytes_f8(128, 48) < 0
     for pack in (hip_lib.md_wino_pack_weights_f8, hip_lib.md_wino_pack_weights_f6):
-        assert pack(None, p, 128, 64, 64 * 27, 27, None) == -1 and pack(p, p, 96, 64, 64 * 27, 27, None) == -1
+        assert pack(None, None, p, 128, 64, 64 * 27, 27, None) == -1 and pack(p, None, p, 96, 64, 64 * 27, 27, None) == -1
     for conv in (hip_lib.md_conv3_wino_f8, hip_lib.md_conv3_wino_f6):
         assert conv(None, p, p, None, 0, None, 0, None, 1, 32, 128, 8, 8, 8, None) == -1
         assert conv(p, p, p, None, 0, None, 0, None, 1, 48, 128, 8, 8, 8, None) == -2    # cin % 32
         assert conv(p, p, p, None, 0, None, 0, None, 1, 32, 128, 6, 8, 8, None) == -2    # D % 4
-    old = (hip_ops.PRECISION, hip_ops.WINO_F8)
-    try:
-        for mode, fmt in (("bf16x3", False), ("f16f8", "f8"), ("f16f6", "f6")):
-            if hip_ops.FORCE_PRECISION:
-                break
-            hip_ops.set_precision(mode)
+    assert not hip_ops._SCOPES
+    before = (hip_ops.PRECISION, hip_ops.WINO_F8, hip_ops.DEFAULT_PRECISION)
+    for mode, fmt in (("bf16x3", False), ("f16f8", "f8"), ("f16f6", "f6")):
+        if hip_ops.FORCE_PRECISION:
+            break
+        with hip_ops.precision_scope(mode):
             assert hip_ops.precision_name() == mode and hip_ops.WINO_F8 == fmt
             assert hip_ops.wino_f8_ok(64) == fmt and hip_ops.wino_f8_ok(64, drop=(0.1, 1)) is False and hip_ops.wino_f8_ok(24) is False
-        if not hip_ops.FORCE_PRECISION:
-            hip_ops.set_precision("f16f6")
+            # an operand that does not come out of a GroupNorm (Upsample: the raw residual stream) keeps bf16x3
+            assert hip_ops.wino_f8_ok(64, normalised=False) is False
+            with hip_ops.precision_scope(None, training=True):          # a training forward / backward inside: always bf16x3
+                assert hip_ops.precision_name() == "bf16x3" and hip_ops.wino_f8_ok(64) is False
+            assert hip_ops.precision_name() == mode
+    if not hip_ops.FORCE_PRECISION:
+        with hip_ops.precision_scope("f16f6"):
             assert hip_ops.wino_f8_ok(64, parts=[(None, 24), (None, 8)]) == "f8"       # parts that are not whole 16-channel blocks fall back
-    finally:
-        hip_ops.PRECISION, hip_ops.WINO_F8 = old
+        try:
+            with hip_ops.precision_scope("f16f8"):
+                raise KeyError("boom")
+        except KeyError:
+            pass
+    # a scope never leaks: the process default is back, whatever happened inside
+    assert (hip_ops.PRECISION, hip_ops.WINO_F8, hip_ops.DEFAULT_PRECISION) == before and not hip_ops._SCOPES

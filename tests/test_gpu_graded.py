@@ -35,12 +35,13 @@ def _check_stats(out, gold, mask, tag):
     assert float((out * (1 - torch.as_tensor(mask).view(1, 1, *out.shape[2:]))).abs().max()) == 0.0
 
 
-def _model(cfg_fn, seed, R):
+def _model(cfg_fn, seed, R, weights="sensitised"):
     from meshdiffusion_amd import synth
     from meshdiffusion_amd.lib.diffusion.models import ddpm_res64, ddpm_res128, utils as mutils  # noqa: F401
     cfg = cfg_fn(); cfg.device = torch.device("cuda")
     model = mutils.create_model(cfg).eval()
-    sd = synth.sensitised_state_dict(model.module.state_dict(), seed=seed, grid_mask=synth.synthetic_grid_mask(R))
+    make = synth.trained_like_state_dict if weights == "trained_like" else synth.sensitised_state_dict
+    sd = make(model.module.state_dict(), seed=seed, grid_mask=synth.synthetic_grid_mask(R))
     model.module.load_state_dict(sd, strict=True)
     return cfg, model, sd
 
@@ -49,14 +50,17 @@ def _cpu_noise(x):   # replay the reference's CPU generator stream on the host, 
     return torch.randn(x.shape).to(x.device)
 
 
-def test_res64_batch8_25_steps_vs_oracle_fp32_on_gpu(hip_lib):
-    """configs[1] at the bench batch: 25 of the 1000 ancestral steps, B = 8, same per-step noise for both trajectories."""
+@pytest.mark.parametrize("weights", ["sensitised", "trained_like"])
+def test_res64_batch8_25_steps_vs_oracle_fp32_on_gpu(hip_lib, weights):
+    """configs[1] at the bench batch: 25 of the 1000 ancestral steps, B = 8, same per-step noise for both trajectories.
+    trained_like: the adversarial weights of synth.trained_like_state_dict (heavy tails, 2^U(-3,3) GroupNorm gammas) -- the oracle on
+    these weights is pinned against the imported reference by oracle/gen_golden.py --only trained."""
     from meshdiffusion_amd import synth
     from meshdiffusion_amd.config import get_config_res64
     from meshdiffusion_amd.lib.diffusion import sampling, sde_lib
     from meshdiffusion_amd.lib.diffusion.models import utils as mutils
     from oracle import unet_oracle as uo
-    cfg, model, sd = _model(get_config_res64, 1234, 64)
+    cfg, model, sd = _model(get_config_res64, 1234 if weights == "sensitised" else 4321, 64, weights)
     sd_gpu = {k: v.cuda() for k, v in sd.items()}
     del sd
     B, K, R = 8, 25, 64
@@ -83,7 +87,7 @@ def test_res64_batch8_25_steps_vs_oracle_fp32_on_gpu(hip_lib):
             x_o = (((x_o - c[0] / c[1] * e) / torch.sqrt(1.0 - c[0])) + torch.sqrt(c[0]) * z) * mask
     e_x, e_xm = rel_l2(x_h.cpu(), x_o.cpu()), rel_l2(xm_h.cpu(), xm_o.cpu())
     per = max(rel_l2(xm_h[b].cpu(), xm_o[b].cpu()) for b in range(B))
-    print(f"res64 B=8, {K} steps vs fp32 oracle on the GPU: x {e_x:.3e} x_mean {e_xm:.3e} (worst sample {per:.3e}); "
+    print(f"res64 B=8 ({weights} weights), {K} steps vs fp32 oracle on the GPU: x {e_x:.3e} x_mean {e_xm:.3e} (worst sample {per:.3e}); "
           f"U-Net evaluation {worst_eval:.3e}")
     assert e_x < 1e-4 and e_xm < 1e-4 and per < 1e-4 and worst_eval < 1e-4
 

@@ -89,6 +89,20 @@ def conv_f16f6(t, g, fmt="e2m3"):
     return F.conv3d(th, gh) + (F.conv3d(tq, glq) + F.conv3d(tlq, gq)) * 2.0 ** -11
 
 
+def equaliser_ref(gamma, beta, w, lo=-14, hi=14):
+    """Restatement of md_wino_equaliser (csrc/wino_eq.hip): the static per-input-channel power-of-two s_c the f16f8 / f16f6 operand
+    pass multiplies the activated operand by (the packed weights carry 1 / s_c):  s_c = 2^round(log2(g_c / a_c) / 2), with
+    a_c = rms of silu(gamma_c z + beta_c) over z ~ N(0, 1) (64-point midpoint rule on [-6, 6]) and g_c = rms of w[:, c]."""
+    z = (-6.0 + 12.0 * (torch.arange(64, dtype=torch.float64) + 0.5) / 64.0)
+    pdf = torch.exp(-0.5 * z * z)
+    y = gamma.double()[:, None] * z[None] + beta.double()[:, None]
+    a2 = ((y * torch.sigmoid(y)) ** 2 * pdf[None]).sum(1) / pdf.sum()
+    g2 = w.double().pow(2).mean(dim=(0, 2, 3, 4))
+    e = torch.round(0.25 * (torch.log2(g2.clamp_min(1e-300)) - torch.log2(a2.clamp_min(1e-300)))).clamp(lo, hi)
+    e = torch.where((a2 > 0) & (g2 > 0), e, torch.zeros_like(e))
+    return torch.exp2(e).float()
+
+
 def wino_conv(x, w, conv):
     """3x3x3 pad-1 conv as F(2,3) along w with `conv` for the four (3,3,1) frequency contractions."""
     B, Ci, D, H, W = x.shape
@@ -121,7 +135,7 @@ def one_conv():
         print("  Winograd f16f8, weight pre-scale 2^%-2d (auto: 2^%d)  %.3e" % (sw, weight_exp(w), rel(wino_conv(x, w, lambda t, g: conv_f16f8(t, g, sw)), ref)))
 
 
-def unet(seeds):
+def unet(seeds, weights="sensitised"):
     from meshdiffusion_amd import synth
     from meshdiffusion_amd.config import get_config_res64
     from meshdiffusion_amd.lib.diffusion.models import ddpm_res64, utils as mutils  # noqa: F401
@@ -129,18 +143,38 @@ def unet(seeds):
     cfg = get_config_res64(); cfg.device = torch.device("cpu")
     R = cfg.data.image_size
     model = mutils.create_model(cfg, use_parallel=False)
-    sd = synth.sensitised_state_dict(model.state_dict(), seed=1234, grid_mask=synth.synthetic_grid_mask(R))
+    if weights == "trained":
+        sd = synth.trained_like_state_dict(model.state_dict(), grid_mask=synth.synthetic_grid_mask(R))
+    else:
+        sd = synth.sensitised_state_dict(model.state_dict(), seed=1234, grid_mask=synth.synthetic_grid_mask(R))
     del model
     ocfg = synth.oracle_cfg(cfg)
     real_conv3d = F.conv3d
-    mode = {"m": None}
+    mode = {"m": None, "eq": False, "gn": None}
+    real_gn, real_up = uo.group_norm, uo.upsample
+
+    def gn_rec(x, w, b):             # the GroupNorm affine in front of the next conv (the static equaliser's input)
+        mode["gn"] = (w, b)
+        return real_gn(x, w, b)
+
+    def up_rec(p, x):                # Upsample: no GroupNorm in front of its conv -> the product path runs it in bf16x3
+        mode["gn"] = None
+        return real_up(p, x)
 
     def patched(x, w, b=None, stride=1, padding=0, *a, **k):
         st = stride if isinstance(stride, int) else stride[0]
         pd = padding if isinstance(padding, int) else padding[0]
         if (mode["m"] is not None and x.dtype == torch.float32 and tuple(w.shape[2:]) == (3, 3, 3) and st == 1 and pd == 1
                 and x.shape[-1] >= 16 and w.shape[1] % 32 == 0 and w.shape[0] % 128 == 0 and not a and not k):
-            y = wino_conv(x, w, mode["m"])
+            gn, mode["gn"] = mode["gn"], None
+            if mode["eq"]:
+                if gn is None or gn[0].numel() != w.shape[1]:
+                    y = wino_conv(x, w, conv_bf16x3)               # un-normalised operand: bf16x3 (hip_ops.wino_f8_ok)
+                else:
+                    s = equaliser_ref(gn[0], gn[1], w).view(1, -1, 1, 1, 1)
+                    y = wino_conv(x * s, w / s, mode["m"])
+            else:
+                y = wino_conv(x, w, mode["m"])
             return y if b is None else y + b[None, :, None, None, None]
         return real_conv3d(x, w, b, stride, padding, *a, **k)
 
@@ -155,19 +189,20 @@ def unet(seeds):
                 ref = uo.unet_res64_forward(sd64, ocfg, x.double(), lab.double())
             finally:
                 uo.timestep_embedding = te
-            F.conv3d = patched
+            F.conv3d, uo.group_norm, uo.upsample = patched, gn_rec, up_rec
             try:
                 out = {}
-                for name, m in (("fp32", None), ("bf16x3 (Winograd convs)", conv_bf16x3), ("f16f8  (Winograd convs)", conv_f16f8),
-                                ("f16 + MX e2m3 (study)", lambda t, g: conv_f16f6(t, g, "e2m3")),
-                                ("f16 + MX e3m2 (study)", lambda t, g: conv_f16f6(t, g, "e3m2"))):
-                    mode["m"] = m
+                f6 = lambda t, g: conv_f16f6(t, g, "e2m3")  # noqa: E731
+                for name, m, eq in (("fp32", None, False), ("bf16x3 (Winograd convs)", conv_bf16x3, False),
+                                    ("f16f8", conv_f16f8, False), ("f16f6", f6, False),
+                                    ("f16f8 + static equaliser, raw operands bf16x3", conv_f16f8, True),
+                                    ("f16f6 + static equaliser, raw operands bf16x3", f6, True)):
+                    mode["m"], mode["eq"] = m, eq
                     out[name] = rel(uo.unet_res64_forward(sd, ocfg, x, lab), ref)
+                    print(f"  {name:48s} {out[name]:.3e}", flush=True)
             finally:
-                F.conv3d = real_conv3d
-        print(f"res64 U-Net evaluation, B = 1, t = 500.3, input seed {seed}: rel-L2 of eps vs fp64")
-        for k, v in out.items():
-            print(f"  {k:28s} {v:.3e}")
+                F.conv3d, uo.group_norm, uo.upsample = real_conv3d, real_gn, real_up
+        print(f"^ res64 U-Net evaluation, {weights} weights, B = 1, t = 500.3, input seed {seed}: rel-L2 of eps vs fp64")
 
 
 if __name__ == "__main__":
@@ -175,8 +210,10 @@ if __name__ == "__main__":
     ap.add_argument("--unet", action="store_true")
     ap.add_argument("--threads", type=int, default=32)
     ap.add_argument("--seeds", default="42")
+    ap.add_argument("--weights", default="sensitised", choices=["sensitised", "trained"],
+                    help="synth.sensitised_state_dict (i.i.d.) or synth.trained_like_state_dict (heavy tails, 2^U(-3,3) GroupNorm gammas)")
     a = ap.parse_args()
     torch.set_num_threads(a.threads)
     one_conv()
     if a.unet:
-        unet([int(s) for s in a.seeds.split(",")])
+        unet([int(s) for s in a.seeds.split(",")], a.weights)
