@@ -482,15 +482,6 @@ def train_step_bench(a, cfg, model, rank, world, dev, dist, barrier):
         dist.all_reduce(wt, op=dist.ReduceOp.MAX)
     s_per_step = float(wt) / a.train_steps
     ex = state.get("exchange") or {}
-    # every rank's own exchange record (buckets, bytes, exposed wait of the instrumented step): rank 0 prints them all
-    mine = torch.tensor([float(ex.get("buckets", 0)), float(ex.get("bytes", 0)), float(split.get("exchange_exposed", 0.0)),
-                         float(split.get("bwd", 0.0))], dtype=torch.float64, device=dev)
-    per_rank = [mine]
-    if dist is not None:
-        per_rank = [torch.empty_like(mine) for _ in range(world)]
-        dist.all_gather(per_rank, mine)
-    per_rank = [{"rank": r, "buckets": int(v[0]), "bytes": int(v[1]), "exchange_exposed_ms": round(float(v[2]), 2),
-                 "backward_ms": round(float(v[3]), 2)} for r, v in enumerate(per_rank)]
     return {"workload": "BASELINE configs[2] per GPU: res64 training step (fwd + loss + bwd + grad exchange + clip + Adam + EMA), "
                         f"batch {B} per GPU, dropout {cfg.model.dropout}",
             "value": round(world * B / s_per_step, 3), "unit": "samples/s", "n_gpus": world, "steps": a.train_steps,
@@ -499,13 +490,31 @@ def train_step_bench(a, cfg, model, rank, world, dev, dist, barrier):
                      "inference hip_precision is)",
             "mfma_frac_step": round(3 * FLOPS_PER_SAMPLE_STEP * B / s_per_step / (PEAK_BF16_TFLOPS * 1e12), 4),
             "split_ms": {k: round(v, 2) for k, v in split.items()},
-            "exchange": {"collective": "RCCL all-reduce (AVG) of fp32 gradients, in place on the flat gradient buffer"
-                                       if world > 1 else "none (single rank)",
-                         "buckets": ex.get("buckets", 0), "bytes": ex.get("bytes", 0), "bucket_cap_bytes": 128 << 20,
-                         "exposed_ms": round(split.get("exchange_exposed", 0.0), 2), "per_rank": per_rank},
+            "exchange": exchange_record(ex, split, world, dist, dev),
             "loss": [round(float(v.detach()), 5) for v in losses_seen],
             "peak_hbm_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1), "optimizer": "reference objects (torch.optim.Adam state, EMA shadow params, optimization_manager hyper-parameters) executed by "
                          "md_grad_sqnorm + md_adam_ema_step over flat buffers (MD_FUSED_OPT=0: torch kernels)"}
+
+
+def exchange_record(ex, split, world, dist, dev, cap_bytes=128 << 20):
+    """The `train_step.exchange` object: what the gradient exchange of the instrumented step did on EVERY rank (each rank's own
+    bucket count / bytes / exposed wait, gathered to rank 0) and the world size the process group itself reports.  Shared by the
+    GPU path (RCCL) and `--dry-run` (gloo, CPU): tests/test_dist_cpu.py checks its shape without a GPU."""
+    mine = torch.tensor([float(ex.get("buckets", 0)), float(ex.get("bytes", 0)), float(split.get("exchange_exposed", 0.0)),
+                         float(split.get("bwd", 0.0))], dtype=torch.float64, device=dev)
+    per_rank = [mine]
+    if dist is not None and world > 1:
+        per_rank = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(per_rank, mine)
+    per_rank = [{"rank": r, "buckets": int(v[0]), "bytes": int(v[1]), "exchange_exposed_ms": round(float(v[2]), 2),
+                 "backward_ms": round(float(v[3]), 2)} for r, v in enumerate(per_rank)]
+    multi = dist is not None and world > 1
+    backend = dist.get_backend() if multi else None
+    return {"collective": ("RCCL" if backend == "nccl" else str(backend)) + " all-reduce (AVG) of fp32 gradients, in place on the flat gradient buffer"
+                          if multi else "none (single rank)",
+            "backend": backend, "world_size": dist.get_world_size() if multi else 1,
+            "buckets": ex.get("buckets", 0), "bytes": ex.get("bytes", 0), "bucket_cap_bytes": cap_bytes,
+            "exposed_ms": round(split.get("exchange_exposed", 0.0), 2), "per_rank": per_rank}
 
 
 def res128_step(dev, steps=3, warmup=2):
@@ -579,7 +588,7 @@ def marching_tets_bench(dev, M=32):
     ts = []
     for _ in range(5):
         torch.cuda.synchronize(); t0 = time.perf_counter()
-        meshes, cnt = dmtet.marching_tets_batch(pos, sdf, tables)       # includes the one host sync for the result sizes
+        meshes, cnt = dmtet.marching_tets_batch(pos, sdf, tables)       # no host sync inside: the counts are copied behind the kernels
         torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
     dt = sorted(ts)[len(ts) // 2]
     V, F = int(cnt[:, 0].sum()), int(cnt[:, 1].sum())
@@ -589,7 +598,8 @@ def marching_tets_bench(dev, M=32):
                         f"edges, {N} vertices; the reference's 64-resolution grid has 159330 / 195331 / 36562)",
             "ms_per_launch": round(dt * 1e3, 3), "meshes_per_s": round(M / dt, 1), "verts_total": V, "faces_total": F,
             "algorithmic_bytes_per_launch": alg, "achieved_gbs": round(alg / dt / 1e9, 1), "hbm_frac": round(alg / dt / 1e9 / PEAK_HBM_GBS, 4),
-            "note": "includes the call's one device->host copy of the per-mesh vertex / face counts"}
+            "note": "the call + its asynchronous device->host copy of the per-mesh vertex / face counts (pinned buffer + event; the meshes "
+                    "are trimmed lazily at their first host access, outside the call)"}
 
 
 def cond_gen_bench(dev, model, cfg, B=32, iters=3):
@@ -666,10 +676,30 @@ def dry_run(a, rank, world):
         ranks = dist.get_world_size()        # what the line reports is what the process group holds, not the flag
         if ranks != a.gpus:
             raise SystemExit(f"--gpus {a.gpus} but the process group has {ranks} ranks")
+    # the training step's exchange through the REAL reducer (parallel.FlatGrads + GradReducer: in-place prefix buckets) on a
+    # stand-in flat buffer, so that the `train_step.exchange` object an N-GPU run prints is exercised without a GPU
+    from meshdiffusion_amd.lib.diffusion import parallel
+    ps = [torch.nn.Parameter(torch.zeros(n)) for n in (300_000, 50_000, 700_000, 1_000)]
+    fg = parallel.FlatGrads(ps)
+    fg.attach()
+    fg.flat.fill_(float(rank + 1))
+    cap = 1 << 20
+    t0 = time.perf_counter()
+    red = parallel.GradReducer(cap_bytes=cap, flat=fg)
+    for p in ps[:3]:
+        red.ready([p])
+    t1 = time.perf_counter()
+    red.finish(ps)
+    t2 = time.perf_counter()
+    want = sum(range(1, world + 1)) / world
+    grads_ok = bool(torch.all(fg.flat == want)) if world > 1 else bool(torch.all(fg.flat == 1.0))
+    exchange = exchange_record(red.stats, {"exchange_exposed": (t2 - t1) * 1e3, "bwd": (t1 - t0) * 1e3}, world,
+                               dist if world > 1 else None, torch.device("cpu"), cap_bytes=cap)
     if rank == 0:
         wall = float(wall_t.item())
         print(json.dumps({"metric": "dry-run", "value": ranks * a.batch * a.steps / wall, "n_gpus": ranks,
-                          "steps": a.steps, "warmup": a.warmup, "max_wall": wall}), flush=True)
+                          "steps": a.steps, "warmup": a.warmup, "max_wall": wall,
+                          "train_step": {"exchange": exchange, "grads_averaged": grads_ok, "grad_bytes": fg.n * 4}}), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

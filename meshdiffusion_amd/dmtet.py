@@ -35,8 +35,83 @@ class TetTables:
         self.tets64 = tets
 
 
+class MeshCounts:
+    """Per-mesh (vertices, faces, 1-triangle tets, 2-triangle tets) of one md_marching_tets call: int32 [M, 4], copied to a pinned
+    host buffer ASYNCHRONOUSLY on the launch stream; the first host read waits for that copy's event.  Behaves like the numpy
+    array (indexing, np.asarray, .sum through it)."""
+
+    def __init__(self, dev_counts):
+        self.device_counts = dev_counts                       # consumers on the GPU can read the sizes without any host sync
+        self._host = torch.empty(dev_counts.shape, dtype=torch.int32, pin_memory=True)
+        self._host.copy_(dev_counts, non_blocking=True)
+        self._event = torch.cuda.Event()
+        self._event.record()
+        self._np = None
+
+    def numpy(self):
+        if self._np is None:
+            self._event.synchronize()
+            self._np = self._host.numpy()
+        return self._np
+
+    def __array__(self, dtype=None, copy=None):
+        a = self.numpy()
+        return a if dtype is None else a.astype(dtype)
+
+    def __getitem__(self, k):
+        return self.numpy()[k]
+
+    def __len__(self):
+        return self._host.shape[0]
+
+    @property
+    def shape(self):
+        return tuple(self._host.shape)
+
+
+class MeshBatch:
+    """The M meshes of one md_marching_tets call as a lazy sequence of (verts [V,3], faces [F,3] int64, face_tet [F]) views into
+    the call's output buffers (allocated at their static bounds V <= E, F <= 2T): the trimming -- which needs the counts on the
+    host -- happens at the first access, not inside the call, so a caller that queues more GPU work does not stall on it."""
+
+    def __init__(self, verts, faces, face_tet, counts):
+        self.verts, self.faces, self.face_tet, self.counts = verts, faces, face_tet, counts
+
+    def __len__(self):
+        return self.verts.shape[0]
+
+    def __getitem__(self, m):
+        if isinstance(m, slice):
+            return [self[i] for i in range(*m.indices(len(self)))]
+        if m < 0:
+            m += len(self)
+        if not 0 <= m < len(self):
+            raise IndexError(m)
+        c = self.counts.numpy()
+        nv, nf = int(c[m, 0]), int(c[m, 1])
+        return self.verts[m, :nv], self.faces[m, :nf], self.face_tet[m, :nf]
+
+    def __iter__(self):
+        return (self[m] for m in range(len(self)))
+
+
+_MT_WORKSPACE = {}
+
+
+def _mt_workspace(nbytes, device):
+    """The call's scratch (edge -> vertex ids, chunk offsets) is dead when its last kernel ends: one buffer per (device, stream),
+    grown to the largest request -- launches on a stream are ordered, so consecutive calls can share it."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    buf = _MT_WORKSPACE.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = _MT_WORKSPACE[key] = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    return buf
+
+
 def marching_tets_batch(pos, sdf, tables):
-    """pos [M,N,3] f32, sdf [M,N] f32 on the GPU -> list of (verts [V,3], faces [F,3] int64, face_tet [F])."""
+    """pos [M,N,3] f32, sdf [M,N] f32 on the GPU -> (MeshBatch, MeshCounts): meshes[m] = (verts [V,3], faces [F,3] int64,
+    face_tet [F]), counts[m] = (V, F, 1-triangle tets, 2-triangle tets).  No host synchronisation inside the call: the counts
+    travel to a pinned buffer behind the kernels and are awaited at the first read."""
     lib = _lib.load()
     if not pos.is_cuda:
         raise _lib.MeshDiffusionHipError("marching tets runs on the GPU only (no CPU fallback)")
@@ -46,17 +121,18 @@ def marching_tets_batch(pos, sdf, tables):
     E, T = tables.n_edges, tables.n_tets
     dev = pos.device
     verts = torch.empty((M, E, 3), dtype=torch.float32, device=dev)
-    faces = torch.empty((M, 2 * T, 3), dtype=torch.int64, device=dev)
-    face_tet = torch.empty((M, 2 * T), dtype=torch.int64, device=dev)
+    faces = torch.empty((M, 2 * T, 4), dtype=torch.int64, device=dev)     # [..., :3] faces, then M * 2T face -> tet ids behind them
+    face_tet = faces.view(-1)[M * 2 * T * 3:].view(M, 2 * T)
+    faces = faces.view(-1)[:M * 2 * T * 3].view(M, 2 * T, 3)
     counts = torch.empty((M, 4), dtype=torch.int32, device=dev)
     ws_bytes = lib.md_marching_tets_workspace_bytes(M, E, T)
-    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    ws = _mt_workspace(ws_bytes, dev)
     _lib.check(lib.md_marching_tets(_ptr(pos), _ptr(sdf), _ptr(tables.tets), _ptr(tables.edges),
                                     _ptr(tables.tet_edges), M, N, E, T, _ptr(verts), _ptr(faces),
                                     _ptr(face_tet), _ptr(counts), _ptr(ws), ws_bytes, _stream()),
                "md_marching_tets")
-    cnt = counts.cpu().numpy()  # the only host sync: result sizes
-    return [(verts[m, :cnt[m, 0]], faces[m, :cnt[m, 1]], face_tet[m, :cnt[m, 1]]) for m in range(M)], cnt
+    cnt = MeshCounts(counts)
+    return MeshBatch(verts, faces, face_tet, cnt), cnt
 
 
 def _map_uv(face_tet, n1, num_tets, device):

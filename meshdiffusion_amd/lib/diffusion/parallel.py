@@ -67,21 +67,29 @@ def sharded_sample(sample_fn, total_batch, seed, gather=True):
     # slot 0: rank count of dims, 1..6: shape, 7: dtype code -- the gather keeps the shard's OWN dtype (the DDIM sampler
     # returns float64 state like the reference: a world-size-dependent cast would change the written .npy)
     codes = {torch.float32: 1, torch.float64: 2, torch.float16: 3, torch.bfloat16: 4}
-    shape_t = torch.zeros(8, dtype=torch.int64)
+    # slot 8: MINUS the dtype code (MAX-reduced like the rest: -min over the ranks that hold samples) -- every rank learns whether the
+    # ranks disagree and ALL of them raise; a rank that raised alone would leave the others hanging in the gather
+    shape_t = torch.zeros(9, dtype=torch.int64)
+    shape_t[8] = -(1 << 40)
     if ref is not None:
         assert ref.dim() <= 6 and ref.dtype in codes, (ref.shape, ref.dtype)
         shape_t[0] = ref.dim()
         shape_t[1:1 + ref.dim()] = torch.tensor(ref.shape)
         shape_t[7] = codes[ref.dtype]
+        shape_t[8] = -codes[ref.dtype]
     # RCCL moves device buffers; gloo gathers through host memory (also when the shards live on a GPU)
     dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
     shape_t = shape_t.to(dev)
     dist.all_reduce(shape_t, op=dist.ReduceOp.MAX)
     nd = int(shape_t[0])
     full = [int(v) for v in shape_t[1:1 + nd]]
+    if int(shape_t[7]) == 0:            # no rank holds a sample (total_batch = 0): nothing to gather, on every rank alike
+        return None
+    if int(shape_t[7]) != -int(shape_t[8]):
+        names = {v: k for k, v in codes.items()}
+        raise RuntimeError(f"sharded_sample: the ranks sampled different dtypes ({names[-int(shape_t[8])]} .. {names[int(shape_t[7])]}); "
+                           f"rank {rank} holds {None if local is None else local.dtype}")
     dtype = {v: k for k, v in codes.items()}[int(shape_t[7])]
-    if local is not None and local.dtype != dtype:
-        raise RuntimeError(f"sharded_sample: rank {rank} sampled {local.dtype}, another rank {dtype}")
     buf = torch.zeros([max(sizes)] + full[1:], dtype=dtype, device=dev)
     if local is not None:
         buf[:sizes[rank]] = local.to(dev)

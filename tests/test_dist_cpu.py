@@ -231,6 +231,22 @@ def test_replica_broadcast_and_bucketed_grad_allreduce_gloo():
         assert torch.allclose(res[0][1][k], p.grad, atol=1e-6) and torch.equal(res[0][1][k], res[1][1][k])
 
 
+def _check_dry_run_exchange(d, world):
+    """the `train_step.exchange` object of an N-rank line -- per-rank exposed wait, bucket count / bytes and the
+    world size the PROCESS GROUP reports -- produced by the real reducer (parallel.FlatGrads + GradReducer) under gloo."""
+    ts = d["train_step"]
+    ex = ts["exchange"]
+    assert ts["grads_averaged"] is True
+    assert ex["world_size"] == world and ex["backend"] == "gloo" and "all-reduce" in ex["collective"]
+    assert ex["bytes"] == ts["grad_bytes"] == (300_000 + 50_000 + 700_000 + 1_000) * 4          # every gradient byte exactly once
+    assert ex["bucket_cap_bytes"] == 1 << 20 and 2 <= ex["buckets"] <= 5                        # in-place prefix buckets of >= 1 MB + the rest
+    assert [r["rank"] for r in ex["per_rank"]] == list(range(world))
+    for r in ex["per_rank"]:
+        assert r["buckets"] == ex["buckets"] and r["bytes"] == ex["bytes"]
+        assert 0.0 <= r["exchange_exposed_ms"] < 60_000 and r["backward_ms"] >= 0.0
+    assert ex["exposed_ms"] == ex["per_rank"][0]["exchange_exposed_ms"]
+
+
 @retry_rendezvous
 def test_bench_multi_process_control_flow_dry_run():
     """bench.py under torch.distributed.run with 2 ranks: rendezvous on 127.0.0.1, barrier, MAX over ranks,
@@ -247,6 +263,7 @@ def test_bench_multi_process_control_flow_dry_run():
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and abs(d["max_wall"] - 0.2) < 1e-9 and d["value"] == 2 * 8 * 3 / 0.2
+    _check_dry_run_exchange(d, 2)
 
 
 @retry_rendezvous
@@ -263,6 +280,7 @@ def test_bench_gpus_flag_starts_its_own_ranks():
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and abs(d["max_wall"] - 0.2) < 1e-9 and d["value"] == 2 * 8 * 3 / 0.2
+    _check_dry_run_exchange(d, 2)
 
 
 def test_bench_refuses_fewer_ranks_than_gpus_flag():
