@@ -12,7 +12,21 @@
 
 namespace {
 constexpr int P2_POS = 256;               // positions per workgroup
-constexpr int P2_STRIDE = 12;             // floats per position in LDS (8 + pad: 48 B keeps 16-byte alignment, 2-way bank conflicts)
+constexpr int P2_STRIDE = 12;             // floats per position in LDS (8 + pad: 48 B keeps 16-byte alignment)
+// LDS image of a channel group's 256 activated positions, round 5: EVEN and ODD positions in two regions, [parity][128][12 floats],
+// the odd region 16 floats further.  Phase 2 reads positions 2 pi - 1 + k (pi = the lane's pair): with the positions in one run a
+// lane group of a ds_read_b128 stepped by 24 dwords -- period 8 over the 64 banks, every read 2-way conflicted (37 % of the f6
+// kernel's LDS cycles were conflict cycles, profiles/r04_final_pmc_sq.summary.txt).  De-interleaved, the lanes of one read all want
+// the same parity at consecutive indices: 12 dwords apart, and 12 l mod 64 puts the 16 lanes of every ds_read_b128 group on 16
+// different 16-byte slots.  The phase-1 stores (8-lane groups, 32 banks) alternate between the regions: the 16-float offset keeps
+// the even lanes' slots {0, 12, 24, 4} and the odd lanes' {16, 28, 8, 20} apart.  (tests/test_cpu_kernel_layouts.py replays both.)
+constexpr int P2_REGION = (P2_POS / 2) * P2_STRIDE + 16;      // floats between the even and the odd region
+constexpr int P2_GROUP = 2 * P2_REGION;                        // floats per channel group
+#ifdef P2_OLD_IMAGE      // A/B build only (tools/bench_prep.py): the round-4 image, positions in one run
+__device__ __forceinline__ int p2_slot(int p) { return p * P2_STRIDE; }
+#else
+__device__ __forceinline__ int p2_slot(int p) { return (p & 1) * P2_REGION + (p >> 1) * P2_STRIDE; }
+#endif
 }  // namespace
 
 // DUAL (md_wino_prep_dual): also writes U, the transposed algorithm's transform of the same activated tensor,
@@ -29,7 +43,7 @@ __global__ __launch_bounds__(256) void md_wino_prep2_kernel(const float* __restr
                                                             uint4* __restrict__ T, uint4* __restrict__ U, float* __restrict__ sums,
                                                             int batch, int D, int H, int W, uint32_t thr16, float drop_scale,
                                                             uint64_t seed, const float* __restrict__ eq) {
-  __shared__ __attribute__((aligned(16))) float act[P2_POS * P2_STRIDE];
+  __shared__ __attribute__((aligned(16))) float act[P2_GROUP];
   __shared__ float wsum[32];                       // DUAL with sums: [wave][channel]
   float psum[8];                                   // this thread's (activated) values, for the channel sums
   const int tid = threadIdx.x;
@@ -90,7 +104,7 @@ __global__ __launch_bounds__(256) void md_wino_prep2_kernel(const float* __restr
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) psum[e] = yv[e];
-    float* dst = act + tid * P2_STRIDE;
+    float* dst = act + p2_slot(tid);
     *(f32x4*)dst = f32x4{yv[0], yv[1], yv[2], yv[3]};
     *(f32x4*)(dst + 4) = f32x4{yv[4], yv[5], yv[6], yv[7]};
   }
@@ -133,7 +147,7 @@ __global__ __launch_bounds__(256) void md_wino_prep2_kernel(const float* __restr
       const bool live = need && xx >= 0 && xx < W;
       f32x4 u0 = {0.f, 0.f, 0.f, 0.f}, u1 = u0;
       if (live) {
-        const float* s = act + (lp - 1 + k) * P2_STRIDE;
+        const float* s = act + p2_slot(lp - 1 + k);
         u0 = *(const f32x4*)s; u1 = *(const f32x4*)(s + 4);
       }
 #pragma unroll
@@ -189,7 +203,7 @@ __global__ __launch_bounds__(256) void md_wino_prep2_kernel(const float* __restr
 __global__ __launch_bounds__(256) void md_wino_prep2_f6_kernel(const float* __restrict__ x1, const float* __restrict__ x2, int c1, int c2,
                                                                const float* __restrict__ ac, int silu, int ups, uint4* __restrict__ T, int batch,
                                                                int D, int H, int W, const float* __restrict__ eq) {
-  __shared__ __attribute__((aligned(16))) float act[2 * P2_POS * P2_STRIDE];
+  __shared__ __attribute__((aligned(16))) float act[2 * P2_GROUP];
   const int tid = threadIdx.x;
   const int Wp = W >> 1;
   const int64_t P = (int64_t)D * H * W, Ph = P >> 1;
@@ -240,7 +254,7 @@ __global__ __launch_bounds__(256) void md_wino_prep2_f6_kernel(const float* __re
 #pragma unroll
         for (int e = 0; e < 8; ++e) yv[e] *= e < 4 ? e0[e] : e1[e - 4];
       }
-      float* dst = act + (g2 * P2_POS + tid) * P2_STRIDE;
+      float* dst = act + g2 * P2_GROUP + p2_slot(tid);
       *(f32x4*)dst = f32x4{yv[0], yv[1], yv[2], yv[3]};
       *(f32x4*)(dst + 4) = f32x4{yv[4], yv[5], yv[6], yv[7]};
     }
@@ -261,7 +275,7 @@ __global__ __launch_bounds__(256) void md_wino_prep2_f6_kernel(const float* __re
       for (int g2 = 0; g2 < 2; ++g2) {
         f32x4 u0 = {0.f, 0.f, 0.f, 0.f}, u1 = u0;
         if (live) {
-          const float* sv = act + (g2 * P2_POS + lp - 1 + k) * P2_STRIDE;
+          const float* sv = act + g2 * P2_GROUP + p2_slot(lp - 1 + k);
           u0 = *(const f32x4*)sv; u1 = *(const f32x4*)(sv + 4);
         }
 #pragma unroll

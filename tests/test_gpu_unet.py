@@ -349,7 +349,7 @@ def test_unet_res64_trained_like_weights_vs_reference_golden(env):
         print(f"res64 U-Net, trained-like weights, {mode}: sub / row / norm per sample {[tuple(f'{v:.2e}' for v in e) for e in out[mode]]}; "
               f"{len(tags)} Winograd conv launches, {n_fmt} of them in the reduced-precision format")
         if fmt and not hip_ops.FORCE_PRECISION:
-            assert n_fmt >= 30 and len(tags) - n_fmt <= 3        # all but the Upsample convs (raw residual stream: bf16x3)
+            assert n_fmt >= 20 and len(tags) - n_fmt <= 3        # all but the Upsample convs (raw residual stream: bf16x3); B = 2: the 64^3 and 32^3 levels
     model.module.hip_precision = default_mode
     for e_sub, e_row, e_norm in out[default_mode]:
         assert e_sub < TOL_EVAL_TRAINED and e_norm < TOL_EVAL_TRAINED and e_row < TOL_EVAL
@@ -386,7 +386,7 @@ def test_precision_is_a_property_of_the_model_not_of_the_process(env):
         kinds = {t.rsplit("/", 1)[1] if t.endswith(("/f8", "/f6")) else "bf16x3" for t in tags}
         n_fmt = sum(t.endswith("/" + fmt) for t in tags) if fmt else 0
         assert kinds <= ({fmt, "bf16x3"} if fmt else {"bf16x3"}), kinds
-        assert (n_fmt >= 20 and len(tags) - n_fmt <= 4) if fmt else tags, (fmt, len(tags), n_fmt)
+        assert (n_fmt >= 10 and len(tags) - n_fmt <= 4) if fmt else tags, (fmt, len(tags), n_fmt)     # B = 1: the 64^3 level (+ 128^3 / 64^3 of res128)
 
     for order in ((m64, m128), (m128, m64), (m64, m128)):
         for m in order:
