@@ -205,6 +205,70 @@ def unet(seeds, weights="sensitised"):
         print(f"^ res64 U-Net evaluation, {weights} weights, B = 1, t = 500.3, input seed {seed}: rel-L2 of eps vs fp64")
 
 
+def audit(weights):
+    """How good is the equaliser's STATIC estimate?  One res64 U-Net evaluation on the CPU (fp32 oracle): for every GroupNorm -> SiLU ->
+    3x3x3 conv pair the per-channel rms of the activated operand the conv really sees against a_c = rms of silu(gamma_c z + beta_c),
+    z ~ N(0, 1) -- GroupNorm normalises a GROUP, not a channel, so a channel's own mean / variance inside its group are what the static
+    model cannot know -- and the spread (max / min over the 16 channels of a K block) of the equalised operand, which is what e2m3's
+    four binades have to hold."""
+    from meshdiffusion_amd import synth
+    from meshdiffusion_amd.config import get_config_res64
+    from meshdiffusion_amd.lib.diffusion.models import ddpm_res64, utils as mutils  # noqa: F401
+    from oracle import unet_oracle as uo
+    cfg = get_config_res64(); cfg.device = torch.device("cpu")
+    R = cfg.data.image_size
+    model = mutils.create_model(cfg, use_parallel=False)
+    make = synth.trained_like_state_dict if weights == "trained" else synth.sensitised_state_dict
+    sd = make(model.state_dict(), grid_mask=synth.synthetic_grid_mask(R))
+    del model
+    real_conv3d, real_gn, real_up, real_down = F.conv3d, uo.group_norm, uo.upsample, uo.downsample
+    st = {"gn": None, "rows": []}
+
+    def down_rec(p, x):              # Downsample: no GroupNorm in front either (md_conv3_s2, bf16x3)
+        st["gn"] = None
+        return real_down(p, x)
+
+    def gn_rec(x, w, b):
+        st["gn"] = (w, b)
+        return real_gn(x, w, b)
+
+    def up_rec(p, x):
+        st["gn"] = None
+        return real_up(p, x)
+
+    def conv_rec(x, w, b=None, stride=1, padding=0, *a, **k):
+        gn, st["gn"] = st["gn"], None
+        if gn is not None and tuple(w.shape[2:]) == (3, 3, 3) and gn[0].numel() == w.shape[1] and w.shape[1] % 16 == 0 and x.shape[-1] >= 16:
+            s = equaliser_ref(gn[0], gn[1], w)
+            z = -6.0 + 12.0 * (torch.arange(64, dtype=torch.float64) + 0.5) / 64.0
+            pdf = torch.exp(-0.5 * z * z)
+            y = gn[0].double()[:, None] * z[None] + gn[1].double()[:, None]
+            a_est = (((y * torch.sigmoid(y)) ** 2 * pdf[None]).sum(1) / pdf.sum()).sqrt()
+            a_real = x.double().pow(2).mean(dim=(0, 2, 3, 4)).sqrt()
+            ratio = (a_real / a_est.clamp_min(1e-30))
+            def blockspread(v):
+                vb = v.reshape(-1, 16)
+                return float((vb.max(1).values / vb.min(1).values.clamp_min(1e-30)).max())
+            st["rows"].append((tuple(w.shape[:2]), x.shape[-1], float(ratio.min()), float(ratio.median()), float(ratio.max()),
+                               blockspread(a_real), blockspread(a_real * s.double())))
+        return real_conv3d(x, w, b, stride, padding, *a, **k)
+
+    x = synth.synthetic_inputs(1, 4, R, seed=42) * synth.synthetic_grid_mask(R).view(1, 1, R, R, R)
+    F.conv3d, uo.group_norm, uo.upsample, uo.downsample = conv_rec, gn_rec, up_rec, down_rec
+    try:
+        with torch.no_grad():
+            uo.unet_res64_forward(sd, synth.oracle_cfg(cfg), x, torch.tensor([500.3]))
+    finally:
+        F.conv3d, uo.group_norm, uo.upsample, uo.downsample = real_conv3d, real_gn, real_up, real_down
+    print(f"equaliser audit, {weights} weights: measured / estimated per-channel operand rms (min, median, max) and the worst 16-channel "
+          "block spread of the operand before -> after equalisation")
+    for (co, ci), S, lo, med, hi, sp0, sp1 in st["rows"]:
+        print(f"  {ci:4d}->{co:4d} @{S:2d}^3   rms ratio {lo:5.2f} {med:5.2f} {hi:5.2f}   block spread {sp0:9.1f} -> {sp1:6.1f}")
+    r = st["rows"]
+    print(f"  over {len(r)} pairs: rms ratio in [{min(v[2] for v in r):.2f}, {max(v[4] for v in r):.2f}]; worst block spread "
+          f"{max(v[5] for v in r):.0f} -> {max(v[6] for v in r):.1f}")
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--unet", action="store_true")
@@ -212,8 +276,12 @@ if __name__ == "__main__":
     ap.add_argument("--seeds", default="42")
     ap.add_argument("--weights", default="sensitised", choices=["sensitised", "trained"],
                     help="synth.sensitised_state_dict (i.i.d.) or synth.trained_like_state_dict (heavy tails, 2^U(-3,3) GroupNorm gammas)")
+    ap.add_argument("--audit", action="store_true", help="compare the equaliser's static activation estimate with the operands of one forward")
     a = ap.parse_args()
     torch.set_num_threads(a.threads)
+    if a.audit:
+        audit(a.weights)
+        sys.exit(0)
     one_conv()
     if a.unet:
         unet([int(s) for s in a.seeds.split(",")], a.weights)
