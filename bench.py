@@ -221,7 +221,8 @@ def main():
                              "arithmetic of rounds 1-3, measured here in the same process on the same box",
                 "value": round(B * a.steps / wf, 3), "unit": "sample-steps/s", "ms_per_step": round(wf / a.steps * 1e3, 3),
                 "parity": "per U-Net evaluation 1.2-2.2e-5, 999-step sampled grids 8.4-8.6e-6 rel-L2 vs the fp32 oracle (profiles/r02_*, r03_longrun_*); "
-                          "f16f8 / f16f6: 4e-5 / 5e-5 per evaluation (tools/f16f8_numerics.py), long-run records in profiles/r04_longrun_*"}
+                          "f16f8 / f16f6 (with the static equaliser): 3.4e-5 / 4.9e-5 per evaluation on the trained-like weights vs the reference golden, "
+                          "long-run records in profiles/r04_longrun_*, r05_longrun_*"}
     # ---- BASELINE configs[0] on the GPU: res64, batch 1 (single-sample latency), same weights ----
     b1 = None
     if world == 1 and B != 1 and not a.no_res128:
@@ -308,8 +309,10 @@ def main():
             "n_gpus": dist.get_world_size() if dist is not None else 1, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
-            "parity": "sampled grids vs the fp32 oracle over the full schedule and per-evaluation figures: profiles/r04_longrun_*.json, "
-                      "DESIGN.md section 5 (target 1e-3 rel-L2)",
+            "parity": "999-step sampled grids at B = 8 vs the fp32 oracle: 1.7e-5 on the adversarial trained-like weights "
+                      "(profiles/r05_longrun_999step_b8_f16f6_trained_like_vs_oracle.json), 1.9e-5 on the i.i.d. ones (profiles/r04_longrun_*); one U-Net "
+                      "evaluation vs the unmodified reference on the trained-like weights 4.6-5.2e-5 (tests/golden/unet_res64_trained.npz); DESIGN.md "
+                      "sections 3 and 5 (target 1e-3 rel-L2 on sampled grids)",
             "dtype": {"bf16x3": "bf16x3 (split-bf16 MFMA operands, fp32 accumulate/IO)",
                                             "fp16x2": "fp16x2 (weights split fp16, activations fp16, fp32 accumulate/IO)",
                                             "f16f8": "f16f8 in the Winograd convs behind a GroupNorm (fp16 hi*hi MFMA + e4m3 cross terms in a K-concatenated scaled "

@@ -121,6 +121,7 @@ def side_stream():
 
 
 PROFILE = None   # set to a list by bench.py to collect (cfg, flops, start_event, end_event) per GEMM/conv launch
+AUDIT = None     # set to a list by tools/audit_precision.py: every f16f8 / f16f6 conv launch is repeated in bf16x3 and the difference recorded
 
 
 def _stream():

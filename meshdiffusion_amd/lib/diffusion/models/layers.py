@@ -133,6 +133,7 @@ def conv3_wino_packed(layer, name, conv, gn=None):
                                  lambda: ops.WinoWeightF8(conv.weight, conv.weight.device, fmt, eq=eq()))
         return layer._cached(f"{name}/wino", [conv.weight], lambda: ops.WinoWeight(conv.weight, conv.weight.device))
     build.eq = eq
+    build.owner, build.site = layer, name      # identifies the conv for per-layer overrides (layer.md_bf16x3_sites) and the audit
     return build
 
 
@@ -171,12 +172,22 @@ def run_conv3(pw, act_s16, B, S_out, *, bias=None, bias_bstride=0, residual=None
         # the raw residual stream (Upsample: ac None) stays in bf16x3
         f8 = (not b_f32.get("wino_only")) and ops.wino_f8_ok(S_out, drop=b_f32.get("drop"), keep=bool(b_f32.get("keep")), parts=b_f32["parts"],
                                                              normalised=b_f32.get("ac") is not None)
+        if f8 and getattr(wino, "owner", None) is not None and wino.site in getattr(wino.owner, "md_bf16x3_sites", ()):
+            f8 = False                   # this conv was taken off the reduced-precision path (layer.md_bf16x3_sites: tools/audit_precision.py)
         t = ops.wino_prep(b_f32["parts"], b_f32.get("ac"), b_f32.get("silu"), ups, B, S_out, drop=b_f32.get("drop"),
                           keep=bool(b_f32.get("keep")), f8=f8, eq=wino.eq() if f8 and hasattr(wino, "eq") else None)
         if b_f32.get("keep"):
             b_f32["t_out"] = t           # training: the Winograd weight gradient reads the operand again (tape)
         ops.conv3_wino(wino(f8) if f8 else wino(), t, B, S_out, bias=bias, bias_bstride=bias_bstride, residual=residual,
                        res_bstride=res_bstride or 0, stats=stats, out=out)
+        if f8 and ops.AUDIT is not None:
+            # diagnostic mode (tools/audit_precision.py): the same launch once more in bf16x3; the pair's relative difference is the
+            # error the reduced-precision format adds on THIS layer with THESE weights and activations
+            t3 = ops.wino_prep(b_f32["parts"], b_f32.get("ac"), b_f32.get("silu"), ups, B, S_out)
+            ref = ops.conv3_wino(wino(), t3, B, S_out, bias=bias, bias_bstride=bias_bstride, residual=residual, res_bstride=res_bstride or 0)
+            ops.AUDIT.append(dict(owner=getattr(wino, "owner", None), site=getattr(wino, "site", None), fmt=f8, cin=pw.kdim, cout=pw.rows,
+                                  S=S_out, rel_l2=float(((out.double() - ref.double()).norm() / ref.double().norm().clamp_min(1e-300)).item())))
+            del t3, ref
         if stats is not None:
             out._md_sums = stats
         elif hasattr(out, "_md_sums"):

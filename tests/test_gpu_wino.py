@@ -774,3 +774,49 @@ def test_unnormalised_tiny_operand_keeps_bf16x3(ops, fmt, monkeypatch):
     e = rel_l2(y, ref)
     print(f"raw 1e-5 operand under a f16{fmt} scope: {e:.2e} (bf16x3 kernels: {tags})")
     assert e < TOL_MFMA
+
+
+def test_precision_audit_record_and_per_layer_override(ops, monkeypatch):
+    """hip_ops.AUDIT (tools/audit_precision.py): a reduced-precision conv launch is repeated in bf16x3 on the same operands and the pair's
+    relative difference recorded -- the per-layer check to run on a real checkpoint; `layer.md_bf16x3_sites` takes a conv off the
+    reduced-precision path for good."""
+    from meshdiffusion_amd.lib.diffusion.models import layers
+    monkeypatch.setattr(ops, "WINO_MIN_WGS", 1)
+    B, S, cin, cout = 1, 16, 128, 128
+
+    class Pair(layers.HipLayer):
+        def __init__(self):
+            super().__init__()
+            self.gn = torch.nn.GroupNorm(32, cin, eps=1e-6)
+            self.conv = torch.nn.Conv3d(cin, cout, 3, padding=1)
+
+    pair = Pair().cuda()
+    x = ops.ncdhw_to_f32b(_rand((B, cin, S, S, S), 400).cuda())
+    _, ac = ops.gn_params([(x, cin)], pair.gn.weight, pair.gn.bias, B, S ** 3, want_ac=True)
+    pw = layers.conv3_packed(pair, "w", pair.conv, ops.conv_cfg_for(S))
+
+    def run():
+        ops.PROFILE = []
+        try:
+            with ops.precision_scope("f16f6"):
+                out = layers.run_conv3(pw, None, B, S, bias=pair.conv.bias, b_f32=dict(parts=[(x, cin)], ac=ac, silu=True),
+                                       wino=layers.conv3_wino_packed(pair, "w", pair.conv, gn=pair.gn))
+            return out.clone(), [r[5] for r in ops.PROFILE if r[0] == "wino"]
+        finally:
+            ops.PROFILE = None
+
+    y6, tags = run()
+    assert tags == [t for t in tags if t.endswith("/f6")] and len(tags) == 1
+    ops.AUDIT = []
+    try:
+        ya, _ = run()
+        recs = ops.AUDIT
+    finally:
+        ops.AUDIT = None
+    assert torch.equal(ya, y6)                                      # the audit does not disturb the product launch
+    assert len(recs) == 1 and recs[0]["owner"] is pair and recs[0]["site"] == "w" and recs[0]["fmt"] == "f6"
+    assert 1e-6 < recs[0]["rel_l2"] < 4e-5
+    pair.md_bf16x3_sites = ("w",)
+    y3, tags3 = run()
+    assert len(tags3) == 1 and "/f" not in tags3[0]
+    assert abs(rel_l2(y6.cpu(), y3.cpu()) - recs[0]["rel_l2"]) < 1e-6      # the recorded difference IS f16f6 vs bf16x3 on this layer
