@@ -130,15 +130,7 @@ SIGNATURES = {
     "md_marching_tets": (C.c_int, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _I64, _P]),
 }
 
-# include/meshdiffusion_hip_experimental.h: present only in a MD_BUILD_EXPERIMENTAL=1 build; bound when the library has them
-EXPERIMENTAL_SIGNATURES = {
-    "md_wino43_operand_bytes": (_I64, [_I32, _I32, _I32, _I32, _I32]),
-    "md_wino43_prep": (C.c_int, [_P, _P, _I32, _I32, _P, _I32, _I32, _P, _I32, _I32, _I32, _I32, _P]),
-    "md_wino43_weight_bytes": (_I64, [_I32, _I32]),
-    "md_wino43_pack_weights": (C.c_int, [_P, _P, _I32, _I32, _I64, _I64, _I32, _P]),
-    "md_conv3_wino43": (C.c_int, [_P, _P, _P, _P, _I64, _P, _I64, _P, _I32, _I32, _I32, _I32, _I32, _I32, _P]),
-}
-# MD_BUILD_ABLATIONS=1 builds only (same header)
+# include/meshdiffusion_hip_experimental.h: MD_BUILD_ABLATIONS=1 builds only (same header)
 ABLATION_SIGNATURES = {"md_wgrad_set_debug": (None, [_I32])}
 
 _lib = None
@@ -168,7 +160,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    for name, (res, args) in list(EXPERIMENTAL_SIGNATURES.items()) + list(ABLATION_SIGNATURES.items()):
+    for name, (res, args) in ABLATION_SIGNATURES.items():
         fn = getattr(lib, name, None)
         if fn is not None:
             fn.restype = res
@@ -187,11 +179,6 @@ def load():
                                     f"({lib.md_device_count()} vs {torch.cuda.device_count()} devices)")
     _lib = lib
     return lib
-
-
-def has_experimental():
-    """True when the loaded library was built with MD_BUILD_EXPERIMENTAL=1."""
-    return all(hasattr(load(), n) for n in EXPERIMENTAL_SIGNATURES)
 
 
 def check(rc, what):

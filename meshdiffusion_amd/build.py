@@ -18,8 +18,6 @@ OBJDIR = os.path.join(CSRC, "build" + _SUFFIX)
 LIB_PATH = os.path.join(HERE, f"libmeshdiffusion_hip{_SUFFIX}.so")
 ARCH = "gfx950"
 SOURCES = ["capi.hip", "gemm_conv.hip", "conv3_main.hip", "conv3_wino.hip", "conv3_s2.hip", "conv3_head.hip", "conv3_stem.hip", "pack_batch.hip", "wino_prep2.hip", "wino_eq.hip", "norm.hip", "elementwise.hip", "attention.hip", "nin_stream.hip", "train.hip", "backward.hip", "wgrad.hip", "wgrad_wino.hip", "dmtet.hip"]
-# default-off experiments (MD_BUILD_EXPERIMENTAL=1): declared in include/meshdiffusion_hip_experimental.h, bound lazily by _lib.py
-EXPERIMENTAL_SOURCES = ["experimental/conv3_wino43.hip"]
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", f"-I{INCLUDE}", f"-I{CSRC}",
          "-munsafe-fp-atomics", "-Wno-unused-result"]
 
@@ -41,20 +39,18 @@ def _newer(target, deps):
 def build(verbose=False, force=False):
     """Compile every HIP source for gfx950 (in parallel) and link the shared library. Returns its path.
     MD_BUILD_ABLATIONS=1 in the environment also builds the timing-only kernel variants of tools/bench_conv.py /
-    tools/bench_wino.py (adds ~4 minutes: seven more instantiations of the unrolled 27-tap conv kernel);
-    MD_BUILD_EXPERIMENTAL=1 adds the default-off experimental kernels (csrc/experimental/: the F(4,3) Winograd prototype)."""
+    tools/bench_wino.py (adds ~4 minutes: seven more instantiations of the unrolled 27-tap conv kernel)."""
     from concurrent.futures import ThreadPoolExecutor
     hipcc = _hipcc()
     os.makedirs(OBJDIR, exist_ok=True)
     headers = [os.path.join(CSRC, "md_common.h"), os.path.join(CSRC, "md_pack.h"), os.path.join(INCLUDE, "meshdiffusion_hip.h")]
     flags = FLAGS + (["-DMD_BUILD_ABLATIONS"] if os.environ.get("MD_BUILD_ABLATIONS") == "1" else [])
-    experimental = os.environ.get("MD_BUILD_EXPERIMENTAL") == "1"
-    flags = flags + (["-DMD_BUILD_EXPERIMENTAL"] if experimental else []) + os.environ.get("MD_EXTRA_DEFINES", "").split()
+    flags = flags + os.environ.get("MD_EXTRA_DEFINES", "").split()
     stamp = os.path.join(OBJDIR, "flags.txt")
     if not os.path.exists(stamp) or open(stamp).read() != " ".join(flags):
         force = True
     objs, jobs = [], []
-    for src in SOURCES + (EXPERIMENTAL_SOURCES if experimental else []):
+    for src in SOURCES:
         sp = os.path.join(CSRC, src)
         if not os.path.exists(sp):
             raise RuntimeError(f"missing source {sp}")

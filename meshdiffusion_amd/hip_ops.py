@@ -725,62 +725,6 @@ def conv3_head(pw, x, ac, B, S, rows_alloc):
     return y
 
 
-# ---- EXPERIMENTAL: Winograd F(4,3) along w (csrc/experimental/conv3_wino43.hip, MD_BUILD_EXPERIMENTAL=1 builds only);
-# ---- tools/bench_wino.py --f43, tests/test_gpu_wino.py.  Nothing on the product path uses it.
-def _need_experimental():
-    if not _lib.has_experimental():
-        raise _lib.MeshDiffusionHipError("the F(4,3) prototype is not in this build (MD_BUILD_EXPERIMENTAL=1 python -m meshdiffusion_amd.build)")
-
-
-class WinoWeight43:
-    def __init__(self, w, device, kind="conv"):
-        _need_experimental()
-        lib = _lib.load()
-        w = w.detach().to(device=device, dtype=torch.float32).contiguous()
-        _require_cuda(w, "weight")
-        assert w.dim() == 5 and tuple(w.shape[2:]) == (3, 3, 3)
-        if kind == "conv":
-            self.rows, self.kdim = w.shape[0], w.shape[1]
-            s_row, s_k, flip = self.kdim * 27, 27, 0
-        else:
-            self.rows, self.kdim = w.shape[1], w.shape[0]
-            s_row, s_k, flip = 27, self.rows * 27, 1
-        nbytes = lib.md_wino43_weight_bytes(self.rows, self.kdim)
-        if nbytes <= 0:
-            raise _lib.MeshDiffusionHipError("md_wino43_weight_bytes: unsupported weight shape")
-        self.data = torch.empty(nbytes // 2, dtype=torch.bfloat16, device=device)
-        check(lib.md_wino43_pack_weights(_ptr(w), _ptr(self.data), self.rows, self.kdim, s_row, s_k, flip, _stream()),
-              "md_wino43_pack_weights")
-
-
-def wino43_prep(parts, ac, silu, ups, B, S):
-    _need_experimental()
-    lib = _lib.load()
-    cin = sum(c for _, c in parts)
-    nbytes = lib.md_wino43_operand_bytes(B, cin, S, S, S)
-    if nbytes <= 0:
-        raise _lib.MeshDiffusionHipError("md_wino43_operand_bytes: unsupported operand shape")
-    t = _wino_scratch(nbytes // 2, parts[0][0].device)
-    x2, c2 = (parts[1][0], parts[1][1]) if len(parts) == 2 else (None, 0)
-    ev = _prof_begin()
-    check(lib.md_wino43_prep(_ptr(parts[0][0]), _ptr(x2), parts[0][1], c2, _ptr(ac), 1 if silu else 0, 1 if ups else 0,
-                             _ptr(t), B, S, S, S, _stream()), "md_wino43_prep")
-    _prof_end(ev, "wino_prep", 0.0, 4.0 * B * cin * (S ** 3 // (8 if ups else 1)) + 6.0 * B * cin * S ** 3, f"{cin}@{S}x{S}x{S}/f43")
-    return t
-
-
-def conv3_wino43(ww, t, B, S, *, bias=None, bias_bstride=0, residual=None, res_bstride=0, stats=None, out=None):
-    lib = _lib.load()
-    P = S ** 3
-    if out is None:
-        out = f32b_empty(B, ww.rows, P, t.device)
-    ev = _prof_begin()
-    check(lib.md_conv3_wino43(_ptr(t), _ptr(ww.data), _ptr(out), _ptr(bias), bias_bstride, _ptr(residual), res_bstride,
-                              _ptr(stats), B, ww.kdim, ww.rows, S, S, S, _stream()), "md_conv3_wino43")
-    _prof_end(ev, "wino", 2.0 * B * ww.rows * ww.kdim * 27 * P, 0.0, f"{ww.kdim}->{ww.rows}@{S}x{S}x{S}/f43")
-    return out
-
-
 def _prof_begin():
     if PROFILE is None:
         return None

@@ -194,59 +194,6 @@ def test_wino_prep_v2_is_bit_identical(ops, case):
     assert float(t1.float().abs().sum()) > 0
 
 
-@pytest.mark.parametrize("case", ["plain_128", "two_parts_gn_silu_res_stats", "ups_256rows", "gn_no_silu_k64"])
-def test_conv3_wino43_experimental_vs_torch(ops, case):
-    """EXPERIMENTAL F(4,3) path (md_wino43_prep + md_wino43_pack_weights + md_conv3_wino43; not used by default): the same
-    cases as test_conv3_wino_vs_torch; its transform constants cost accuracy (1.3e-5 per conv on the CPU model,
-    tools/wino_numerics.py), so the tolerance is 4e-5.  Runs only against a MD_BUILD_EXPERIMENTAL=1 library."""
-    from meshdiffusion_amd import _lib
-    if not _lib.has_experimental():
-        pytest.skip("F(4,3) prototype not in the default build (MD_BUILD_EXPERIMENTAL=1)")
-    cfgs = {
-        "plain_128": dict(cs=[128], cout=128, S=16, B=2, gn=False, silu=False, ups=False, res=False, stats=False),
-        "two_parts_gn_silu_res_stats": dict(cs=[96, 32], cout=128, S=16, B=2, gn=True, silu=True, ups=False, res=True, stats=True),
-        "ups_256rows": dict(cs=[64], cout=256, S=16, B=1, gn=False, silu=False, ups=True, res=False, stats=True),
-        "gn_no_silu_k64": dict(cs=[32, 32], cout=128, S=8, B=3, gn=True, silu=False, ups=False, res=True, stats=False),
-    }
-    c = cfgs[case]
-    cs, cout, S, B = c["cs"], c["cout"], c["S"], c["B"]
-    cin = sum(cs)
-    Sin = S // 2 if c["ups"] else S
-    xs = [_rand((B, k, Sin, Sin, Sin), 40 + i) * (1.0 + i) + 0.3 * i for i, k in enumerate(cs)]
-    x = torch.cat(xs, 1)
-    gamma, beta = 1.0 + 0.2 * _rand((cin,), 50), 0.5 * _rand((cin,), 51)
-    w = _rand((cout, cin, 3, 3, 3), 52, 0.05)
-    bias = _rand((B, cout), 53)
-    res = _rand((B, cout, S, S, S), 54) if c["res"] else None
-    parts = [(ops.ncdhw_to_f32b(t.cuda()), k) for t, k in zip(xs, cs)]
-    ac = None
-    ref_in = x
-    if c["gn"]:
-        _, ac = ops.gn_params(parts, gamma.cuda(), beta.cuda(), B, Sin ** 3, want_ac=True)
-        ref_in = F.group_norm(x, 32, gamma, beta, eps=1e-6)
-        ref_in = F.silu(ref_in) if c["silu"] else ref_in
-    if c["ups"]:
-        ref_in = F.interpolate(ref_in, scale_factor=2, mode="nearest")
-    ww = ops.WinoWeight43(w.cuda(), "cuda")
-    t = ops.wino43_prep(parts, ac, c["silu"], c["ups"], B, S)
-    stats = torch.zeros((B, cout, 2), dtype=torch.float64, device="cuda") if c["stats"] else None
-    res_f = ops.ncdhw_to_f32b(res.cuda()) if res is not None else None
-    out = ops.conv3_wino43(ww, t, B, S, bias=bias.cuda(), bias_bstride=cout, residual=res_f,
-                           res_bstride=cout * S ** 3 if res is not None else 0, stats=stats)
-    y = ops.f32b_to_ncdhw(out, (S, S, S)).cpu()
-    ref = F.conv3d(ref_in, w, padding=1) + bias[:, :, None, None, None]
-    if res is not None:
-        ref = ref + res
-    e = rel_l2(y, ref)
-    print(f"wino F(4,3) conv ({case}): vs torch fp32 {e:.2e}")
-    assert e < 4e-5
-    if stats is not None:
-        st = stats.cpu()
-        yd = y.double()
-        assert rel_l2(st[..., 0], yd.sum(dim=(2, 3, 4))) < 1e-6
-        assert rel_l2(st[..., 1], (yd * yd).sum(dim=(2, 3, 4))) < 1e-6
-
-
 def test_conv3_wino_rejects_unsupported_shapes(ops):
     from meshdiffusion_amd import _lib
     lib = _lib.load()

@@ -26,7 +26,6 @@ def main():
     ap.add_argument("--shapes", default="128:128:64:8,256:128:64:8,256:256:32:8,512:256:16:8")
     ap.add_argument("--out", default=None)
     ap.add_argument("--prep-v2", action="store_true", help="also time the experimental two-phase operand pass")
-    ap.add_argument("--f43", action="store_true", help="also time the experimental F(4,3) kernels (md_wino43_*)")
     ap.add_argument("--f8", action="store_true", help="also time the f16f8 arithmetic (md_wino_prep_f8 + md_conv3_wino_f8), interleaved with "
                                                        "the bf16x3 production kernel (same box, same clocks)")
     ap.add_argument("--no-stats", action="store_true", help="launch without the GroupNorm-sum epilogue")
@@ -67,20 +66,6 @@ def main():
             ops.WINO_PREP_V2 = False
             rows.append(dict(shape=sh, kernel="md_wino_prep_v2", ms=round(ms2, 4), gbs=round(12.0 * B * cin * S ** 3 / ms2 / 1e6, 1)))
             print(json.dumps(rows[-1]), flush=True)
-        if a.f43:
-            ww43 = ops.WinoWeight43(w, dev)
-            t43 = ops.wino43_prep([(x, cin)], ac, True, False, B, S)
-            ms = timed(lambda: ops.wino43_prep([(x, cin)], ac, True, False, B, S))
-            rows.append(dict(shape=sh, kernel="md_wino43_prep", ms=round(ms, 4), gbs=round(10.0 * B * cin * S ** 3 / ms / 1e6, 1)))
-            print(json.dumps(rows[-1]), flush=True)
-            for rep in range(2):
-                ms = timed(lambda: ops.conv3_wino43(ww43, t43, B, S, bias=bias, bias_bstride=cout, residual=None if a.no_res else res,
-                                                    res_bstride=0 if a.no_res else cout * S ** 3,
-                                                    stats=None if a.no_stats else stats, out=out))
-                rows.append(dict(shape=sh, kernel="md_conv3_wino43", ms=round(ms, 4), tflops_alg=round(flops / ms / 1e9, 1),
-                                 issued_frac_of_peak=round(flops * 0.5 * 3 / ms / 1e9 / 2500.0, 4)))
-                print(json.dumps(rows[-1]), flush=True)
-            t = ops.wino_prep([(x, cin)], ac, True, False, B, S)      # the two paths share one scratch buffer: restore T
         if a.f8 and 256 % S == 0:
             ww8, ww6 = ops.WinoWeightF8(w, dev), ops.WinoWeightF8(w, dev, "f6")
             kw = dict(bias=bias, bias_bstride=cout, residual=None if a.no_res else res, res_bstride=0 if a.no_res else cout * S ** 3,
