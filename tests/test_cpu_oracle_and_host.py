@@ -565,3 +565,27 @@ def test_round4_entry_points_reject_bad_arguments_without_a_gpu(hip_lib):
             pass
     # a scope never leaks: the process default is back, whatever happened inside
     assert (hip_ops.PRECISION, hip_ops.WINO_F8, hip_ops.DEFAULT_PRECISION) == before and not hip_ops._SCOPES
+
+
+def test_trained_like_state_dict_is_deterministic_and_compensated():
+    """synth.trained_like_state_dict (the adversarial weights of the round-5 parity gate): same keys / shapes as the template, bit-identical
+    between calls, heavy-tailed conv weights, and every rescaled GroupNorm is compensated in its consumer: gamma_c * rms(W[:, c]) keeps
+    the spread of the un-rescaled pair (every channel keeps mattering) while gamma itself spans ~2^6."""
+    import torch
+    from meshdiffusion_amd import synth
+    from meshdiffusion_amd.lib.diffusion.models import ddpm_res64, utils as mutils  # noqa: F401
+    cfg = synth.small_config(); cfg.device = torch.device("cpu")
+    tmpl = mutils.create_model(cfg, use_parallel=False).state_dict()
+    a = synth.trained_like_state_dict(tmpl, grid_mask=synth.synthetic_grid_mask(16))
+    b = synth.trained_like_state_dict(tmpl, grid_mask=synth.synthetic_grid_mask(16))
+    assert list(a) == list(tmpl) and all(a[k].shape == tmpl[k].shape and torch.equal(a[k], b[k]) for k in a)
+    gk = [k for k in a if k.endswith("GroupNorm_0.weight") and k.replace("GroupNorm_0.weight", "Conv_0.weight") in a]
+    assert len(gk) >= 5
+    for k in gk:
+        g, w = a[k].abs(), a[k.replace("GroupNorm_0.weight", "Conv_0.weight")]
+        assert float(g.max() / g.min()) > 8.0                                  # the GroupNorm scale really spreads
+        imp = g * w.pow(2).mean(dim=(0, 2, 3, 4)).sqrt()
+        assert float(imp.max() / imp.min()) < 8.0                               # ... and the consumer undoes it (up to gamma's own +-15 % and the weights' tails)
+    w = a[gk[0].replace("GroupNorm_0.weight", "Conv_0.weight")]
+    kurt = float(((w - w.mean()) ** 4).mean() / w.var() ** 2)
+    assert kurt > 4.0                                                           # Student-t tails (a uniform draw has 1.8, a normal one 3)

@@ -355,6 +355,28 @@ def test_unet_res64_trained_like_weights_vs_reference_golden(env):
         assert e_sub < TOL_EVAL_TRAINED and e_norm < TOL_EVAL_TRAINED and e_row < TOL_EVAL
 
 
+@pytest.mark.skipif(not os.path.exists(os.path.join(GOLD, "unet_res128_trained.npz")), reason="trained-like res128 golden not generated")
+def test_unet_res128_full_size_trained_like_weights_vs_reference_golden(env):
+    """The same adversarial gate for configs[3]'s network: ddpm_res128 at 128^3 on synth.trained_like_state_dict against the
+    unmodified reference's output (oracle/gen_golden.py --only trained), in the config's own arithmetic."""
+    from meshdiffusion_amd.config import get_config_res128
+    synth, mutils = env["synth"], env["mutils"]
+    gold = np.load(os.path.join(GOLD, "unet_res128_trained.npz"))
+    cfg = get_config_res128(); cfg.device = torch.device("cuda")
+    model = mutils.create_model(cfg).eval()
+    sd = synth.trained_like_state_dict(model.module.state_dict(), seed=int(gold["sd_seed"]), grid_mask=synth.synthetic_grid_mask(128))
+    model.module.load_state_dict(sd, strict=True)
+    del sd
+    x = synth.synthetic_inputs(1, 4, 128, seed=int(gold["x_seed"])).cuda()
+    with torch.no_grad():
+        y = model(x, torch.tensor(gold["labels"]).cuda()).cpu()
+    e_sub = rel_l2(y[:, :, ::8, ::8, ::8], gold["y_sub"])
+    e_row = rel_l2(y[0, :, 63, 17, :], gold["y_row"])
+    e_norm = abs(float(y.double().norm()) - float(gold["y_norm"])) / float(gold["y_norm"])
+    print(f"res128 full size, trained-like weights ({cfg.model.hip_precision}) vs reference golden: sub {e_sub:.3e} row {e_row:.3e} norm {e_norm:.3e}")
+    assert e_sub < TOL_EVAL and e_row < TOL_EVAL and e_norm < TOL_EVAL
+
+
 def test_precision_is_a_property_of_the_model_not_of_the_process(env):
     """res64 (f16f8 here, to tell it from the other) and res128 (its config's own hip_precision) evaluated in both
     orders: every model's Winograd launches are the ones ITS config names, whatever ran before; the process default is untouched and
