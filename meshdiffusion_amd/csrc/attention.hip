@@ -29,6 +29,31 @@ constexpr int AT_V_ITEMS = (AT_TK / 8) * 2 * AT_C;   // 2048 uint4 (32 KB)
 constexpr int AT_PF = AT_K_ITEMS / AT_THREADS;       // 8 K items + 8 V items per thread and tile
 constexpr int AT_BUF_BYTES = (AT_K_ITEMS + AT_V_ITEMS) * 16;   // 64 KB per buffer
 typedef __attribute__((ext_vector_type(4))) short bf16x4;
+
+// Round 5: the wave's Q operand (128 registers) lives in AccVGPRs and feeds the S^T MFMAs from there.  The MFMA encoding takes either
+// register file for its A / B sources, but hipcc only ever allocates the accumulator there: with Q in the architectural file the kernel
+// needed ~330 VGPRs, so hipcc parked half of Q in AccVGPRs itself and copied it back before every use -- 208 v_accvgpr_read out of
+// ~620 instructions per 32-key tile, in a kernel that is bound by the instruction issue of its single wave per SIMD.  The S^T MFMAs are
+// therefore written as inline asm with an "a" (AccVGPR) B operand; Q is pinned there once after its load.  AT_Q_AGPR=0: the round-4 form.
+#ifndef AT_Q_AGPR
+#define AT_Q_AGPR 1
+#endif
+// acc += A * B with B in AccVGPRs.  Three of these on one accumulator issue back to back like the builtin's (same opcode, SrcC = vDst:
+// no wait state needed); the accumulators are read by VALU only behind at_mfma_fence().
+__device__ __forceinline__ void at_mfma_bq(f32x16& acc, const bf16x8& a, const bf16x8& bq) {
+#if AT_Q_AGPR
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(bq));
+#else
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bq, acc, 0, 0, 0);
+#endif
+}
+// hipcc does not see inside the asm: the wait states between an MFMA's register write and a VALU read of it (up to 19 for a 16-pass
+// MFMA; the compiler inserts them for its own MFMAs) are spelled out once per tile, tied to the accumulators so that nothing moves across
+__device__ __forceinline__ void at_mfma_fence(f32x16& s0, f32x16& s1) {
+#if AT_Q_AGPR
+  asm volatile("s_nop 15\n\ts_nop 3" : "+v"(s0), "+v"(s1));
+#endif
+}
 }  // namespace
 
 __global__ __launch_bounds__(AT_THREADS) void md_attn_fwd_kernel(const uint4* __restrict__ qk, const uint4* __restrict__ vT,
@@ -54,6 +79,10 @@ __global__ __launch_bounds__(AT_THREADS) void md_attn_fwd_kernel(const uint4* __
     qhi[ks] = __builtin_bit_cast(bf16x8, qkb[((int64_t)(g * 2 + 0)) * N + q0 + j]);
     qlo[ks] = __builtin_bit_cast(bf16x8, qkb[((int64_t)(g * 2 + 1)) * N + q0 + j]);
   }
+#if AT_Q_AGPR
+#pragma unroll
+  for (int ks = 0; ks < AT_C / 16; ++ks) asm volatile("" : "+a"(qhi[ks]), "+a"(qlo[ks]));      // Q -> AccVGPRs, for good
+#endif
   f32x16 oacc[AT_C / 32];
 #pragma unroll
   for (int rt = 0; rt < AT_C / 32; ++rt)
@@ -130,17 +159,20 @@ __global__ __launch_bounds__(AT_THREADS) void md_attn_fwd_kernel(const uint4* __
       }
       const bf16x8 khi = kf[ks & 1][0], klo = kf[ks & 1][1];
       if (ks & 1) {
-        s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(klo, qhi[ks], s1, 0, 0, 0);
-        s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(khi, qlo[ks], s1, 0, 0, 0);
-        s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(khi, qhi[ks], s1, 0, 0, 0);
+        at_mfma_bq(s1, klo, qhi[ks]);
+        at_mfma_bq(s1, khi, qlo[ks]);
+        at_mfma_bq(s1, khi, qhi[ks]);
       } else {
-        s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(klo, qhi[ks], s0, 0, 0, 0);
-        s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(khi, qlo[ks], s0, 0, 0, 0);
-        s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(khi, qhi[ks], s0, 0, 0, 0);
+        at_mfma_bq(s0, klo, qhi[ks]);
+        at_mfma_bq(s0, khi, qlo[ks]);
+        at_mfma_bq(s0, khi, qhi[ks]);
       }
+#if !AT_Q_AGPR
       if (ks + 1 < AT_C / 16) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
       __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+#endif
     }
+    at_mfma_fence(s0, s1);
     // the other buffer's last readers (tile t - 1) are behind the previous barrier: K of tile t + 1 goes in now, its V is requested
     if (more) { commit_k((t + 1) & 1); issue_v(t + 1); }
     // ---- online softmax of this query column (log2 domain: exp(x) = 2^(x log2 e), the 1/sqrt(C) scale folded in) ----
@@ -157,6 +189,12 @@ __global__ __launch_bounds__(AT_THREADS) void md_attn_fwd_kernel(const uint4* __
       const float corr = __builtin_amdgcn_exp2f(m_run - m_new);
       m_run = m_new;
       l_run *= corr;
+#if AT_Q_AGPR
+      // the accumulators live in AccVGPRs; hipcc hoisted the 128 v_accvgpr_read of this rarely taken branch to the loop head
+      // (every tile paid them).  An opaque redefinition inside the branch keeps the copies where they are needed.
+#pragma unroll
+      for (int rt = 0; rt < AT_C / 32; ++rt) asm volatile("" : "+a"(oacc[rt]));
+#endif
 #pragma unroll
       for (int rt = 0; rt < AT_C / 32; ++rt)
 #pragma unroll
