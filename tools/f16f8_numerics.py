@@ -135,7 +135,7 @@ def one_conv():
         print("  Winograd f16f8, weight pre-scale 2^%-2d (auto: 2^%d)  %.3e" % (sw, weight_exp(w), rel(wino_conv(x, w, lambda t, g: conv_f16f8(t, g, sw)), ref)))
 
 
-def unet(seeds, weights="sensitised"):
+def unet(seeds, weights="sensitised", span=3.0):
     from meshdiffusion_amd import synth
     from meshdiffusion_amd.config import get_config_res64
     from meshdiffusion_amd.lib.diffusion.models import ddpm_res64, utils as mutils  # noqa: F401
@@ -144,7 +144,8 @@ def unet(seeds, weights="sensitised"):
     R = cfg.data.image_size
     model = mutils.create_model(cfg, use_parallel=False)
     if weights == "trained":
-        sd = synth.trained_like_state_dict(model.state_dict(), grid_mask=synth.synthetic_grid_mask(R))
+        sd = synth.trained_like_state_dict(model.state_dict(), grid_mask=synth.synthetic_grid_mask(R), span=span)
+        weights = f"trained-like (GroupNorm spread 2^+-{span:g})"
     else:
         sd = synth.sensitised_state_dict(model.state_dict(), seed=1234, grid_mask=synth.synthetic_grid_mask(R))
     del model
@@ -276,6 +277,7 @@ if __name__ == "__main__":
     ap.add_argument("--seeds", default="42")
     ap.add_argument("--weights", default="sensitised", choices=["sensitised", "trained"],
                     help="synth.sensitised_state_dict (i.i.d.) or synth.trained_like_state_dict (heavy tails, 2^U(-3,3) GroupNorm gammas)")
+    ap.add_argument("--span", type=float, default=3.0, help="--weights trained: per-channel GroupNorm scales 2^U(-span, span)")
     ap.add_argument("--audit", action="store_true", help="compare the equaliser's static activation estimate with the operands of one forward")
     a = ap.parse_args()
     torch.set_num_threads(a.threads)
@@ -284,4 +286,4 @@ if __name__ == "__main__":
         sys.exit(0)
     one_conv()
     if a.unet:
-        unet([int(s) for s in a.seeds.split(",")], a.weights)
+        unet([int(s) for s in a.seeds.split(",")], a.weights, a.span)
