@@ -16,6 +16,7 @@ outputs are stored):
   sampler_res128_b2.npz       BASELINE config #4: res128, B=2, first 2 ancestral steps
   train_grads.npz    reference loss function (train mode): loss + per-parameter gradient norms / samples
   train_grads_b2.npz the same for the real res64 network at B = 2 (--only train_b2)
+  train_grads_trained.npz the same at B = 1 on the adversarial trained-like weights (--only train_trained)
   dataset.npz        reference ShapeNetDMTetDataset items (augmentation on/off) for seeded on-disk grids
   dmtet.npz          reference DMTet.__call__ on the shipped 64-grid: counts, hashes, samples
   64_tets_cropped.npz  the tet-grid DATA asset (vertices/indices), copied verbatim
@@ -532,7 +533,7 @@ class fixed_draws:
         torch.randint, torch.randn_like = self.ri, self.rl
 
 
-def gen_train(full, b2_only=False):
+def gen_train(full, b2_only=False, trained_only=False):
     """Loss and parameter gradients of the UNMODIFIED reference loss function (lib/diffusion/losses.py:54-85, train
     mode, dropout 0) for the small res64/res128 configs and -- `full` -- the real res64 network at B=1.
     Stored per parameter: gradient norm and a strided sample of <= 256 entries."""
@@ -548,12 +549,23 @@ def gen_train(full, b2_only=False):
         # the reference's autograd, not to one block
         from meshdiffusion_amd.config import get_config_res64
         cases = [("res64_b2", get_config_res64(), 2, 1234)]
+    if trained_only:
+        # train_grads_trained.npz: the real res64 network at B = 1 on the adversarial trained-like weights (the training path runs
+        # bf16x3, which has no block scale to upset: this pins that claim to the reference's autograd)
+        from meshdiffusion_amd.config import get_config_res64
+        cases = [("res64_trained", get_config_res64(), 1, 4321)]
     out = {}
     for name, cfg, B, sd_seed in cases:
         cfg.device = torch.device("cpu")
         cfg.model.dropout = 0.0
         R = cfg.data.image_size
-        sd = make_sd(cfg, R, seed=sd_seed)
+        if name.endswith("_trained"):
+            from meshdiffusion_amd.lib.diffusion.models import ddpm_res64, utils as mutils  # noqa: F401
+            tmpl = mutils.create_model(ConfigDict(cfg), use_parallel=False).state_dict()
+            sd = synth.trained_like_state_dict(tmpl, seed=sd_seed, grid_mask=synth.synthetic_grid_mask(R))
+            del tmpl
+        else:
+            sd = make_sd(cfg, R, seed=sd_seed)
         model = ref_model(rmutils, cfg, sd)
         batch, labels, noise, mask = train_step_inputs(B, R, seed=2024)
         sde = rsde.VPSDE(beta_min=cfg.model.beta_min, beta_max=cfg.model.beta_max, N=cfg.model.num_scales)
@@ -575,7 +587,8 @@ def gen_train(full, b2_only=False):
             out[f"{name}/{n}/sample"] = g[::stride][:256].numpy().copy()
             gsq += float(g.double().square().sum())
         out[f"{name}_gnorm"] = np.float64(gsq ** 0.5)
-    np.savez_compressed(os.path.join(GOLD, "train_grads_b2.npz" if b2_only else "train_grads.npz"), **out)
+    fname = "train_grads_trained.npz" if trained_only else ("train_grads_b2.npz" if b2_only else "train_grads.npz")
+    np.savez_compressed(os.path.join(GOLD, fname), **out)
 
 
 def dataset_inputs(tmp, R=8):
@@ -619,7 +632,7 @@ def gen_dataset():
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-res64", action="store_true")
-    ap.add_argument("--only", choices=["unet", "dmtet", "dataset", "train", "train_b2", "graded", "ddim", "trained"], default=None)
+    ap.add_argument("--only", choices=["unet", "dmtet", "dataset", "train", "train_b2", "train_trained", "graded", "ddim", "trained"], default=None)
     ap.add_argument("--graded", default="config1,cond32,res128", help="which graded-size sampler fixtures to (re)generate")
     a = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
@@ -632,6 +645,8 @@ if __name__ == "__main__":
         gen_train(full=not a.skip_res64)
     if a.only in (None, "train_b2"):
         gen_train(full=False, b2_only=True)
+    if a.only == "train_trained" or (a.only is None and not a.skip_res64):
+        gen_train(full=False, trained_only=True)
     if a.only in (None, "unet"):
         gen_unet_and_sampler(a.skip_res64)
     if a.only in (None, "ddim"):

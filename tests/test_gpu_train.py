@@ -150,13 +150,15 @@ def test_whole_unet_backward_and_train_step_vs_oracle_autograd(hip_lib, arch, B)
     assert len(moved) == len(grads) and state["step"] == 2 and ema.num_updates == 1
 
 
-@pytest.mark.parametrize("case", ["small_res64", "small_res128", "res64", "res64_b2"])
+@pytest.mark.parametrize("case", ["small_res64", "small_res128", "res64", "res64_b2", "res64_trained"])
 def test_loss_and_gradients_vs_reference_golden(hip_lib, case):
     """The UNMODIFIED reference loss function run on the CPU by oracle/gen_golden.py (train mode, dropout 0, fixed
     labels/noise) pins loss and every parameter gradient of the HIP path -- `res64` is the real 364 M-parameter
     network at B = 1 (the autograd reference takes 40 s on the build host; here only its recorded norms/samples);
     `res64_b2` (train_grads_b2.npz) the same at B = 2, where the 32^3 levels run through the Winograd forward /
-    data-gradient kernels as well (hip_ops.wino_ok), so those are pinned to the reference's autograd at two grid sizes."""
+    data-gradient kernels as well (hip_ops.wino_ok), so those are pinned to the reference's autograd at two grid sizes;
+    `res64_trained` (train_grads_trained.npz) the real network at B = 1 on the adversarial trained-like weights of round 5 (heavy tails,
+    2^U(-3,3) GroupNorm gammas): training runs bf16x3, which has no block scale to upset."""
     import os
     from conftest import GOLD
     from oracle.gen_golden import fixed_draws, train_step_inputs
@@ -164,15 +166,18 @@ def test_loss_and_gradients_vs_reference_golden(hip_lib, case):
     from meshdiffusion_amd.config import get_config_res64
     from meshdiffusion_amd.lib.diffusion import losses, sde_lib
     from meshdiffusion_amd.lib.diffusion.models import ddpm_res64, ddpm_res128, utils as mutils  # noqa: F401
-    gold = np.load(os.path.join(GOLD, "train_grads_b2.npz" if case == "res64_b2" else "train_grads.npz"))
+    gfile = {"res64_b2": "train_grads_b2.npz", "res64_trained": "train_grads_trained.npz"}.get(case, "train_grads.npz")
+    if not os.path.exists(os.path.join(GOLD, gfile)):
+        pytest.skip(f"{gfile} not generated")
+    gold = np.load(os.path.join(GOLD, gfile))
     cfg = {"small_res64": synth.small_config, "small_res128": synth.small_config_res128, "res64": get_config_res64,
-           "res64_b2": get_config_res64}[case]()
+           "res64_b2": get_config_res64, "res64_trained": get_config_res64}[case]()
     cfg.device = torch.device("cuda")
     cfg.model.dropout = 0.0
     R, B = cfg.data.image_size, int(gold[f"{case}_B"])
     model = mutils.create_model(cfg)
-    sd = synth.sensitised_state_dict(model.module.state_dict(), seed=int(gold[f"{case}_sd_seed"]),
-                                     grid_mask=synth.synthetic_grid_mask(R))
+    make = synth.trained_like_state_dict if case.endswith("_trained") else synth.sensitised_state_dict
+    sd = make(model.module.state_dict(), seed=int(gold[f"{case}_sd_seed"]), grid_mask=synth.synthetic_grid_mask(R))
     model.module.load_state_dict(sd, strict=True)
     del sd
     batch, labels, noise, mask = train_step_inputs(B, R, seed=2024)
