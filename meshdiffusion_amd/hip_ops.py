@@ -52,6 +52,7 @@ def _decode(mode):
 # the CURRENT arithmetic: PRECISION = operand format of the direct kernels, WINO_F8 = False | "f8" | "f6" (cross-term format of the
 # inference Winograd convs).  Written only by set_precision (process default) and precision_scope (a model call).
 PRECISION, WINO_F8 = _decode(DEFAULT_PRECISION)
+TRAINING_SCOPE = False          # inside precision_scope(training=True): a training forward / backward of a model
 _SCOPES = []
 
 
@@ -75,17 +76,17 @@ class precision_scope:
             mode = "bf16x3"
         else:
             mode = FORCE_PRECISION or mode or DEFAULT_PRECISION
-        self.state = _decode(mode)
+        self.state = _decode(mode) + (bool(training),)
 
     def __enter__(self):
-        global PRECISION, WINO_F8
-        _SCOPES.append((PRECISION, WINO_F8))
-        PRECISION, WINO_F8 = self.state
+        global PRECISION, WINO_F8, TRAINING_SCOPE
+        _SCOPES.append((PRECISION, WINO_F8, TRAINING_SCOPE))
+        PRECISION, WINO_F8, TRAINING_SCOPE = self.state
         return self
 
     def __exit__(self, *exc):
-        global PRECISION, WINO_F8
-        PRECISION, WINO_F8 = _SCOPES.pop()
+        global PRECISION, WINO_F8, TRAINING_SCOPE
+        PRECISION, WINO_F8, TRAINING_SCOPE = _SCOPES.pop()
         return False
 
 
@@ -487,13 +488,18 @@ def wino_equaliser(gamma, beta, w):
     return eq
 
 
-WINO_MIN_WGS = int(os.environ.get("MD_WINO_MIN_WGS", "256"))   # fewest workgroups the Winograd kernel is launched with
+# fewest workgroups the Winograd kernel is launched with.  256 (one per CU) through round 4; with the f16f6 kernel half a chip of Winograd
+# workgroups beats the direct bf16x3 kernel with split-K: res64 B = 1 15.00 -> 14.50 ms per step at 128 (the 32^3 level), 14.59 at 64, 15.38 at
+# 32 (profiles/r05_b1_wino_floor.txt); sampling at batches >= 2 of the registered configs is unaffected (every level already has >= 256).
+# Training steps (precision_scope(training=True)) keep 256: their kernels are the ones the gradient goldens and the B = 8 bench pinned.
+WINO_MIN_WGS = int(os.environ.get("MD_WINO_MIN_WGS", "128"))
+WINO_MIN_WGS_TRAIN = int(os.environ.get("MD_WINO_MIN_WGS_TRAIN", "256"))
 
 
 def wino_ok(rows, kdim, S, B):
     """Shapes md_conv3_wino takes AND fills the chip with (one workgroup per CU, 128 rows x 4x8x8 positions each)."""
     return (WINO and PRECISION == "bf16x3" and rows % 128 == 0 and kdim % 32 == 0 and S % 8 == 0
-            and B * (S ** 3 // 256) * (rows // 128) >= WINO_MIN_WGS)
+            and B * (S ** 3 // 256) * (rows // 128) >= (max(WINO_MIN_WGS, WINO_MIN_WGS_TRAIN) if TRAINING_SCOPE else WINO_MIN_WGS))
 
 
 WGRAD_NIN = os.environ.get("MD_WGRAD_NIN", "1") == "1"   # NIN weight gradients straight from S16B tensors (md_wgrad_nin)
