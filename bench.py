@@ -97,6 +97,8 @@ def main():
     a = parse()
     if a.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
+    if a.steps < 1 or a.warmup < 0:
+        raise SystemExit("--steps must be >= 1 and --warmup >= 0: the line reports the time of exactly --steps timed steps")
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return self_launch(a)
     rank = int(os.environ.get("RANK", "0"))

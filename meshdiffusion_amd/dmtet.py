@@ -108,6 +108,11 @@ def _mt_workspace(nbytes, device):
     return buf
 
 
+def release_workspace():
+    """Drop the per-stream scratch buffers of md_marching_tets (the next call allocates again)."""
+    _MT_WORKSPACE.clear()
+
+
 def marching_tets_batch(pos, sdf, tables):
     """pos [M,N,3] f32, sdf [M,N] f32 on the GPU -> (MeshBatch, MeshCounts): meshes[m] = (verts [V,3], faces [F,3] int64,
     face_tet [F]), counts[m] = (V, F, 1-triangle tets, 2-triangle tets).  No host synchronisation inside the call: the counts
