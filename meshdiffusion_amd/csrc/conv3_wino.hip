@@ -34,12 +34,10 @@ constexpr int WN_TZ = 4, WN_TY = 8, WN_TX = 8;          // output tile; 4 pairs 
 constexpr int WN_TPOS = 6 * 10 * 4;                      // 240 transformed halo entries (dz, hy, pair) per (k-group, plane)
 constexpr int WN_HBUF = 4 * WN_TPOS * 16;                // 15360 B: [h 2][plane 2][240][16 B] = one chunk of one frequency
 constexpr int WN_NDMA = WN_HBUF / 1024;                  // 15 pieces of 1 KB (64 lanes x 16 B) per chunk and wave
-constexpr int WN_XSTRIDE = 36;                           // floats per (freq, column) row of the exchange area (32 + pad)
-constexpr int WN_XREGION = 4 * 128 * WN_XSTRIDE;         // floats: [f 4][col 128][36]
-constexpr int WN_RED = 4 * 2 * 32 * 2;                   // floats: [wave][DPP row of a half wave][channel][sum, sumsq]
+constexpr int WN_RED = 4 * 32 * 2;                       // floats: [wave][channel][sum, sumsq]
 constexpr int WN_WAVE_LDS = 2 * WN_HBUF;                 // 30720 B private to a wave: two halo buffers
-constexpr int WN_EPI_BYTES = 2 * WN_XREGION * 4 + 2 * WN_RED * 4;                                   // 151552 B
-constexpr int WN_LDS_BYTES = 4 * WN_WAVE_LDS > WN_EPI_BYTES ? 4 * WN_WAVE_LDS : WN_EPI_BYTES;       // 151552 B
+constexpr int WN_LDS_BYTES = 4 * WN_WAVE_LDS + 4 * WN_NDMA * 64 * 4;      // 138240 B: halo buffers + the f16f8 loop's offset tables; the epilogue's
+                                                                          // exchange area (2 x 65792 B + statistics) aliases them
 
 __device__ const uint4 wn_zero16 = {0u, 0u, 0u, 0u};     // source of halo entries outside the grid
 
@@ -223,16 +221,30 @@ typedef int wn_i32x4 __attribute__((ext_vector_type(4)));
 // in the fp16 mix, tools/probes/f6_probe.hip: 0.85 of the f16f8 pair-step on random data).  Same geometry, loads, LDS image and
 // schedule: the 32-byte fragment a lane assembles from its two 16-byte items is [6 registers of codes | the block's E8M0 scale |
 // 0], and register 6 of either fragment is that MFMA's per-lane scale operand.
-template <int ABL, bool F8 = false, bool F6 = false>
+// RES: the launch has a residual operand (compile-time: with the request behind a run-time branch hipcc cannot count the loads in
+// flight and waits with vmcnt(0) -- for the NEXT round's prefetch and the round's own stores as well, profiles/r06_wino_epilogue_ab.txt)
+template <int ABL, bool F8 = false, bool F6 = false, bool RES = false>
 __global__ __launch_bounds__(WN_THREADS) void md_conv3_wino_kernel(const WnArgs A) {
   __shared__ __attribute__((aligned(16))) unsigned char wn_smem[WN_LDS_BYTES];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);       // = frequency f of this wave
   const int j = lane & 31, h = lane >> 5;
-  uint64_t stamp[10];
+  uint64_t stamp[12];      // 0..8: s_memtime (shader cycles) at the phase boundaries; 9: hardware ids; 10, 11: s_memrealtime (100 MHz) at start / end
   auto mark = [&](int k) { if constexpr (ABL & 128) stamp[k] = __builtin_amdgcn_s_memtime(); };
+  if constexpr (ABL & 128) stamp[10] = __builtin_amdgcn_s_memrealtime();
   mark(0);
 
+#ifndef W8_STAGGER
+#define W8_STAGGER 0      // A/B: > 0 delays the first workgroup of every CU by a hashed phase of up to that many shader cycles (see conv3_main.hip)
+#endif
+  if constexpr (W8_STAGGER > 0) {
+    const unsigned lin = blockIdx.x + gridDim.x * blockIdx.y;
+    if (lin < 256u) {
+      const unsigned ph = (lin * 0x9E3779B1u) >> 24;
+      const uint64_t t_end = __builtin_amdgcn_s_memtime() + ((uint64_t)ph * (uint64_t)W8_STAGGER >> 8);
+      while (__builtin_amdgcn_s_memtime() < t_end) __builtin_amdgcn_s_sleep(16);
+    }
+  }
   const int D = A.D, H = A.H, W = A.W, Wp = W >> 1;
   const int64_t P = (int64_t)D * H * W, Ph = P >> 1;
   const int ntx = W / WN_TX, nty = H / WN_TY, ntz = D / WN_TZ;
@@ -690,124 +702,148 @@ __global__ __launch_bounds__(WN_THREADS) void md_conv3_wino_kernel(const WnArgs 
     if (keep == 123.456f) A.out[tid] = keep;
     return;
   }
+  // Exchange area (round 6): one region = [f 4][col 128][8 items of 16 B] with NO padding; item k (rows 4k .. 4k+3 of the round's
+  // 32) of column col sits at slot k ^ sigma(col), sigma = ((col & 1) << 2) | ((col >> 1) & 3), and frequency f starts at
+  // f * 1024 + {0, 0, 8, 16}[f] items: with that both sides are conflict-free (tests/test_cpu_kernel_layouts.py replays the
+  // ds_write_b128 / ds_read_b128 lane groups).
+  // Write side (MFMA layout): lane (j, h) holds column j of a column tile, rows 8 q + 4 h + {0..3} = item 2 q + h.
+  // Read side: this wave finishes column tile `wid` (output plane z0 + wid).  A lane owns ONE position of a tile row and ONE
+  // 16-byte half of its 8-channel item: lane bits [0] half, [3:1] x, [5:4] channel-group pair; its 8 slots are the 8 rows y0 + yr.
+  // So a global load / store instruction covers, per channel group, the 256 contiguous bytes of a whole tile row (8 full
+  // 128-byte lines per instruction).  Round 5 gave a lane 4 channels x the 8 positions of a row (y0 in one store, y1 in the
+  // next): 32 separate 32-byte runs per instruction, and the epilogue was bound by the address path -- 36 loads + 32 stores
+  // per wave at ~32 lines each (profiles/r06_wino_epilogue_ab.txt: removing every exposed latency from the rounds left the
+  // tile time where it was).  Price: an output needs 3 of the 4 frequencies (y0 = m0 + m1 + m2, y1 = m1 - m2 - m3), so a
+  // lane reads 3 items per output instead of 4 per two -- 24 ds_read_b128 per round instead of 16, from an LDS that idles.
+  constexpr int XF_ITEMS = 1024, XREG_FLOATS = (4 * XF_ITEMS + 16) * 4;
+  static_assert(2 * XREG_FLOATS * 4 + 2 * WN_RED * 4 <= WN_LDS_BYTES, "two exchange regions + the statistics area fit");
   float* xreg = (float*)wn_smem;
-  float* red = xreg + 2 * WN_XREGION;
+  float* red = xreg + 2 * XREG_FLOATS;
   const int rows_total = A.cout;
   float* outp = A.out + (int64_t)b * rows_total * P;
   const float* resp = A.residual ? A.residual + (int64_t)b * A.res_bstride : nullptr;
   const float* biasp = A.bias ? A.bias + (int64_t)b * A.bias_bstride : nullptr;
   const bool want_stats = (ABL & 128) ? false : A.stats != nullptr;
-  // Write side (MFMA layout): lane (j, h) holds column j of a column tile, rows 8 q + 4 h + {0..3}.
-  // Read side: this wave finishes column tile `wid` (output plane z0 + wid).  A lane takes FOUR output channels
-  // (4 cq .. 4 cq + 3: one 16-byte store per position) of the EIGHT positions of one tile row (y0 + yr, the 4 pairs along
-  // w), so that the GroupNorm sums of a channel are mostly in-lane adds: 8 positions per lane, then 2 DPP steps over the 4
-  // lanes of a DPP row that share the channel quad (the first form held 16 channels x 2 positions per lane: 32 values x 4
-  // DPP steps per round, a dependent chain that was 1/4 of the epilogue).  Lane bits: [1:0] cq low, [3:2] yr low, [4] yr
-  // high, [5] cq high -- the 16 lanes of a ds_read_b128 group read 16 different 16-byte bank groups (row stride 36 floats:
-  // (4 yr + pr) * 9 + cq = 4 yr + cq mod 16).
-  const int cq = (lane & 3) | ((lane >> 5) << 2), yr = (lane >> 2) & 7;
-  // positions: plane z0 + wid, row y0 + yr, x = x0 + 2 pr + {0, 1}
-  const int64_t gp0 = ((int64_t)(z0 + wid) * H + (y0 + yr)) * W + x0;
+  const int half = lane & 1, xq = (lane >> 1) & 7, cgp = lane >> 4;      // read side
+  const int cq = 2 * cgp + half, prr = xq >> 1;
+  const bool odd = xq & 1;                                                // y1 lanes
+  const float sgn = odd ? -1.f : 1.f;
+  // positions: plane z0 + wid, row y0 + yr, x = x0 + xq
+  const int64_t gp0 = ((int64_t)(z0 + wid) * H + y0) * W + x0 + xq;
   auto flush_stats = [&](int r) {     // after the barrier that follows round r's red[] writes: 64 fp64 atomics
     if (tid < 64) {
       const int ch = tid >> 1, which = tid & 1;
       const float* rb = red + (r & 1) * WN_RED;
       float sum = 0.f;
 #pragma unroll
-      for (int k = 0; k < 8; ++k) sum += rb[(k * 32 + ch) * 2 + which];
+      for (int k = 0; k < 4; ++k) sum += rb[(k * 32 + ch) * 2 + which];
       const int row = rtb * 128 + r * 32 + ch;
       atomicAdd(A.stats + ((int64_t)b * rows_total + row) * 2 + which, (double)sum);
     }
   };
-  // bias / residual of round r are requested one round ahead (round 0: before the first barrier): the rounds are short and a
-  // load issued where it is used would expose one HBM latency per round
-  f32x4 pbias[2], pres[2][4][2];
-  auto prefetch = [&](int r) {
-    const int row = rtb * 128 + r * 32 + 4 * cq;
-    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-    pbias[r & 1] = biasp != nullptr ? *(const f32x4*)(biasp + row) : z;
-    if (resp != nullptr) {
-      const float* rp = resp + ((int64_t)(row >> 3) * P + gp0) * 8 + (row & 7);
+  // bias of all four rounds and the residual of rounds 0 and 1 are requested here, before the first barrier; round r + 2's
+  // residual at the end of round r, into the registers round r has just consumed (two rounds = ~5 k cycles ahead of its use).
+  // Everything is straight-line code, so hipcc counts the loads exactly (a wait never covers a later request or the round's own
+  // stores).  RES is a template parameter for the same reason: behind a run-time `if (residual)` the waits degrade to vmcnt(0).
+  // (All four rounds' residual up front = 128 registers next to the 96 of a round's exchange reads: 65 spilled.)
+  const bool has_bias = biasp != nullptr;
+  f32x4 pbias[4], pres[RES ? 2 : 1][8];
+  auto prefetch_res = [&](int r) {
+    if constexpr (RES) {
+      const float* rp = resp + ((int64_t)(rtb * 16 + r * 4 + cgp) * P + gp0) * 8 + 4 * half;
 #pragma unroll
-      for (int pr = 0; pr < 4; ++pr) {
-        pres[r & 1][pr][0] = *(const f32x4*)(rp + pr * 16);
-        pres[r & 1][pr][1] = *(const f32x4*)(rp + pr * 16 + 8);
-      }
-    } else {
-#pragma unroll
-      for (int pr = 0; pr < 4; ++pr) { pres[r & 1][pr][0] = z; pres[r & 1][pr][1] = z; }
+      for (int yr = 0; yr < 8; ++yr) pres[r & 1][yr] = *(const f32x4*)(rp + (int64_t)yr * W * 8);
     }
   };
-  auto quad_sum = [](float v) {       // over the 4 lanes of a DPP row with the same lane & 3 (row_ror 8, row_ror 4)
+  {
+    const float* bsrc = has_bias ? biasp : (const float*)A.wpk;      // always a valid address: the value is dropped at its use
+#pragma unroll
+    for (int r = 0; r < 4; ++r) pbias[r] = *(const f32x4*)(bsrc + rtb * 128 + r * 32 + 4 * cq);
+    prefetch_res(0);
+    prefetch_res(1);
+  }
+  auto row_sum8 = [](float v) {       // over the 8 lanes of a DPP row with the same lane & 1 (row_ror 8, 4, 2)
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, true));
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xF, 0xF, true));
     return v;
   };
-  // The accumulators of round r go to LDS in MFMA layout (AccVGPRs straight into ds_write_b128).
+  // write side: item addresses of this lane's four q (the xor term), + ct * 32 columns as an immediate
+  const int sj = ((j & 1) << 2) | ((j >> 1) & 3);
+  const int wbase_items = wid * XF_ITEMS + (wid == 2 ? 8 : (wid == 3 ? 16 : 0)) + j * 8;
   auto write_round = [&](int r) {
-    float* xw = xreg + (r & 1) * WN_XREGION;
+    float* xw = xreg + (r & 1) * XREG_FLOATS;
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct)
+    for (int q = 0; q < 4; ++q) {
+      float* pq = xw + (wbase_items + ((2 * q + h) ^ sj)) * 4;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
+      for (int ct = 0; ct < 4; ++ct) {
         f32x4 v;
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = acc[r][ct][q * 4 + e];
-        *(f32x4*)(xw + ((wid * 128 + ct * 32 + j) * WN_XSTRIDE + 8 * q + 4 * h)) = v;
+        *(f32x4*)(pq + ct * 32 * 8 * 4) = v;
       }
+    }
   };
-  prefetch(0);
+  // read side: column wid * 32 + yr * 4 + prr; sigma(col) = ((prr & 1) << 2) | ((yr & 1) << 1) | (prr >> 1)
+  const int rcol_items = (wid * 32 + prr) * 8;
+  const int rx0 = cq ^ (((prr & 1) << 2) | (prr >> 1)), rx1 = rx0 ^ 2;                       // rows yr even / odd
+  const int offA = odd ? 2 * XF_ITEMS + 8 : 0, offC = odd ? 3 * XF_ITEMS + 16 : 2 * XF_ITEMS + 8;   // y0: m0, m1, m2; y1: m2, m1, m3
   __syncthreads();                                       // every wave is done with its private buffers (the exchange area aliases them)
   mark(3);
-  // (measured and dropped, profiles/r03_wino_epilogue_ab.txt: writing round r + 1 to the other region before round r is read and
-  // combined -- 2.878 vs 2.853 ms; pulling the first halo chunk of the workgroup that follows on this XCD into L2 at the end --
-  // 3.06 vs 2.85 ms: the lines are evicted before use and fetched twice)
+#ifndef W8_EPI_EARLYW
+#define W8_EPI_EARLYW 1     // A/B: 0 = round r + 1's accumulators go to LDS behind round r's combine and stores (their latency then sits in front of the barrier)
+#endif
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    float* xr = xreg + (r & 1) * WN_XREGION;
-    write_round(r);
-    if (r < 3) prefetch(r + 1);
+    const float* xr = xreg + (r & 1) * XREG_FLOATS;
+    if (!W8_EPI_EARLYW || r == 0) write_round(r);
     __syncthreads();
-#if defined(W8_FLUSH_LATE) && !W8_FLUSH_LATE
-    if (want_stats && r > 0) flush_stats(r - 1);
-#endif
-    f32x4 m[4][4];
+    f32x4 mA[8], mB[8], mC[8];
 #pragma unroll
-    for (int ff = 0; ff < 4; ++ff)
-#pragma unroll
-      for (int pr = 0; pr < 4; ++pr)
-        m[ff][pr] = *(const f32x4*)(xr + ((ff * 128 + wid * 32 + yr * 4 + pr) * WN_XSTRIDE + 4 * cq));
-    // the statistics of the round before (wave 0 only: 8 dependent LDS reads + 64 fp64 atomics) go BEHIND this round's reads in the
-    // LDS queue: issued first they delayed wave 0 -- and with it the next barrier -- by their latency every round
-#ifndef W8_FLUSH_LATE
-#define W8_FLUSH_LATE 1     // A/B: 0 = the round-3 order (statistics first)
-#endif
-    if (W8_FLUSH_LATE && want_stats && r > 0) flush_stats(r - 1);
-    const int row = rtb * 128 + r * 32 + 4 * cq;
-    float* op = outp + ((int64_t)(row >> 3) * P + gp0) * 8 + (row & 7);
-    const f32x4 bv = pbias[r & 1];
-    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1;
-#pragma unroll
-    for (int pr = 0; pr < 4; ++pr) {
-      f32x4 o0, o1;
-      if constexpr (F8) {       // the accumulators hold 2^sw x the products (the weights' pre-scale): an exact power of two
-        o0 = ((m[0][pr] + m[1][pr]) + m[2][pr]) * descale + bv + pres[r & 1][pr][0];
-        o1 = ((m[1][pr] - m[2][pr]) - m[3][pr]) * descale + bv + pres[r & 1][pr][1];
-      } else {
-        o0 = ((m[0][pr] + m[1][pr]) + m[2][pr]) + bv + pres[r & 1][pr][0];
-        o1 = ((m[1][pr] - m[2][pr]) - m[3][pr]) + bv + pres[r & 1][pr][1];
-      }
-      *(f32x4*)(op + pr * 16) = o0;
-      *(f32x4*)(op + pr * 16 + 8) = o1;
-      s1 += o0 + o1;
-      s2 += o0 * o0 + o1 * o1;
+    for (int yr = 0; yr < 8; ++yr) {
+      const float* pb = xr + (rcol_items + yr * 32 + ((yr & 1) ? rx1 : rx0)) * 4;
+      mA[yr] = *(const f32x4*)(pb + offA * 4);
+      mB[yr] = *(const f32x4*)(pb + XF_ITEMS * 4);
+      mC[yr] = *(const f32x4*)(pb + offC * 4);
     }
+    // the statistics of the round before (wave 0 only: 4 LDS reads + 64 fp64 atomics) go BEHIND this round's reads in the LDS queue
+    // (issued first they delayed wave 0 -- and with it the next barrier -- by their latency every round) and in front of the early write
+    if (want_stats && r > 0) flush_stats(r - 1);
+    if (W8_EPI_EARLYW && r < 3) {
+      // the other region's last readers (round r - 1) are behind this round's barrier: round r + 1's accumulators follow this
+      // round's reads into the LDS queue, and their write latency runs under the combine and the stores instead of in front of
+      // the next barrier (LDS executes a wave's accesses in order: the reads return first)
+      __builtin_amdgcn_sched_barrier(0);
+      write_round(r + 1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    float* op = outp + ((int64_t)(rtb * 16 + r * 4 + cgp) * P + gp0) * 8 + 4 * half;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 bv = has_bias ? pbias[r] : zero4;
+    f32x4 s1 = zero4, s2 = s1;
+#pragma unroll
+    for (int yr = 0; yr < 8; ++yr) {
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        // y0 = (m1 + m0) + m2, y1 = (m1 - m2) - m3: one code path, the sign is the lane's (exact: fma with +-1)
+        const float y = __builtin_fmaf(sgn, mC[yr][e], __builtin_fmaf(sgn, mA[yr][e], mB[yr][e]));
+        if constexpr (F8) o[e] = y * descale + bv[e];       // the accumulators hold 2^sw x the products (the weights' pre-scale): an exact power of two
+        else o[e] = y + bv[e];
+      }
+      if constexpr (RES) o += pres[r & 1][yr];
+      *(f32x4*)(op + (int64_t)yr * W * 8) = o;
+      s1 += o;
+      s2 += o * o;
+    }
+    if (r < 2) prefetch_res(r + 2);
     if (want_stats) {
       f32x4 a1, a2;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { a1[e] = quad_sum(s1[e]); a2[e] = quad_sum(s2[e]); }
-      if ((lane & 12) == 0) {         // one lane per (channel quad, half of the tile rows): 8 consecutive floats of red[]
-        float* rb = red + (r & 1) * WN_RED + ((wid * 2 + ((lane >> 4) & 1)) * 32 + 4 * cq) * 2;
+      for (int e = 0; e < 4; ++e) { a1[e] = row_sum8(s1[e]); a2[e] = row_sum8(s2[e]); }
+      if ((lane & 14) == 0) {         // one lane per channel quad: 8 consecutive floats of red[]
+        float* rb = red + (r & 1) * WN_RED + (wid * 32 + 4 * cq) * 2;
         const f32x4 w0 = {a1[0], a2[0], a1[1], a2[1]}, w1 = {a1[2], a2[2], a1[3], a2[3]};
         *(f32x4*)rb = w0;
         *(f32x4*)(rb + 4) = w1;
@@ -828,13 +864,14 @@ __global__ __launch_bounds__(WN_THREADS) void md_conv3_wino_kernel(const WnArgs 
     const unsigned lin0 = 0u;
 #endif
     if (lin >= lin0 && lin - lin0 < 1024u && lane == 0) {
-      uint64_t* dst = (uint64_t*)A.stats + ((size_t)(lin - lin0) * 4 + wid) * 10;
+      uint64_t* dst = (uint64_t*)A.stats + ((size_t)(lin - lin0) * 4 + wid) * 12;
       // the stores are waited for by the end of the kernel, so the last stamp is taken before them
       stamp[8] = __builtin_amdgcn_s_memtime();
+      stamp[11] = __builtin_amdgcn_s_memrealtime();
       stamp[9] = (uint64_t)(uint32_t)__builtin_amdgcn_s_getreg((31 << 11) | 4) |                 // HW_REG_HW_ID (CU / SE of the wave)
                  ((uint64_t)(uint32_t)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);        // HW_REG_XCC_ID
 #pragma unroll
-      for (int k = 0; k < 10; ++k) dst[k] = stamp[k];
+      for (int k = 0; k < 12; ++k) dst[k] = stamp[k];
     }
   }
 }
@@ -930,12 +967,14 @@ static int md_conv3_wino_f8_launch(bool f6, const void* t_in, const void* wpk, f
   const dim3 grid((unsigned)(tiles * batch), (unsigned)(cout / 128));
   MD_HIP_CLEAR_ERROR();
 #ifdef W8_STAMPS      // A/B build only (tools/bench_wino.py --f8 --stamps): `stats` receives the per-wave s_memtime stamps, no statistics
-  if (f6) hipLaunchKernelGGL((md_conv3_wino_kernel<128, true, true>), grid, dim3(WN_THREADS), 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL((md_conv3_wino_kernel<128, true>), grid, dim3(WN_THREADS), 0, (hipStream_t)stream, a);
+  constexpr int ABL_ = 128;
 #else
-  if (f6) hipLaunchKernelGGL((md_conv3_wino_kernel<0, true, true>), grid, dim3(WN_THREADS), 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL((md_conv3_wino_kernel<0, true>), grid, dim3(WN_THREADS), 0, (hipStream_t)stream, a);
+  constexpr int ABL_ = 0;
 #endif
+#define WN_LAUNCH8(F6_, RES_) hipLaunchKernelGGL((md_conv3_wino_kernel<ABL_, true, F6_, RES_>), grid, dim3(WN_THREADS), 0, (hipStream_t)stream, a)
+  if (f6) { if (residual) WN_LAUNCH8(true, true); else WN_LAUNCH8(true, false); }
+  else { if (residual) WN_LAUNCH8(false, true); else WN_LAUNCH8(false, false); }
+#undef WN_LAUNCH8
   MD_HIP_CHECK_LAUNCH();
   return MD_OK;
 }
@@ -967,9 +1006,13 @@ extern "C" int md_conv3_wino(const void* t_in, const void* wpk, float* out, cons
   const int tiles = (D / WN_TZ) * (H / WN_TY) * (W / WN_TX);
   MD_HIP_CLEAR_ERROR();
   const dim3 grid((unsigned)(tiles * batch), (unsigned)(cout / 128));
-#define WN_LAUNCH(A_) hipLaunchKernelGGL((md_conv3_wino_kernel<A_>), grid, dim3(WN_THREADS), 0, (hipStream_t)stream, a)
+#define WN_LAUNCH(A_) hipLaunchKernelGGL((md_conv3_wino_kernel<A_, false, false, true>), grid, dim3(WN_THREADS), 0, (hipStream_t)stream, a)
+  if (variant != 0 && residual == nullptr) return MD_ERR_UNSUPPORTED;      // the timing-only variants are built in the residual form
   switch (variant) {
-    case 0: WN_LAUNCH(0); break;
+    case 0:
+      if (residual) WN_LAUNCH(0);
+      else hipLaunchKernelGGL((md_conv3_wino_kernel<0, false, false, false>), grid, dim3(WN_THREADS), 0, (hipStream_t)stream, a);
+      break;
 #ifdef MD_BUILD_ABLATIONS      // timing-only variants for tools/bench_wino.py
     case 1: WN_LAUNCH(1); break;
     case 2: WN_LAUNCH(2); break;

@@ -1,7 +1,7 @@
 """Compile-time guards on the gfx950 code objects (hipcc cross-compiles without a GPU): register / LDS budgets the kernels'
 designs rely on, no scratch traffic, and the one compiler hazard this repo works around.
 
-* The Winograd conv kernels own a whole CU (one wave per SIMD, 512 registers, 151 552 B of LDS): a spill turns the loop's
+* The Winograd conv kernels own a whole CU (one wave per SIMD, 512 registers, 138 240 B of LDS): a spill turns the loop's
   in-order memory queue into a scratch queue (the persistent-workgroup experiment of round 4: 255 spilled registers, 30 % slower).
 * v_cvt_scalef32_2xpk16_fp6_f32 reads its 32 source registers while it writes its 6 destination registers; hipcc (ROCm 7.2) lets
   them overlap when the builtin is used directly (tools/probes/f6_probe.hip: two values of a block came out as +-7.5).
@@ -47,12 +47,20 @@ def _ranges(operand):
 def test_winograd_conv_kernels_fit_the_register_file_without_scratch(tmp_path):
     text = _asm("conv3_wino.hip", tmp_path)
     ks = {n: v for n, v in _kernels(text).items() if "md_conv3_wino_kernel" in n}
-    assert len(ks) == 3, list(ks)                                   # bf16x3, f16f8, f16f6
+    assert len(ks) == 6, list(ks)                                   # bf16x3, f16f8, f16f6, each with and without a residual operand
     for name, k in ks.items():
-        assert k["vgpr_count"] <= 512 and k["vgpr_spill_count"] == 0 and k["sgpr_spill_count"] == 0, (name, k)
+        assert k["vgpr_count"] <= 512 and k["vgpr_spill_count"] == 0 and k["sgpr_spill_count"] <= 2, (name, k)
         assert k["private_segment_fixed_size"] == 0, (name, k)
-        assert k["group_segment_fixed_size"] == 151552, (name, k)   # the exchange area; the halo buffers + offset table alias it
+        assert k["group_segment_fixed_size"] == 138240, (name, k)   # halo buffers + offset tables; the exchange area aliases them
     assert "scratch_" not in text
+    # the residual forms park one SGPR pair (the residual pointer) in a VGPR's lanes across the main loop: allowed OUTSIDE the MFMA
+    # loop only (a v_readlane / v_writelane between the first and the last MFMA of a kernel would sit in the issue stream)
+    for name in ks:
+        body = text[text.index(name + ":"):]
+        body = body[:body.index("s_endpgm")].split("\n")
+        mf = [i for i, ln in enumerate(body) if "v_mfma" in ln]
+        lanes = [i for i, ln in enumerate(body) if "v_readlane" in ln or "v_writelane" in ln]
+        assert all(i < mf[0] or i > mf[-1] for i in lanes), name
     # the weight packer of the f16f6 fragments uses the e2m3 conversion
     assert "v_cvt_scalef32_2xpk16_fp6_f32" in text
 

@@ -30,6 +30,7 @@ def main():
                                                        "the bf16x3 production kernel (same box, same clocks)")
     ap.add_argument("--no-stats", action="store_true", help="launch without the GroupNorm-sum epilogue")
     ap.add_argument("--no-res", action="store_true", help="launch without the residual operand")
+    ap.add_argument("--dump", default=None, help="with --stamps: save the raw stamp array of every shape to <dump>_<shape>.npy")
     ap.add_argument("--stamps", action="store_true", help="variant 128 (MD_BUILD_ABLATIONS=1): per-wave s_memtime stamps of the first 1024 workgroups")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -100,7 +101,7 @@ def main():
                              tflops_alg=round(flops / ms / 1e9, 1), issued_frac_of_peak=round(flops * 2 / 3 * 3 / ms / 1e9 / 2500.0, 4)))
             print(json.dumps(rows[-1]), flush=True)
         if a.stamps:
-            dbg = torch.zeros((1024, 4, 10), dtype=torch.int64, device=dev)
+            dbg = torch.zeros((1024, 4, 12), dtype=torch.int64, device=dev)
             for _ in range(2):
                 if a.f8:      # a library built with MD_EXTRA_DEFINES=-DW8_STAMPS: md_conv3_wino_f8 runs its stamping instantiation
                     t8 = ops.wino_prep([(x, cin)], ac, True, False, B, S, f8=True)
@@ -110,6 +111,9 @@ def main():
                 ops.conv3_wino(ww, t, B, S, bias=bias, bias_bstride=cout, residual=None if a.no_res else res,
                                res_bstride=0 if a.no_res else cout * S ** 3, stats=dbg, out=out, variant=128)
             torch.cuda.synchronize()
+            if a.dump:
+                import numpy as np
+                np.save(f"{a.dump}_{sh.replace(':', '_')}.npy", dbg.cpu().numpy())
             st = dbg.cpu().double()
             st = st[st[:, 0, 0] > 0]
             tt = st[:, :, :9]
@@ -123,6 +127,21 @@ def main():
                        phases_frac={n: round(float(d[:, :, k].mean() / wg.mean()), 4) for k, n in enumerate(names)},
                        loop_end_skew_ticks=round(float((tt[:, :, 2].max(1).values - tt[:, :, 2].min(1).values).mean()), 1),
                        first_gen_start_spread=round(float(tt[:256, :, 0].max() - tt[:256, :, 0].min()), 1))
+            # effective shader clock of a workgroup: s_memtime ticks per s_memrealtime tick (100 MHz); gap between consecutive workgroups of a CU in real time
+            rt0, rt1 = st[:, :, 10].min(1).values, st[:, :, 11].max(1).values
+            rep["wg_real_us_mean"] = round(float((rt1 - rt0).mean()) / 100.0, 2)
+            rep["shader_clock_ghz"] = round(float((wg / (rt1 - rt0).clamp_min(1)).mean()) * 0.1, 3)
+            hw = dbg.cpu()[: st.shape[0], 0, 9]
+            cu_real = {}
+            for i in range(st.shape[0]):
+                cu_real.setdefault(int(hw[i]) & ~0xF, []).append((float(rt0[i]), float(rt1[i])))   # same (XCC, SE, CU) id; wave slot masked
+            g2 = []
+            for v in cu_real.values():
+                v.sort()
+                g2 += [v[k + 1][0] - v[k][1] for k in range(len(v) - 1) if v[k + 1][0] - v[k][1] < 2000]      # < 20 us: really the next workgroup
+            if g2:
+                rep["real_gap_us_between_consecutive_wgs"] = round(sum(g2) / len(g2) / 100.0, 2)
+                rep["n_gaps"] = len(g2)
             # second generation: gap between a workgroup's end and the next start on the same CU (hw id + xcc id)
             ids = dbg.cpu()[:, 0, 9][: st.shape[0]]
             cu = {}
