@@ -54,6 +54,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=8, help="samples per GPU (configs[1]: 8)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--no-calibrate", action="store_true", help="skip the load-time calibration of the reduced-precision convs (the Upsample "
+                                                                "convs then stay in bf16x3 and the equalisers are the static ones)")
     ap.add_argument("--precision", default="f16f6", choices=["bf16x3", "fp16x2", "f16f8", "f16f6"],
                     help="arithmetic of the hot conv kernel for the headline number (DESIGN.md section 3): f16f6 = the package default "
                          "(config.model.hip_precision), f16f8 = its e4m3 form, bf16x3 = the round-1..3 arithmetic")
@@ -144,6 +146,9 @@ def main():
     else:
         sd_cpu = synth.sensitised_state_dict(model.module.state_dict(), seed=1234, grid_mask=synth.synthetic_grid_mask(R))
     model.module.load_state_dict(sd_cpu, strict=True)
+    # load-time calibration of the reduced-precision convs, as evaler.uncond_gen / cond_gen run it after restoring a checkpoint
+    # (measured equalisers, per-conv audit against bf16x3; untimed: it happens once per weight set): models/utils.calibrate_model
+    calibration = None if a.no_calibrate else mutils.calibrate_model(model, cfg)
     if not (rank == 0 and world == 1 and not a.no_cpu_baseline):
         sd_cpu = None
     sde = sde_lib.VPSDE(cfg.model.beta_min, cfg.model.beta_max, cfg.model.num_scales, device=dev)
@@ -338,6 +343,11 @@ def main():
             "roofline": roof, "whole_step": whole, "train_step": train, "other_configs": other,
             "hbm_bound_kernels": hbm_kernels, "cpu_baseline": cpu, "bf16x3_mode": fast,
             "setup_s": round(t_setup, 1),
+            "calibration": None if calibration is None else {
+                "what": "DDPMUNet3D.calibrate at load time (untimed): per-conv operand mean squares measured on noise batches at 3 timesteps, "
+                        "equalisers rebuilt from them, every reduced-precision conv audited against bf16x3; bar 4e-5",
+                "convs_measured": calibration["measured"], "worst_kept_rel_l2": round(calibration["worst"], 7),
+                "demoted_to_bf16x3": [list(d[:2]) for d in calibration["demoted"]]},
         }
         print(json.dumps(line), flush=True)
     if dist is not None:
@@ -540,6 +550,7 @@ def res128_step(dev, steps=3, warmup=2):
     sd = synth.sensitised_state_dict(model.module.state_dict(), seed=99, grid_mask=synth.synthetic_grid_mask(R))
     model.module.load_state_dict(sd, strict=True)
     del sd
+    calibration = mutils.calibrate_model(model, cfg, batch=1)
     sde = sde_lib.VPSDE(cfg.model.beta_min, cfg.model.beta_max, cfg.model.num_scales, device=dev)
     st = sampling.AncestralStepper(sde, (B, 4, R, R, R), device=dev, grid_mask=synth.synthetic_grid_mask(R).view(1, R, R, R).to(dev))
     fn = mutils.get_model_fn(model)
@@ -558,7 +569,9 @@ def res128_step(dev, steps=3, warmup=2):
            "dtype": launch_arithmetic(hip_ops, lambda: st.step(fn, x, warmup + steps), model.module.hip_precision),
            "ms_per_step": round(dt * 1e3, 2), "sample_steps_per_s": round(B / dt, 3), "steps": steps,
            "mfma_frac_step": round(B * FLOPS_PER_SAMPLE_STEP_RES128 / dt / (PEAK_BF16_TFLOPS * 1e12), 4),
-           "peak_hbm_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}
+           "peak_hbm_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
+           "calibration": None if calibration is None else {"convs_measured": calibration["measured"], "worst_kept_rel_l2": round(calibration["worst"], 7),
+                                                            "demoted_to_bf16x3": [list(d[:2]) for d in calibration["demoted"]]}}
     del model, st, x, xm
     torch.cuda.empty_cache()
     return out

@@ -41,7 +41,7 @@ extern "C" {
 #define MD_ERR_UNSUPPORTED (-2)
 #define MD_ERR_NO_DEVICE (-3)
 
-#define MD_ABI_VERSION 14
+#define MD_ABI_VERSION 15
 
 /* ---- tile configurations of md_gemm_conv (compile-time instantiations) ---- */
 enum {
@@ -297,10 +297,22 @@ int md_conv3_wino(const void* t_in, const void* wpk, float* out, const float* bi
  * md_wino_equaliser (csrc/wino_eq.hip): eq[c] = 2^round(log2(g_c / a_c) / 2), clamped to 2^+-14, with a_c = rms of
  *   silu(gamma_c z + beta_c) over z ~ N(0, 1) (64-point midpoint rule on [-6, 6]) -- what nn.GroupNorm + nn.SiLU
  *   (layers.py:652,660,676-681) hand the conv, per channel -- and g_c = rms of w[:, c, :, :, :]; w element (co, ci, t27) at
- *   w[co * s_row + ci * s_k + t27].  gamma / beta: the GroupNorm affine over the (concatenated) Cin input channels.
+ *   w[co * s_row + ci * s_k + t27].  gamma / beta: the GroupNorm affine over the (concatenated) Cin input channels.  The exponent is
+ *   additionally bounded by the fp16 headroom of the operand: eq[c] (8 |gamma_c| + |beta_c|) 2 < 2^15.
+ * md_wino_equaliser_measured (ABI 15): the same with a_c^2 = a2m[c], the MEASURED per-channel mean square of the operand (float [Cin]
+ *   from md_wino_operand_ms over a calibration evaluation); gamma / beta may both be NULL (a conv on a tensor no GroupNorm precedes:
+ *   Upsample, layers.py:611-623).  GroupNorm normalises groups of channels, so a channel's own scale inside its group -- which the
+ *   static estimate cannot see -- is part of the measurement.  All exponents are then shifted by one common u so that
+ *   max_c eq[c] sqrt(a2m[c]) = 2^0 (+-1/2): the operand's fp16 plane sits mid-range whatever the tensor's absolute magnitude.
+ * md_wino_operand_ms (ABI 15): ms[c] += mean over samples and positions of act(x[c])^2 for up to two concatenated F32B parts, act =
+ *   the conv's operand transform (x * ac[..][0] + ac[..][1], SiLU) or the identity (ac NULL); ms zeroed by the caller.
  */
 int md_wino_equaliser(const float* gamma, const float* beta, const float* w, int32_t cout, int32_t cin, int64_t s_row, int64_t s_k,
                       float* eq, void* stream);
+int md_wino_equaliser_measured(const float* gamma, const float* beta, const float* w, const float* a2m, int32_t cout, int32_t cin,
+                               int64_t s_row, int64_t s_k, float* eq, void* stream);
+int md_wino_operand_ms(const float* x1, const float* x2, int32_t c1, int32_t c2, const float* ac, int32_t silu, int32_t batch, int64_t P,
+                       float* ms, void* stream);
 int md_wino_prep_f8(const float* x1, const float* x2, int32_t c1, int32_t c2, const float* ac, int32_t silu, int32_t ups,
                     const float* eq, void* t_out, int32_t batch, int32_t D, int32_t H, int32_t W, void* stream);
 int64_t md_wino_weight_bytes_f8(int32_t cout, int32_t cin);
@@ -308,6 +320,19 @@ int md_wino_pack_weights_f8(const float* w, const float* eq, void* wpk, int32_t 
 int md_conv3_wino_f8(const void* t_in, const void* wpk, float* out, const float* bias, int64_t bias_bstride,
                      const float* residual, int64_t res_bstride, double* stats, int32_t batch, int32_t cin, int32_t cout,
                      int32_t D, int32_t H, int32_t W, void* stream);
+/*
+ * Training (ABI 15): the data-gradient convs of a step in the f16f6 arithmetic.
+ * md_wino_prep_dual_f6: as md_wino_prep_dual for ONE raw fp32 part (an output gradient; c % 16 == 0, W | 256), except that T is the
+ *   f16f6 operand of md_conv3_wino_f6 of `tscale` x the tensor (tscale a power of two: gradient magnitudes lifted into the fp16
+ *   plane's normal range); U (md_wgrad_wino's operand) and sums are those of the unscaled tensor, bit-identical to md_wino_prep_dual's.
+ * md_conv3_wino_f6_scaled: md_conv3_wino_f6 whose result is multiplied by out_scale (= 1 / tscale, exact).
+ * The weights: an MD_PACK_WINO_F6 job of md_pack_batch (fixed pre-scale, `flip` for the data-gradient orientation).
+ */
+int md_wino_prep_dual_f6(const float* x, int32_t c, void* t_out, void* u_out, float* sums, float tscale, int32_t batch, int32_t D,
+                         int32_t H, int32_t W, void* stream);
+int md_conv3_wino_f6_scaled(const void* t_in, const void* wpk, float* out, const float* bias, int64_t bias_bstride,
+                            const float* residual, int64_t res_bstride, double* stats, int32_t batch, int32_t cin, int32_t cout,
+                            int32_t D, int32_t H, int32_t W, float out_scale, void* stream);
 
 /*
  * The same convolution in the "f16f6" arithmetic: as f16f8, the two cross terms from MX block-scaled OCP e2m3 images (a K block = 16
@@ -357,6 +382,9 @@ int md_conv3_head(const float* x, const float* ac, const void* wpk, float* y, in
  *   tiled = 0    : one 16-byte item per thread; a job has ceil(n_items / 256) blocks
  *     kind MD_PACK_WPK : fields as the arguments of md_pack_weights (n_items = md_packed_weight_bytes / 16)
  *     kind MD_PACK_WINO: rows = cout, kdim = cin, s_row, s_k, flip as md_wino_pack_weights (n_items = md_wino_weight_bytes / 16)
+ *     kind MD_PACK_WINO_F6 (ABI 15): the f16f6 fragments of md_conv3_wino_f6 with a FIXED pre-scale 2^prec in place of the max |w|
+ *                        pass of md_wino_pack_weights_f6 (no equaliser), `flip` as above; n_items = md_wino_weight_bytes_f8 / 16
+ *                        (fragments + the 256-byte header, which the job writes)
  *   tiled = 1    : MD_PACK_WPK jobs only, taps > 1 with s_tap = +-1, 16 * kc * taps <= 13824 and nt % 16 == 0: a block stages 16
  *                  rows x one K chunk x all taps through LDS (contiguous reads, 256-byte write runs); a job has
  *                  ceil(rows / nt) * (nt / 16) * ceil(kdim / kc) blocks.  The form for the 3x3x3 weights, which hold most of the
@@ -365,7 +393,7 @@ int md_conv3_head(const float* x, const float* ac, const void* wpk, float* y, in
  *   tiled = 3    : MD_PACK_WINO jobs, block-cooperative (a block = 32 rows x 16 channels x 27 taps); a job has
  *                  (cout / 32) * (cin / 16) blocks.
  */
-enum { MD_PACK_WPK = 0, MD_PACK_WINO = 1 };
+enum { MD_PACK_WPK = 0, MD_PACK_WINO = 1, MD_PACK_WINO_F6 = 2 };
 typedef struct MdPackJob {
   const float* w;
   void* out;

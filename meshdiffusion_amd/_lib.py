@@ -52,8 +52,8 @@ class MdPackJob(C.Structure):
     ]
 
 
-PACK_WPK, PACK_WINO = 0, 1
-ABI_VERSION = 14     # MD_ABI_VERSION of include/meshdiffusion_hip.h this host code was written against
+PACK_WPK, PACK_WINO, PACK_WINO_F6 = 0, 1, 2
+ABI_VERSION = 15     # MD_ABI_VERSION of include/meshdiffusion_hip.h this host code was written against
 _P, _I32, _I64, _F, _U64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint64
 
 # name -> (restype, argtypes); exactly the entry points of include/meshdiffusion_hip.h
@@ -85,10 +85,14 @@ SIGNATURES = {
     "md_wino_pack_weights": (C.c_int, [_P, _P, _I32, _I32, _I64, _I64, _I32, _P]),
     "md_conv3_wino": (C.c_int, [_P, _P, _P, _P, _I64, _P, _I64, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P]),
     "md_wino_equaliser": (C.c_int, [_P, _P, _P, _I32, _I32, _I64, _I64, _P, _P]),
+    "md_wino_equaliser_measured": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I64, _I64, _P, _P]),
+    "md_wino_operand_ms": (C.c_int, [_P, _P, _I32, _I32, _P, _I32, _I32, _I64, _P, _P]),
     "md_wino_prep_f8": (C.c_int, [_P, _P, _I32, _I32, _P, _I32, _I32, _P, _P, _I32, _I32, _I32, _I32, _P]),
     "md_wino_weight_bytes_f8": (_I64, [_I32, _I32]),
     "md_wino_pack_weights_f8": (C.c_int, [_P, _P, _P, _I32, _I32, _I64, _I64, _P]),
     "md_conv3_wino_f8": (C.c_int, [_P, _P, _P, _P, _I64, _P, _I64, _P, _I32, _I32, _I32, _I32, _I32, _I32, _P]),
+    "md_wino_prep_dual_f6": (C.c_int, [_P, _I32, _P, _P, _P, _F, _I32, _I32, _I32, _I32, _P]),
+    "md_conv3_wino_f6_scaled": (C.c_int, [_P, _P, _P, _P, _I64, _P, _I64, _P, _I32, _I32, _I32, _I32, _I32, _I32, _F, _P]),
     "md_wino_prep_f6": (C.c_int, [_P, _P, _I32, _I32, _P, _I32, _I32, _P, _P, _I32, _I32, _I32, _I32, _P]),
     "md_wino_pack_weights_f6": (C.c_int, [_P, _P, _P, _I32, _I32, _I64, _I64, _P]),
     "md_conv3_wino_f6": (C.c_int, [_P, _P, _P, _P, _I64, _P, _I64, _P, _I32, _I32, _I32, _I32, _I32, _I32, _P]),

@@ -83,8 +83,9 @@ __device__ __forceinline__ float md_wino_f8_wscale(float amax) {       // 2^sw; 
   return ldexpf(1.f, sw);
 }
 // eq (may be null): the per-input-channel equaliser of md_wino_equaliser; the fragments hold G' / eq[ci] (eq is a power of two: exact).
+// flip: the data-gradient orientation W'[ci][co][t] = W[co][ci][26 - t], read in place (as md_pack_wino_item)
 __device__ __forceinline__ uint4 md_pack_wino_f8_item(const float* __restrict__ w, int cout, int cin, int64_t s_row, int64_t s_k, float wscale,
-                                                      int64_t id, const float* __restrict__ eq = nullptr) {
+                                                      int64_t id, const float* __restrict__ eq = nullptr, int flip = 0) {
   int64_t r = id;
   const int lane = (int)(r % 64); r /= 64;
   const int piece = (int)(r % 4); r /= 4;
@@ -101,8 +102,9 @@ __device__ __forceinline__ uint4 md_pack_wino_f8_item(const float* __restrict__ 
   float g8[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
-    const float* g = w + (int64_t)co * s_row + (int64_t)(ci0 + e) * s_k + tap * 3;
-    const float g0 = g[0], g1 = g[1], g2 = g[2];
+    const float* g = w + (int64_t)co * s_row + (int64_t)(ci0 + e) * s_k;
+    const int t0 = tap * 3;
+    const float g0 = g[flip ? 26 - t0 : t0], g1 = g[flip ? 25 - t0 : t0 + 1], g2 = g[flip ? 24 - t0 : t0 + 2];
     const float G = f == 0 ? g0 : f == 1 ? (g0 + g1 + g2) * 0.5f : f == 2 ? (g0 - g1 + g2) * 0.5f : g2;
     g8[e] = G * (eq ? wscale / eq[ci0 + e] : wscale);
   }
@@ -117,9 +119,9 @@ __device__ __forceinline__ uint4 md_pack_wino_f8_item(const float* __restrict__ 
 // the two halves of the lane's 32-byte MX record: lane (row, h) belongs to step 2p + h and its K block is the 16 input channels of
 // that step's chunk: [e2m3 codes of (lo(G') 2^11, G') x 16, interleaved | E8M0 byte of the block, 2^-11 folded in | 0].
 __device__ __forceinline__ uint4 md_pack_wino_f6_item(const float* __restrict__ w, int cout, int cin, int64_t s_row, int64_t s_k, float wscale,
-                                                      int64_t id, const float* __restrict__ eq = nullptr) {
+                                                      int64_t id, const float* __restrict__ eq = nullptr, int flip = 0) {
   const int piece = (int)((id / 64) % 4);
-  if (piece < 2) return md_pack_wino_f8_item(w, cout, cin, s_row, s_k, wscale, id, eq);      // the fp16 fragments are the same
+  if (piece < 2) return md_pack_wino_f8_item(w, cout, cin, s_row, s_k, wscale, id, eq, flip);      // the fp16 fragments are the same
   int64_t r = id;
   const int lane = (int)(r % 64); r /= 64;
   r /= 4;
@@ -135,8 +137,9 @@ __device__ __forceinline__ uint4 md_pack_wino_f6_item(const float* __restrict__ 
   float g16[16];
 #pragma unroll
   for (int e = 0; e < 16; ++e) {
-    const float* g = w + (int64_t)co * s_row + (int64_t)(chunk * 16 + e) * s_k + tap * 3;
-    const float g0 = g[0], g1 = g[1], g2 = g[2];
+    const float* g = w + (int64_t)co * s_row + (int64_t)(chunk * 16 + e) * s_k;
+    const int t0 = tap * 3;
+    const float g0 = g[flip ? 26 - t0 : t0], g1 = g[flip ? 25 - t0 : t0 + 1], g2 = g[flip ? 24 - t0 : t0 + 2];
     const float G = f == 0 ? g0 : f == 1 ? (g0 + g1 + g2) * 0.5f : f == 2 ? (g0 - g1 + g2) * 0.5f : g2;
     g16[e] = G * (eq ? wscale / eq[chunk * 16 + e] : wscale);
   }

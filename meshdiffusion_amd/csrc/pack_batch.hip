@@ -19,6 +19,14 @@ __global__ __launch_bounds__(256) void md_pack_batch_kernel(const MdPackJob* __r
   if (item >= J.n_items) return;
   uint4* out = (uint4*)J.out;
   if (J.kind == MD_PACK_WINO) out[item] = md_pack_wino_item(J.w, J.rows, J.kdim, J.s_row, J.s_k, J.flip, item);
+  else if (J.kind == MD_PACK_WINO_F6) {
+    // f16f6 fragments with a FIXED power-of-two pre-scale 2^prec (no max |w| pass: the training step re-packs every weight, the MX
+    // records carry their own block scales and 2^prec only has to keep the fp16 fragments off the subnormals); the last 16 items of
+    // the job are the 256-byte header {0, sw, 2^-sw, 6} md_conv3_wino_f6 reads its descale from
+    const int64_t n_frag = J.n_items - 16;
+    if (item < n_frag) out[item] = md_pack_wino_f6_item(J.w, J.rows, J.kdim, J.s_row, J.s_k, ldexpf(1.f, J.prec), item, nullptr, J.flip);
+    else out[item] = item == n_frag ? make_uint4(0u, (uint32_t)J.prec, __float_as_uint(ldexpf(1.f, -J.prec)), 6u) : make_uint4(0u, 0u, 0u, 0u);
+  }
   else out[item] = md_pack_wpk_item(J.w, J.rows, J.kdim, J.taps, J.s_row, J.s_k, J.s_tap, J.nt, J.kc, J.prec, item);
 }
 

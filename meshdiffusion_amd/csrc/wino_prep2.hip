@@ -200,10 +200,17 @@ __global__ __launch_bounds__(256) void md_wino_prep2_kernel(const float* __restr
 // md_split_f16f6) split over the block's two channel groups.  The block scale couples two channel groups, so a workgroup takes
 // BOTH of them (16 channels x 256 positions): phase 1 activates every position once per group (2 x 32 bytes per thread), phase 2
 // owns a (pair, frequency half) with all 16 channels.
+// DUAL (md_wino_prep_dual_f6, round 6: the data-gradient convs of a training step in f16f6): the tensor is an output gradient;
+//   T = the f16f6 operand of md_conv3_wino_f6 of `tscale` x the tensor (a power of two that lifts gradient magnitudes into the
+//   fp16 plane's normal range; the conv's launch divides it out again), U = the bf16 hi / lo operand of md_wgrad_wino of the
+//   UNSCALED tensor (bit-identical to md_wino_prep_dual's), sums = its per-(sample, channel) sums (bias gradients).
+template <bool DUAL>
 __global__ __launch_bounds__(256) void md_wino_prep2_f6_kernel(const float* __restrict__ x1, const float* __restrict__ x2, int c1, int c2,
                                                                const float* __restrict__ ac, int silu, int ups, uint4* __restrict__ T, int batch,
-                                                               int D, int H, int W, const float* __restrict__ eq) {
+                                                               int D, int H, int W, const float* __restrict__ eq, uint4* __restrict__ U,
+                                                               float* __restrict__ sums, float tscale) {
   __shared__ __attribute__((aligned(16))) float act[2 * P2_GROUP];
+  __shared__ float wsum[4][16];                    // DUAL with sums: [wave][channel]
   const int tid = threadIdx.x;
   const int Wp = W >> 1;
   const int64_t P = (int64_t)D * H * W, Ph = P >> 1;
@@ -257,9 +264,22 @@ __global__ __launch_bounds__(256) void md_wino_prep2_f6_kernel(const float* __re
       float* dst = act + g2 * P2_GROUP + p2_slot(tid);
       *(f32x4*)dst = f32x4{yv[0], yv[1], yv[2], yv[3]};
       *(f32x4*)(dst + 4) = f32x4{yv[4], yv[5], yv[6], yv[7]};
+      if constexpr (DUAL) {
+        if (sums != nullptr) {      // per-wave channel sums as in md_wino_prep2_kernel<true>
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float v = md_wave_sum(yv[e]);
+            if ((tid & 63) == 0) wsum[tid >> 6][g2 * 8 + e] = v;
+          }
+        }
+      }
     }
   }
   __syncthreads();
+  if constexpr (DUAL) {
+    if (sums != nullptr && tid < 16)
+      atomicAdd(sums + (int64_t)b * (c1 + c2) + cgp * 16 + tid, (wsum[0][tid] + wsum[1][tid]) + (wsum[2][tid] + wsum[3][tid]));
+  }
   // ---- phase 2 ----
   {
     const int pi = tid & 127, fh = tid >> 7;
@@ -290,14 +310,38 @@ __global__ __launch_bounds__(256) void md_wino_prep2_f6_kernel(const float* __re
       const int f = 2 * fh + g;
       float t[16];
 #pragma unroll
-      for (int e = 0; e < 16; ++e)
+      for (int e = 0; e < 16; ++e) {
         t[e] = f == 0 ? d[0][e] - d[2][e] : f == 1 ? d[1][e] + d[2][e] : f == 2 ? d[2][e] - d[1][e] : d[1][e] - d[3][e];
+        if constexpr (DUAL) t[e] *= tscale;
+      }
       uint4 h0, h1, r0, r1;
       md_split_f16f6(t, false, 0, h0, h1, r0, r1);
       out0[(int64_t)(f * 2) * Ph] = h0;
       out1[(int64_t)(f * 2) * Ph] = h1;
       out0[(int64_t)(f * 2 + 1) * Ph] = r0;
       out1[(int64_t)(f * 2 + 1) * Ph] = r1;
+    }
+    if constexpr (DUAL) {
+      uint4* uo0 = U + ((int64_t)b * CG + 2 * cgp) * 8 * Ph + pos2;
+      uint4* uo1 = uo0 + 8 * Ph;
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const int f = 2 * fh + g;
+#pragma unroll
+        for (int g2 = 0; g2 < 2; ++g2) {
+          uint32_t hw[4], lw[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int e0 = g2 * 8 + 2 * q;
+            const float ta = f == 0 ? d[1][e0] : f == 1 ? d[1][e0] + d[2][e0] : f == 2 ? d[1][e0] - d[2][e0] : d[2][e0];
+            const float tb = f == 0 ? d[1][e0 + 1] : f == 1 ? d[1][e0 + 1] + d[2][e0 + 1] : f == 2 ? d[1][e0 + 1] - d[2][e0 + 1] : d[2][e0 + 1];
+            md_split2(ta, tb, hw[q], lw[q]);
+          }
+          uint4* uo = g2 ? uo1 : uo0;
+          uo[(int64_t)(f * 2) * Ph] = make_uint4(hw[0], hw[1], hw[2], hw[3]);
+          uo[(int64_t)(f * 2 + 1) * Ph] = make_uint4(lw[0], lw[1], lw[2], lw[3]);
+        }
+      }
     }
   }
 }
@@ -359,8 +403,23 @@ extern "C" int md_wino_prep_f6(const float* x1, const float* x2, int32_t c1, int
   const int64_t blocks = (int64_t)batch * ((c1 + c2) / 16) * (P / P2_POS);
   if (blocks > 0x7fffffff) return MD_ERR_UNSUPPORTED;
   MD_HIP_CLEAR_ERROR();
-  hipLaunchKernelGGL(md_wino_prep2_f6_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x1, x2, c1, c2, ac, silu, ups,
-                     (uint4*)t_out, batch, D, H, W, eq);
+  hipLaunchKernelGGL(md_wino_prep2_f6_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x1, x2, c1, c2, ac, silu, ups,
+                     (uint4*)t_out, batch, D, H, W, eq, (uint4*)nullptr, (float*)nullptr, 1.0f);
+  MD_HIP_CHECK_LAUNCH();
+  return MD_OK;
+}
+
+extern "C" int md_wino_prep_dual_f6(const float* x, int32_t c, void* t_out, void* u_out, float* sums, float tscale, int32_t batch, int32_t D,
+                                    int32_t H, int32_t W, void* stream) {
+  if (!x || !t_out || !u_out || batch <= 0 || c <= 0 || (c & 15)) return MD_ERR_BAD_ARG;
+  if (D <= 0 || H <= 0 || W <= 0 || (W & 1) || !(tscale > 0.f)) return MD_ERR_BAD_ARG;
+  const int64_t P = (int64_t)D * H * W;
+  if ((P2_POS % W) || (P % P2_POS)) return MD_ERR_UNSUPPORTED;
+  const int64_t blocks = (int64_t)batch * (c / 16) * (P / P2_POS);
+  if (blocks > 0x7fffffff) return MD_ERR_UNSUPPORTED;
+  MD_HIP_CLEAR_ERROR();
+  hipLaunchKernelGGL(md_wino_prep2_f6_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, (const float*)nullptr, c, 0,
+                     (const float*)nullptr, 0, 0, (uint4*)t_out, batch, D, H, W, (const float*)nullptr, (uint4*)u_out, sums, tscale);
   MD_HIP_CHECK_LAUNCH();
   return MD_OK;
 }

@@ -239,6 +239,8 @@ def _flush(queue):
                     and 16 * j["kc"] * j["taps"] <= 13824 and j["nt"] % 16 == 0)
 
         def mode(j):       # md_pack_batch `tiled` argument for this job
+            if j["kind"] == _lib.PACK_WINO_F6:
+                return 0
             if PACK_TILED and j["kind"] == _lib.PACK_WINO:
                 return 3
             if not tiled(j):
@@ -271,6 +273,14 @@ def _flush(queue):
             if j["kind"] == _lib.PACK_WPK:
                 check(lib.md_pack_weights(wp, _ptr(out), j["rows"], j["kdim"], j["taps"], j["s_row"], j["s_k"], j["s_tap"], j["nt"],
                                           j["kc"], j["prec"], _stream()), "md_pack_weights")
+            elif j["kind"] == _lib.PACK_WINO_F6:      # a table of one job (the fixed-pre-scale f16f6 form exists as a batch job only)
+                jobs = (_lib.MdPackJob * 1)()
+                J = jobs[0]
+                J.w, J.out = j["w"].data_ptr() + j["w_off"], out.data_ptr()
+                J.s_row, J.s_k, J.s_tap, J.n_items, J.block0 = j["s_row"], j["s_k"], 0, j["nbytes"] // 16, 0
+                J.rows, J.kdim, J.taps, J.nt, J.kc, J.prec, J.flip, J.kind = j["rows"], j["kdim"], 9, 0, 0, j["prec"], j["flip"], j["kind"]
+                table = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).to(out.device)
+                check(lib.md_pack_batch(_ptr(table), 1, (J.n_items + 255) // 256, 0, _stream()), "md_pack_batch")
             else:
                 check(lib.md_wino_pack_weights(wp, _ptr(out), j["rows"], j["kdim"], j["s_row"], j["s_k"], j["flip"], _stream()),
                       "md_wino_pack_weights")
@@ -473,19 +483,79 @@ class WinoWeightF8:
         check(pack(_ptr(w), _ptr(eq), _ptr(self.data), self.rows, self.kdim, self.kdim * 27, 27, _stream()), "md_wino_pack_weights_" + fmt)
 
 
-def wino_equaliser(gamma, beta, w):
-    """float [Cin] on the device: the static per-input-channel power-of-two equaliser of a GroupNorm(gamma, beta) -> SiLU -> Conv3d(w)
-    pair for the f16f8 / f16f6 arithmetic (md_wino_equaliser, csrc/wino_eq.hip)."""
+# Training, round 6: the data-gradient convs of the layers on the Winograd path run in the f16f6 arithmetic (2/3 .. 3/4 of the bf16x3
+# kernel's matrix-core energy: the kernel is power-bound) -- their operand is lifted by DGRAD_TSCALE (a power of
+# two: gradient magnitudes into the fp16 plane's normal range, divided out again by the conv's launch), their weights are packed by the
+# step's md_pack_batch table with a fixed pre-scale.  A/B switch: MD_DGRAD_F6=0 = bf16x3 data gradients (rounds 2-5).
+DGRAD_F6 = os.environ.get("MD_DGRAD_F6", "1") == "1"
+DGRAD_TSCALE = 2.0 ** int(os.environ.get("MD_DGRAD_TSCALE_LOG2", "8"))
+DGRAD_WSCALE_LOG2 = 8
+
+
+class WinoWeightF6Dgrad:
+    """Conv3d weight [Co][Ci][3][3][3] -> the f16f6 fragments of its DATA-GRADIENT conv W'[ci][co][t] = W[co][ci][26 - t] (read in
+    place), packed by md_pack_batch (MD_PACK_WINO_F6: fixed pre-scale 2^DGRAD_WSCALE_LOG2, no equaliser: the operand is a gradient)."""
+    fmt, eq = "f6", None
+
+    def __init__(self, w, device):
+        lib = _lib.load()
+        w = w.detach().to(device=device, dtype=torch.float32).contiguous()
+        _require_cuda(w, "weight")
+        assert w.dim() == 5 and tuple(w.shape[2:]) == (3, 3, 3)
+        self.rows, self.kdim = w.shape[1], w.shape[0]
+        nbytes = lib.md_wino_weight_bytes_f8(self.rows, self.kdim)
+        if nbytes <= 0:
+            raise _lib.MeshDiffusionHipError("md_wino_weight_bytes_f8: unsupported weight shape")
+        self._data, self._queued = None, False
+        self._src = dict(kind=_lib.PACK_WINO_F6, w=w, w_off=0, nbytes=nbytes, rows=self.rows, kdim=self.kdim, taps=9, s_row=27,
+                         s_k=self.rows * 27, s_tap=0, nt=0, kc=0, prec=DGRAD_WSCALE_LOG2, flip=1)
+
+    request = WinoWeight.request
+    data = WinoWeight.data
+
+
+def wino_equaliser(gamma, beta, w, a2m=None):
+    """float [Cin] on the device: the per-input-channel power-of-two equaliser of a GroupNorm(gamma, beta) -> SiLU -> Conv3d(w)
+    pair for the f16f8 / f16f6 arithmetic (md_wino_equaliser, csrc/wino_eq.hip).  a2m: float [Cin] MEASURED mean squares of the
+    operand (wino_operand_ms over a calibration evaluation) in place of the static estimate from (gamma, beta); gamma = beta = None
+    (with a2m) for a conv no GroupNorm precedes (Upsample)."""
     lib = _lib.load()
     w = w.detach().to(dtype=torch.float32).contiguous()
     _require_cuda(w, "weight")
     cout, cin = w.shape[0], w.shape[1]
-    gamma = gamma.detach().to(device=w.device, dtype=torch.float32).contiguous()
-    beta = beta.detach().to(device=w.device, dtype=torch.float32).contiguous()
-    assert w.dim() == 5 and tuple(w.shape[2:]) == (3, 3, 3) and gamma.numel() == cin and beta.numel() == cin
+    assert w.dim() == 5 and tuple(w.shape[2:]) == (3, 3, 3)
+    assert (gamma is None) == (beta is None) and (gamma is not None or a2m is not None)
+    if gamma is not None:
+        gamma = gamma.detach().to(device=w.device, dtype=torch.float32).contiguous()
+        beta = beta.detach().to(device=w.device, dtype=torch.float32).contiguous()
+        assert gamma.numel() == cin and beta.numel() == cin
     eq = torch.empty(cin, dtype=torch.float32, device=w.device)
-    check(lib.md_wino_equaliser(_ptr(gamma), _ptr(beta), _ptr(w), cout, cin, cin * 27, 27, _ptr(eq), _stream()), "md_wino_equaliser")
+    if a2m is not None:
+        assert a2m.is_cuda and a2m.dtype == torch.float32 and a2m.numel() == cin and a2m.is_contiguous()
+        check(lib.md_wino_equaliser_measured(_ptr(gamma), _ptr(beta), _ptr(w), _ptr(a2m), cout, cin, cin * 27, 27, _ptr(eq), _stream()),
+              "md_wino_equaliser_measured")
+    else:
+        check(lib.md_wino_equaliser(_ptr(gamma), _ptr(beta), _ptr(w), cout, cin, cin * 27, 27, _ptr(eq), _stream()), "md_wino_equaliser")
     return eq
+
+
+# Calibration (DDPMUNet3D.calibrate): while this is a dict, every inference conv on the Winograd path records the per-channel mean
+# squares of the operand it reads -- {(id(layer), site): [layer, site, sum of ms vectors, evaluations]} -- from which the layer's
+# MEASURED equaliser is built (layer._md_act_ms[site]; layers.conv3_wino_packed).
+CALIBRATE = None
+
+
+def wino_operand_ms(parts, ac, silu, B, P):
+    """float [Cin]: mean over samples and positions of the squared operand (GroupNorm affine + SiLU applied when `ac`) of up to two
+    concatenated F32B parts -- md_wino_operand_ms."""
+    lib = _lib.load()
+    assert 1 <= len(parts) <= 2
+    cin = sum(c for _, c in parts)
+    x2, c2 = (parts[1][0], parts[1][1]) if len(parts) == 2 else (None, 0)
+    ms = torch.zeros(cin, dtype=torch.float32, device=parts[0][0].device)
+    check(lib.md_wino_operand_ms(_ptr(parts[0][0]), _ptr(x2), parts[0][1], c2, _ptr(ac), 1 if silu else 0, B, P, _ptr(ms), _stream()),
+          "md_wino_operand_ms")
+    return ms
 
 
 # fewest workgroups the Winograd kernel is launched with.  256 (one per CU) through round 4; with the f16f6 kernel half a chip of Winograd
@@ -558,7 +628,7 @@ def wino_f8_ok(S, drop=None, keep=False, parts=None, normalised=True):
     return WINO_F8
 
 
-def wino_prep(parts, ac, silu, ups, B, S, drop=None, keep=False, dual=False, sums=None, f8=False, eq=None):
+def wino_prep(parts, ac, silu, ups, B, S, drop=None, keep=False, dual=False, sums=None, f8=False, eq=None, tscale=1.0):
     """fp32 F32B parts (+ folded GroupNorm affine, SiLU, nearest-x2 upsampling) -> transformed split operand T.
     drop = (p, seed): training dropout after SiLU, the mask gn_apply(drop=...) produces for the same pair.
     keep: T goes to its own tensor instead of the shared scratch buffer (training forward: the Winograd weight gradient of the
@@ -579,7 +649,14 @@ def wino_prep(parts, ac, silu, ups, B, S, drop=None, keep=False, dual=False, sum
     ev = _prof_begin()
     args = (_ptr(parts[0][0]), _ptr(x2), parts[0][1], c2, _ptr(ac), 1 if silu else 0, 1 if ups else 0)
     tail = (B, S, S, S, drop[0] if drop else 0.0, drop[1] if drop else 0, _stream())
-    if f8:
+    if f8 and dual:
+        # training backward: T = the f16f6 operand of tscale x the output gradient (data-gradient conv), U = the bf16 operand of the
+        # unscaled gradient (md_wgrad_wino), sums = its channel sums
+        assert f8 == "f6" and len(parts) == 1 and ac is None and not (ups or keep or drop or eq is not None) and 256 % S == 0
+        u = _wino_scratch(nbytes // 2, dev, slot="u")
+        check(lib.md_wino_prep_dual_f6(_ptr(parts[0][0]), cin, _ptr(t), _ptr(u), _ptr(sums), float(tscale), B, S, S, S, _stream()),
+              "md_wino_prep_dual_f6")
+    elif f8:
         assert not (dual or keep or drop), "the f16f8 / f16f6 operand is an inference format"
         if f8 == "f6":
             check(lib.md_wino_prep_f6(*args, _ptr(eq), _ptr(t), B, S, S, S, _stream()), "md_wino_prep_f6")
@@ -630,19 +707,23 @@ def wgrad_wino(u_dy, t_act, B, co, ci, S, dw):
 WINO_VARIANT = int(os.environ.get("MD_WINO_VARIANT", "0"))
 
 
-def conv3_wino(ww, t, B, S, *, bias=None, bias_bstride=0, residual=None, res_bstride=0, stats=None, out=None, variant=None):
+def conv3_wino(ww, t, B, S, *, bias=None, bias_bstride=0, residual=None, res_bstride=0, stats=None, out=None, variant=None, out_scale=1.0):
     lib = _lib.load()
     P = S ** 3
     if out is None:
         out = f32b_empty(B, ww.rows, P, t.device)
     ev = _prof_begin()
-    f8 = isinstance(ww, WinoWeightF8)        # the weight object fixes the arithmetic; `t` must come from wino_prep(f8=...) accordingly
+    f8 = isinstance(ww, (WinoWeightF8, WinoWeightF6Dgrad))        # the weight object fixes the arithmetic; `t` must come from wino_prep(f8=...) accordingly
     t_fmt = getattr(t, "_md_fmt", None)
     if t_fmt is not None:                    # an operand that went through wino_prep: format and equaliser must be the weight object's
         want = ww.fmt if f8 else False
         if t_fmt != want or getattr(t, "_md_eq", 0) != ((ww.eq.data_ptr() if ww.eq is not None else 0) if f8 else 0):
             raise _lib.MeshDiffusionHipError(f"conv3_wino: operand format {t_fmt!r} / equaliser does not belong to these weights ({want!r})")
-    if f8:
+    if f8 and out_scale != 1.0:
+        assert ww.fmt == "f6"
+        check(lib.md_conv3_wino_f6_scaled(_ptr(t), _ptr(ww.data), _ptr(out), _ptr(bias), bias_bstride, _ptr(residual), res_bstride,
+                                          _ptr(stats), B, ww.kdim, ww.rows, S, S, S, float(out_scale), _stream()), "md_conv3_wino_f6_scaled")
+    elif f8:
         fn = lib.md_conv3_wino_f6 if ww.fmt == "f6" else lib.md_conv3_wino_f8
         check(fn(_ptr(t), _ptr(ww.data), _ptr(out), _ptr(bias), bias_bstride, _ptr(residual), res_bstride,
                  _ptr(stats), B, ww.kdim, ww.rows, S, S, S, _stream()), "md_conv3_wino_" + ww.fmt)

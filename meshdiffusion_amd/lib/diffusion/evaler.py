@@ -44,6 +44,14 @@ def _setup(config, mask_shape, local_batch=None):
     state = restore_checkpoint(ckpt_path, state, device=config.device)
     ema.copy_to(score_model.parameters())
     print(f"loaded model is trained till iter {state['step'] // config.training.iter_size}")
+    # the checkpoint's weights meet the reduced-precision conv formats here for the first time: measure every conv's operand on a
+    # few noise batches, rebuild the equalisers from the measurement, audit each conv against its bf16x3 form and demote the ones
+    # above the bar (models/utils.calibrate_model; config.eval.calibrate = False skips it)
+    if getattr(config.eval, "calibrate", True) and torch.device(config.device).type == "cuda":
+        rep = mutils.calibrate_model(score_model, config)
+        if rep is not None:
+            print(f"calibrated the {score_model.module.hip_precision} convs: {rep['measured']} measured, worst kept {rep['worst']:.2e}, "
+                  f"demoted to bf16x3: {rep['demoted']}")
     return score_model, sampling_fn, eval_dir
 
 

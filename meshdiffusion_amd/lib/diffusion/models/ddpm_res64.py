@@ -436,6 +436,55 @@ class DDPMUNet3D(layers.HipLayer):
         with ops.precision_scope(self.hip_precision):
             return self._forward_eval(x, labels)
 
+    def calibrate(self, x, labels, bar=4e-5):
+        """Load-time calibration of the reduced-precision conv arithmetic on THESE weights (call it once after `load_state_dict` /
+        `restore_checkpoint`, in eval mode; the trained checkpoints are external downloads, README.md:35-37 of the reference, so the
+        first real one meets the f16f8 / f16f6 formats unseen).  x, labels: one batch, or lists of batches (e.g. a noise batch at a
+        few timesteps).  Two steps, both on the model's own inference path:
+          1. one evaluation per batch with `hip_ops.CALIBRATE` on: every Winograd conv records the per-channel mean squares of the
+             operand it reads; each layer keeps the mean over the batches (`layer._md_act_ms[site]`), from which its equaliser is
+             rebuilt (hip_ops.wino_equaliser(a2m=...)): GroupNorm normalises groups of channels, the static estimate assumes unit
+             variance per CHANNEL; and the Upsample convs, which read the raw residual stream, get an equaliser at all;
+          2. one audited evaluation per batch (`hip_ops.AUDIT`: every reduced-precision launch repeated in bf16x3 on the same operand):
+             a conv whose relative difference exceeds `bar` on any batch is taken off the reduced-precision path for good
+             (`layer.md_bf16x3_sites`).
+        Returns {"measured": n convs, "audited": n launches, "worst": largest difference kept, "demoted": [(module name, site, diff)]}."""
+        xs, ls = (list(x), list(labels)) if isinstance(x, (list, tuple)) else ([x], [labels])
+        assert len(xs) == len(ls) and not self.training
+        names = {id(m): n for n, m in self.named_modules()}
+        ops.CALIBRATE = {}
+        try:
+            with torch.no_grad():
+                for xi, li in zip(xs, ls):
+                    self.forward(xi, li)
+            cal = ops.CALIBRATE
+        finally:
+            ops.CALIBRATE = None
+        for owner, site, tot, n in cal.values():
+            owner.__dict__.setdefault("_md_act_ms", {})[site] = (tot / float(n)).contiguous()
+        worst = {}
+        n_audited = 0
+        for xi, li in zip(xs, ls):
+            ops.AUDIT = []
+            try:
+                with torch.no_grad():
+                    self.forward(xi, li)
+                recs = ops.AUDIT
+            finally:
+                ops.AUDIT = None
+            n_audited += len(recs)
+            for r in recs:
+                key = (id(r["owner"]), r["site"])
+                if key not in worst or r["rel_l2"] > worst[key]["rel_l2"]:
+                    worst[key] = r
+        demoted = []
+        for r in worst.values():
+            if r["rel_l2"] > bar:
+                r["owner"].md_bf16x3_sites = tuple(sorted(set(getattr(r["owner"], "md_bf16x3_sites", ())) | {r["site"]}))
+                demoted.append((names.get(id(r["owner"]), "?"), r["site"], r["rel_l2"]))
+        kept = [r["rel_l2"] for r in worst.values() if r["rel_l2"] <= bar]
+        return dict(measured=len(cal), audited=n_audited, worst=max(kept) if kept else 0.0, demoted=sorted(demoted))
+
     def _forward_eval(self, x, labels):
         mods = self.all_modules
         B, R = x.shape[0], self.img_size

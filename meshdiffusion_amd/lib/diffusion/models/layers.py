@@ -115,25 +115,36 @@ def conv3_packed(layer, name, conv, cfg):
 def conv3_wino_packed(layer, name, conv, gn=None):
     """Lazy builder of the Winograd-transformed weight tiles of `conv` (cached like conv3_packed); f8: the fragments of the
     f16f8 / f16f6 arithmetic (hip_ops.WinoWeightF8, inference).  gn: the nn.GroupNorm whose output (through SiLU) the conv reads --
-    the f16f8 / f16f6 fragments are then packed with the pair's static equaliser (`build.eq()`: the vector the operand pass of the
-    same launch needs; hip_ops.wino_equaliser), rebuilt whenever the weight or the GroupNorm affine changes."""
-    use_eq = gn is not None and ops.WINO_EQ
+    the f16f8 / f16f6 fragments are then packed with the pair's equaliser (`build.eq()`: the vector the operand pass of the
+    same launch needs; hip_ops.wino_equaliser), rebuilt whenever the weight or the GroupNorm affine changes.  After a calibration
+    (DDPMUNet3D.calibrate) the layer holds the MEASURED per-channel mean squares of this conv's operand (`layer._md_act_ms[name]`):
+    the equaliser is then built from them (also for a conv no GroupNorm precedes: `build.measured()` is what lets an Upsample
+    conv onto the reduced-precision path)."""
+    def measured():
+        return layer.__dict__.get("_md_act_ms", {}).get(name)
 
     def eq():
-        if not use_eq:
+        ms = measured() if ops.WINO_EQ else None
+        if ms is None and not (gn is not None and ops.WINO_EQ):
             return None
-        return layer._cached(f"{name}/wino_eq", [conv.weight, gn.weight, gn.bias],
-                             lambda: ops.wino_equaliser(gn.weight, gn.bias, conv.weight))
+        gp = [gn.weight, gn.bias] if gn is not None else []
+        if ms is None:
+            return layer._cached(f"{name}/wino_eq", [conv.weight] + gp, lambda: ops.wino_equaliser(gn.weight, gn.bias, conv.weight))
+        return layer._cached(f"{name}/wino_eqm", [conv.weight] + gp + [ms],
+                             lambda: ops.wino_equaliser(gn.weight if gn is not None else None, gn.bias if gn is not None else None,
+                                                        conv.weight, a2m=ms))
 
     def build(f8=False):
         if f8:
             fmt = "f6" if f8 == "f6" else "f8"
-            deps = [conv.weight] + ([gn.weight, gn.bias] if use_eq else [])
-            return layer._cached(f"{name}/wino_{fmt}{'e' if use_eq else ''}", deps,
+            ms = measured() if ops.WINO_EQ else None
+            use_eq = ms is not None or (gn is not None and ops.WINO_EQ)
+            deps = [conv.weight] + ([gn.weight, gn.bias] if (use_eq and gn is not None) else []) + ([ms] if ms is not None else [])
+            return layer._cached(f"{name}/wino_{fmt}{('m' if ms is not None else 'e') if use_eq else ''}", deps,
                                  lambda: ops.WinoWeightF8(conv.weight, conv.weight.device, fmt, eq=eq()))
         return layer._cached(f"{name}/wino", [conv.weight], lambda: ops.WinoWeight(conv.weight, conv.weight.device))
-    build.eq = eq
-    build.owner, build.site = layer, name      # identifies the conv for per-layer overrides (layer.md_bf16x3_sites) and the audit
+    build.eq, build.measured = eq, measured
+    build.owner, build.site = layer, name      # identifies the conv for per-layer overrides (layer.md_bf16x3_sites), the audit and the calibration
     return build
 
 
@@ -168,11 +179,21 @@ def run_conv3(pw, act_s16, B, S_out, *, bias=None, bias_bstride=0, residual=None
     if (b_f32 is not None and wino is not None and out_mode == ops.OUT_F32B and rows_alloc == pw.rows
             and pw.prec == ops.PREC_BF16X3 and ops.wino_ok(pw.rows, pw.kdim, S_out, B)):
         stats = ops.stats_zeros(B, rows_alloc, dev) if want_stats and ops.FUSE_GN_STATS else None
-        # f16f8 / f16f6: inference operands that come out of a GroupNorm (the layer's static equaliser flattens their channels);
-        # the raw residual stream (Upsample: ac None) stays in bf16x3
-        f8 = (not b_f32.get("wino_only")) and ops.wino_f8_ok(S_out, drop=b_f32.get("drop"), keep=bool(b_f32.get("keep")), parts=b_f32["parts"],
-                                                             normalised=b_f32.get("ac") is not None)
-        if f8 and getattr(wino, "owner", None) is not None and wino.site in getattr(wino.owner, "md_bf16x3_sites", ()):
+        # f16f8 / f16f6: inference operands that come out of a GroupNorm (the layer's static equaliser flattens their channels), or
+        # any operand whose layer holds a measured equaliser (DDPMUNet3D.calibrate); an uncalibrated raw residual stream (Upsample:
+        # ac None) stays in bf16x3
+        owner = getattr(wino, "owner", None)
+        if ops.CALIBRATE is not None and owner is not None and not b_f32.get("wino_only"):
+            # calibration evaluation: what this conv's operand really looks like, per input channel (nearest-x2 upsampling does not
+            # change a channel's mean square: measured on the coarse tensor)
+            ms = ops.wino_operand_ms(b_f32["parts"], b_f32.get("ac"), b_f32.get("silu"), B, b_f32["parts"][0][0].shape[2])
+            rec = ops.CALIBRATE.setdefault((id(owner), wino.site), [owner, wino.site, torch.zeros_like(ms), 0])
+            rec[2] += ms
+            rec[3] += 1
+        f8 = (not b_f32.get("wino_only")) and ops.wino_f8_ok(
+            S_out, drop=b_f32.get("drop"), keep=bool(b_f32.get("keep")), parts=b_f32["parts"],
+            normalised=b_f32.get("ac") is not None or (hasattr(wino, "measured") and wino.measured() is not None))
+        if f8 and owner is not None and wino.site in getattr(owner, "md_bf16x3_sites", ()):
             f8 = False                   # this conv was taken off the reduced-precision path (layer.md_bf16x3_sites: tools/audit_precision.py)
         t = ops.wino_prep(b_f32["parts"], b_f32.get("ac"), b_f32.get("silu"), ups, B, S_out, drop=b_f32.get("drop"),
                           keep=bool(b_f32.get("keep")), f8=f8, eq=wino.eq() if f8 and hasattr(wino, "eq") else None)

@@ -57,6 +57,30 @@ def create_model(config, use_parallel=True):
     return model
 
 
+def calibrate_model(model, config, batch=2, timesteps=(900.0, 400.0, 60.0), seed=20260930, bar=4e-5):
+    """Load-time calibration of the reduced-precision conv arithmetic (DDPMUNet3D.calibrate) on what the sampler will feed the
+    model: unit-variance noise on the grid mask at a few timesteps of the schedule (the ancestral trajectory starts as exactly that
+    and keeps unit scale: the VP SDE is variance preserving).  Call it once after `load_state_dict` / `restore_checkpoint`;
+    `evaler.uncond_gen / cond_gen` do.  Returns the calibration report, or None for a model without the method / in bf16x3."""
+    net = model.module if hasattr(model, "module") else model
+    if not hasattr(net, "calibrate") or getattr(net, "hip_precision", None) not in ("f16f8", "f16f6"):
+        return None
+    was_training = net.training
+    net.eval()
+    try:
+        dev = next(net.parameters()).device
+        R, C = config.data.image_size, config.data.num_channels
+        g = torch.Generator().manual_seed(seed)
+        mask = net.mask.detach().to(dev).view(1, 1, R, R, R) if hasattr(net, "mask") else 1.0
+        xs, ls = [], []
+        for t in timesteps:
+            xs.append(torch.randn((batch, C, R, R, R), generator=g).to(dev) * mask)
+            ls.append(torch.full((batch,), float(t), device=dev))
+        return net.calibrate(xs, ls, bar=bar)
+    finally:
+        net.train(was_training)
+
+
 def get_model_fn(model, train=False):
     def model_fn(x, labels):
         model.train() if train else model.eval()

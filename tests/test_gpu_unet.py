@@ -355,6 +355,54 @@ def test_unet_res64_trained_like_weights_vs_reference_golden(env):
         assert e_sub < TOL_EVAL_TRAINED and e_norm < TOL_EVAL_TRAINED and e_row < TOL_EVAL
 
 
+@pytest.mark.skipif(not os.path.exists(os.path.join(GOLD, "unet_res64_trained.npz")), reason="trained-like golden not generated")
+def test_calibrate_measured_equalisers_audit_and_upsample_convs_on_f16f6(env):
+    """DDPMUNet3D.calibrate on the adversarial weights: one measured + one audited evaluation per batch.
+    After it (a) every Winograd conv -- the three Upsample convs on the raw residual stream included -- runs in the configured reduced
+    precision unless the audit demoted it, (b) no conv kept on that path differs from its bf16x3 form by more than the bar, (c) the
+    evaluation against the UNMODIFIED reference's golden is no worse than uncalibrated (and under the same 6e-5 budget)."""
+    from meshdiffusion_amd import hip_ops
+    from meshdiffusion_amd.config import get_config_res64
+    synth, mutils = env["synth"], env["mutils"]
+    if hip_ops.FORCE_PRECISION:
+        pytest.skip("the calibration is about the configured default arithmetic")
+    gold = np.load(os.path.join(GOLD, "unet_res64_trained.npz"))
+    cfg = get_config_res64(); cfg.device = torch.device("cuda")
+    model = mutils.create_model(cfg).eval()
+    sd = synth.trained_like_state_dict(model.module.state_dict(), seed=int(gold["sd_seed"]), grid_mask=synth.synthetic_grid_mask(64))
+    model.module.load_state_dict(sd, strict=True)
+    del sd
+    x = synth.synthetic_inputs(2, 4, 64, seed=int(gold["x_seed"])).cuda()
+    labels = torch.tensor(gold["labels"]).cuda()
+
+    def evaluate():
+        hip_ops.PROFILE = []
+        try:
+            with torch.no_grad():
+                y = model(x, labels).cpu()
+            tags = [r[5] for r in hip_ops.PROFILE if r[0] == "wino"]
+        finally:
+            hip_ops.PROFILE = None
+        e = max(max(rel_l2(y[b:b + 1, :, ::4, ::4, ::4], gold["y_sub"][b:b + 1]),
+                    abs(float(y[b].double().norm()) - float(gold["y_norm"][b])) / float(gold["y_norm"][b])) for b in range(2))
+        return e, tags
+
+    e0, tags0 = evaluate()
+    fmt = cfg.model.hip_precision[3:]
+    n0 = sum(t.endswith("/" + fmt) for t in tags0)
+    # calibration batches: the golden's inputs are NOT among them (a noise batch at three other timesteps)
+    xc = synth.synthetic_inputs(2, 4, 64, seed=77).cuda() * synth.synthetic_grid_mask(64).view(1, 1, 64, 64, 64).cuda()
+    rep = model.module.calibrate([xc, xc, xc], [torch.full((2,), t, device="cuda") for t in (900.0, 400.0, 60.0)], bar=4e-5)
+    e1, tags1 = evaluate()
+    n1 = sum(t.endswith("/" + fmt) for t in tags1)
+    print(f"calibrate(): {rep['measured']} convs measured, {rep['audited']} launches audited, worst kept {rep['worst']:.2e}, demoted {rep['demoted']}; "
+          f"golden error {e0:.2e} -> {e1:.2e}; reduced-precision Winograd launches {n0} -> {n1} of {len(tags1)}")
+    assert rep["measured"] >= len(tags0) and rep["worst"] <= 4e-5
+    assert n1 == len(tags1) - sum(1 for d in rep["demoted"]) or n1 >= n0          # demoted sites run bf16x3, everything else reduced precision
+    assert n1 + len(rep["demoted"]) >= len(tags1)
+    assert e1 < TOL_EVAL_TRAINED and e1 < e0 * 1.1
+
+
 @pytest.mark.skipif(not os.path.exists(os.path.join(GOLD, "unet_res128_trained.npz")), reason="trained-like res128 golden not generated")
 def test_unet_res128_full_size_trained_like_weights_vs_reference_golden(env):
     """The same adversarial gate for configs[3]'s network: ddpm_res128 at 128^3 on synth.trained_like_state_dict against the
