@@ -521,21 +521,43 @@ def exchange_record(ex, split, world, dist, dev, cap_bytes=128 << 20):
     """The `train_step.exchange` object: what the gradient exchange of the instrumented step did on EVERY rank (each rank's own
     bucket count / bytes / exposed wait, gathered to rank 0) and the world size the process group itself reports.  Shared by the
     GPU path (RCCL) and `--dry-run` (gloo, CPU): tests/test_dist_cpu.py checks its shape without a GPU."""
+    # what each rank's OWN process sees of the node: the device it computes on (index inside its visible set, the visible count, and
+    # the device's PCI bus id as a number -- eight distinct values on a first 8-GPU line prove that RCCL ran over eight devices and
+    # not eight ranks on one), HIP_VISIBLE_DEVICES as a hash (-1: unset)
+    on_gpu = torch.device(dev).type == "cuda"
+    dev_index = (torch.device(dev).index if torch.device(dev).index is not None else torch.cuda.current_device()) if on_gpu else -1
+    n_visible = torch.cuda.device_count() if on_gpu else 0
+    bus = -1
+    if on_gpu:
+        try:
+            p = torch.cuda.get_device_properties(dev_index)
+            bus = (int(getattr(p, "pci_domain_id", 0)) << 16) | (int(getattr(p, "pci_bus_id", -1)) << 8) | int(getattr(p, "pci_device_id", 0))
+        except Exception:
+            bus = -1
+    vis = os.environ.get("HIP_VISIBLE_DEVICES", os.environ.get("CUDA_VISIBLE_DEVICES"))
+    vis_code = -1 if vis is None else int.from_bytes(vis.encode()[:6].ljust(6, b"\0"), "little")
     mine = torch.tensor([float(ex.get("buckets", 0)), float(ex.get("bytes", 0)), float(split.get("exchange_exposed", 0.0)),
-                         float(split.get("bwd", 0.0))], dtype=torch.float64, device=dev)
+                         float(split.get("bwd", 0.0)), float(dev_index), float(n_visible), float(bus), float(vis_code)],
+                        dtype=torch.float64, device=dev)
     per_rank = [mine]
     if dist is not None and world > 1:
         per_rank = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(per_rank, mine)
+
+    def _vis(code):
+        return None if code < 0 else int(code).to_bytes(6, "little").rstrip(b"\0").decode(errors="replace")
+
     per_rank = [{"rank": r, "buckets": int(v[0]), "bytes": int(v[1]), "exchange_exposed_ms": round(float(v[2]), 2),
-                 "backward_ms": round(float(v[3]), 2)} for r, v in enumerate(per_rank)]
+                 "backward_ms": round(float(v[3]), 2), "device_index": int(v[4]), "visible_devices": int(v[5]),
+                 "pci_bus_id": int(v[6]), "HIP_VISIBLE_DEVICES": _vis(float(v[7]))} for r, v in enumerate(per_rank)]
     multi = dist is not None and world > 1
     backend = dist.get_backend() if multi else None
     return {"collective": ("RCCL" if backend == "nccl" else str(backend)) + " all-reduce (AVG) of fp32 gradients, in place on the flat gradient buffer"
                           if multi else "none (single rank)",
             "backend": backend, "world_size": dist.get_world_size() if multi else 1,
             "buckets": ex.get("buckets", 0), "bytes": ex.get("bytes", 0), "bucket_cap_bytes": cap_bytes,
-            "exposed_ms": round(split.get("exchange_exposed", 0.0), 2), "per_rank": per_rank}
+            "exposed_ms": round(split.get("exchange_exposed", 0.0), 2), "per_rank": per_rank,
+            "distinct_devices": len({(r["pci_bus_id"], r["device_index"], r["HIP_VISIBLE_DEVICES"]) for r in per_rank}) if on_gpu else 0}
 
 
 def res128_step(dev, steps=3, warmup=2):

@@ -177,6 +177,11 @@ def dgrad_wino_weight(layer, name, conv):
                          lambda: ops.WinoWeight(conv.weight, conv.weight.device, kind="conv_dgrad"))
 
 
+def dgrad_wino_weight_f6(layer, name, conv):
+    """f16f6 fragments of the data-gradient conv (hip_ops.WinoWeightF6Dgrad: packed by the step's md_pack_batch table)."""
+    return layer._cached(f"{name}/dgrad_wino_f6", [conv.weight], lambda: ops.WinoWeightF6Dgrad(conv.weight, conv.weight.device))
+
+
 def conv3_backward(layer, name, conv, dy, act_s16, B, S_out, ups=0, stride=1, need_dx=True, act_channels=None,
                    bias_sums=None, shared=None, t_act=None, bias_sums_out=False):
     """Backward of y = conv k^3 (act) (+bias), k = 3 (any layer) or 5 (stem / head of ddpm_res128, stride 1).
@@ -207,13 +212,22 @@ def conv3_backward(layer, name, conv, dy, act_s16, B, S_out, ups=0, stride=1, ne
         bs = None
         if fused_sums:      # the operand pass over dy also adds up its channels: no md_channel_sums pass
             bs = bias_sums if bias_sums is not None else torch.zeros((B, co), dtype=torch.float32, device=dev)
-        t_dy, u_dy = ops.wino_prep([(dy, co)], None, False, False, B, S_out, dual=True, sums=bs)
+        # round 6: the data-gradient conv in f16f6 (hip_ops.DGRAD_F6): the dual operand pass writes T in that format, lifted by a
+        # power of two; U (the weight gradient's operand) and the channel sums are those of the bf16x3 path, bit for bit
+        f6 = ops.DGRAD_F6 and need_dx and co % 32 == 0 and ci % 128 == 0 and 256 % S_out == 0
+        if f6:
+            t_dy, u_dy = ops.wino_prep([(dy, co)], None, False, False, B, S_out, dual=True, sums=bs, f8="f6", tscale=ops.DGRAD_TSCALE)
+        else:
+            t_dy, u_dy = ops.wino_prep([(dy, co)], None, False, False, B, S_out, dual=True, sums=bs)
         if fused_sums:
             _grad_of(conv.bias).add_(bs.sum(0)[:co])
         ops.wgrad_wino(u_dy, t_act, B, co, ci, S_out, _grad_of(conv.weight))
         if not need_dx:
             return None
-        dx = ops.conv3_wino(dgrad_wino_weight(layer, name, conv), t_dy, B, S_out)
+        if f6:
+            dx = ops.conv3_wino(dgrad_wino_weight_f6(layer, name, conv), t_dy, B, S_out, out_scale=1.0 / ops.DGRAD_TSCALE)
+        else:
+            dx = ops.conv3_wino(dgrad_wino_weight(layer, name, conv), t_dy, B, S_out)
         if ups:
             dx = resample(dx, B, ci, S_out // 2, 0)
         return dx

@@ -244,6 +244,9 @@ def _check_dry_run_exchange(d, world):
     for r in ex["per_rank"]:
         assert r["buckets"] == ex["buckets"] and r["bytes"] == ex["bytes"]
         assert 0.0 <= r["exchange_exposed_ms"] < 60_000 and r["backward_ms"] >= 0.0
+        # each rank echoes the device it ran on (CPU dry run: none) so that a first 8-GPU line shows 8 distinct ones
+        assert r["device_index"] == -1 and r["visible_devices"] == 0 and "pci_bus_id" in r and "HIP_VISIBLE_DEVICES" in r
+    assert ex["distinct_devices"] == 0
     assert ex["exposed_ms"] == ex["per_rank"][0]["exchange_exposed_ms"]
 
 
