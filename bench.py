@@ -148,7 +148,7 @@ def main():
     model.module.load_state_dict(sd_cpu, strict=True)
     # load-time calibration of the reduced-precision convs, as evaler.uncond_gen / cond_gen run it after restoring a checkpoint
     # (measured equalisers, per-conv audit against bf16x3; untimed: it happens once per weight set): models/utils.calibrate_model
-    calibration = None if a.no_calibrate else mutils.calibrate_model(model, cfg)
+    calibration = None if a.no_calibrate else mutils.calibrate_model(model, cfg, batch=B)      # at the bench batch: the calibration's launches have the timed launches' shapes (kernel-trace averages stay those of the workload)
     if not (rank == 0 and world == 1 and not a.no_cpu_baseline):
         sd_cpu = None
     sde = sde_lib.VPSDE(cfg.model.beta_min, cfg.model.beta_max, cfg.model.num_scales, device=dev)
