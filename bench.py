@@ -421,15 +421,16 @@ def roofline(events, hip_ops, a, B, wall_prof):
     f8 = wino and a.precision == "f16f8"
     f6 = wino and a.precision == "f16f6"
     if f6:
-        kname = ("md_conv3_wino_kernel<0, true, true> (md_conv3_wino_f6: 3x3x3 conv as Winograd F(2,3) along w, 9 taps x 4 frequencies, one "
+        kname = ("md_conv3_wino_kernel<0, true, true, RES> (both forms: RES = true with a residual operand, false without; md_conv3_wino_f6: "
+                 "3x3x3 conv as Winograd F(2,3) along w, 9 taps x 4 frequencies, one "
                  "frequency per wave; f16f6 arithmetic: per two steps and accumulator tile two v_mfma_f32_32x32x16_f16 + one K-concatenated "
                  "v_mfma_scale_f32_32x32x64_f8f6f4 on MX block-scaled e2m3 cross terms; operand prepared by md_wino_prep_f6)")
     elif f8:
-        kname = ("md_conv3_wino_kernel<0, true> (md_conv3_wino_f8: 3x3x3 conv as Winograd F(2,3) along w, 9 taps x 4 frequencies, one frequency "
+        kname = ("md_conv3_wino_kernel<0, true, false, RES> (md_conv3_wino_f8: 3x3x3 conv as Winograd F(2,3) along w, 9 taps x 4 frequencies, one frequency "
                  "per wave; f16f8 arithmetic: per two steps and accumulator tile two v_mfma_f32_32x32x16_f16 + one K-concatenated "
                  "v_mfma_scale_f32_32x32x64_f8f6f4 (e4m3 cross terms); operand prepared by md_wino_prep_f8)")
     elif wino:
-        kname = ("md_conv3_wino_kernel<0> (3x3x3 conv as Winograd F(2,3) along w: 9 taps x 4 frequencies, bf16x3 MFMA, one frequency "
+        kname = ("md_conv3_wino_kernel<0, false, false, RES> (3x3x3 conv as Winograd F(2,3) along w: 9 taps x 4 frequencies, bf16x3 MFMA, one frequency "
                  "per wave; operand prepared by md_wino_prep)")
     elif fused:
         kname = ("md_conv3_main_kernel<0,0,0,1> (3x3x3 conv, implicit GEMM, bf16x3 MFMA; fp32 operand with GroupNorm "

@@ -312,7 +312,9 @@ __global__ __launch_bounds__(256) void md_wino_prep2_f6_kernel(const float* __re
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         t[e] = f == 0 ? d[0][e] - d[2][e] : f == 1 ? d[1][e] + d[2][e] : f == 2 ? d[2][e] - d[1][e] : d[1][e] - d[3][e];
-        if constexpr (DUAL) t[e] *= tscale;
+        // the lift, saturated at the fp16 plane's range: a gradient element beyond 6e4 / tscale (tscale = 64: ~1e3, four orders of
+        // magnitude above a healthy run's) is clipped instead of turning the whole data gradient into inf / NaN
+        if constexpr (DUAL) t[e] = fminf(fmaxf(t[e] * tscale, -60000.f), 60000.f);
       }
       uint4 h0, h1, r0, r1;
       md_split_f16f6(t, false, 0, h0, h1, r0, r1);

@@ -488,7 +488,7 @@ class WinoWeightF8:
 # two: gradient magnitudes into the fp16 plane's normal range, divided out again by the conv's launch), their weights are packed by the
 # step's md_pack_batch table with a fixed pre-scale.  A/B switch: MD_DGRAD_F6=0 = bf16x3 data gradients (rounds 2-5).
 DGRAD_F6 = os.environ.get("MD_DGRAD_F6", "1") == "1"
-DGRAD_TSCALE = 2.0 ** int(os.environ.get("MD_DGRAD_TSCALE_LOG2", "8"))
+DGRAD_TSCALE = 2.0 ** int(os.environ.get("MD_DGRAD_TSCALE_LOG2", "6"))      # fp16 normal range of the lifted gradient: 1e-6 .. 1e3
 DGRAD_WSCALE_LOG2 = 8
 
 

@@ -129,10 +129,10 @@ def conv3_wino_packed(layer, name, conv, gn=None):
             return None
         gp = [gn.weight, gn.bias] if gn is not None else []
         if ms is None:
-            return layer._cached(f"{name}/wino_eq", [conv.weight] + gp, lambda: ops.wino_equaliser(gn.weight, gn.bias, conv.weight))
+            return layer._cached(f"{name}/wino_eq", [conv.weight] + gp, lambda: ops.wino_equaliser(gn.weight, gn.bias, conv.weight), mark=False)
         return layer._cached(f"{name}/wino_eqm", [conv.weight] + gp + [ms],
                              lambda: ops.wino_equaliser(gn.weight if gn is not None else None, gn.bias if gn is not None else None,
-                                                        conv.weight, a2m=ms))
+                                                        conv.weight, a2m=ms), mark=False)
 
     def build(f8=False):
         if f8:
@@ -140,8 +140,10 @@ def conv3_wino_packed(layer, name, conv, gn=None):
             ms = measured() if ops.WINO_EQ else None
             use_eq = ms is not None or (gn is not None and ops.WINO_EQ)
             deps = [conv.weight] + ([gn.weight, gn.bias] if (use_eq and gn is not None) else []) + ([ms] if ms is not None else [])
+            # mark=False (here and for the equalisers): inference-only entries -- a training step's prewarm_packs must not rebuild them
+            # after every evaluation in between
             return layer._cached(f"{name}/wino_{fmt}{('m' if ms is not None else 'e') if use_eq else ''}", deps,
-                                 lambda: ops.WinoWeightF8(conv.weight, conv.weight.device, fmt, eq=eq()))
+                                 lambda: ops.WinoWeightF8(conv.weight, conv.weight.device, fmt, eq=eq()), mark=False)
         return layer._cached(f"{name}/wino", [conv.weight], lambda: ops.WinoWeight(conv.weight, conv.weight.device))
     build.eq, build.measured = eq, measured
     build.owner, build.site = layer, name      # identifies the conv for per-layer overrides (layer.md_bf16x3_sites), the audit and the calibration

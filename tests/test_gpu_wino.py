@@ -213,7 +213,7 @@ def test_conv3_wino_data_gradient_f16f6(ops, mag):
     """Round 6, training backward: the data-gradient conv of a layer on the Winograd path in f16f6 -- md_wino_prep_dual_f6 (T = the
     f16f6 operand of tscale x dy; U and the channel sums those of md_wino_prep_dual, bit for bit), the flipped f16f6 fragments from an
     MD_PACK_WINO_F6 job of md_pack_batch (fixed pre-scale), md_conv3_wino_f6_scaled.  Against torch float64 at gradient magnitudes from
-    1 down to 3e-6 (the lift 2^8 keeps the fp16 plane normal down to ~2e-7)."""
+    1 down to 3e-6 (the lift 2^6 keeps the fp16 plane normal down to ~1e-6; beyond ~1e3 it saturates instead of overflowing)."""
     B, S, ci, co = 2, 16, 128, 160
     w = _rand((co, ci, 3, 3, 3), 70, 0.05)
     dy = _rand((B, co, S, S, S), 71) * mag
@@ -238,6 +238,11 @@ def test_conv3_wino_data_gradient_f16f6(ops, mag):
     t_plain = ops.wino_prep(parts, None, False, False, B, S, f8="f6")
     dx_plain = ops.f32b_to_ncdhw(ops.conv3_wino(ops.WinoWeightF8(wt.cuda(), "cuda", "f6"), t_plain, B, S), (S, S, S)).cpu()
     assert rel_l2(dx_plain, ref) < (4e-5 if mag >= 1e-3 else 1.0)                        # the unscaled operand degrades at tiny magnitudes: why tscale exists
+    if mag == 1.0:      # far outside a healthy run: the lift saturates at the fp16 range -- clipped elements, never inf / NaN
+        big = [(ops.ncdhw_to_f32b((dy * 1e4).cuda()), co)]
+        tb, _ = ops.wino_prep(big, None, False, False, B, S, dual=True, sums=None, f8="f6", tscale=ops.DGRAD_TSCALE)
+        dxb = ops.conv3_wino(ww, tb, B, S, out_scale=1.0 / ops.DGRAD_TSCALE)
+        assert bool(torch.isfinite(dxb).all())
 
 
 def test_wino_prep_dual_second_output_bit_exact(ops):

@@ -20,11 +20,18 @@ import bench  # noqa: E402
 KERNEL = "md_conv3_wino_kernel"
 
 
-def counter(path, name):
+def counter(path, name, form):
+    """Launch-weighted mean of counter `name` over the summary lines of KERNEL whose template arguments start with `form`
+    (round 6: the kernel exists in a residual and a no-residual form per arithmetic: "<0, true, true" = both f16f6 forms)."""
+    tot = n = 0.0
     for ln in open(path):
-        if KERNEL in ln and f"{name}=" in ln:
-            return float(re.search(name + r"=([0-9.e+]+)", ln).group(1))
-    raise SystemExit(f"{name} of {KERNEL} not found in {path}")
+        if KERNEL + form in ln and f"{name}=" in ln:
+            k = float(re.search(r"n=\s*(\d+)", ln).group(1))
+            tot += k * float(re.search(name + r"=([0-9.e+]+)", ln).group(1))
+            n += k
+    if not n:
+        raise SystemExit(f"{name} of {KERNEL}{form} not found in {path}")
+    return tot / n
 
 
 def main():
@@ -36,9 +43,11 @@ def main():
     ap.add_argument("--kernel", default=KERNEL, help="substring of the kernel name in the summaries")
     ap.add_argument("--source", default="conv3_wino.hip", help="source file whose sha keys the entry")
     ap.add_argument("--precision", default="f16f6", help="hip_precision of the profiled run (bench.py reports the entry only for the same one)")
+    ap.add_argument("--form", default=None, help="leading template arguments of the kernel forms to average over (default: by --precision)")
     a = ap.parse_args()
     KERNEL = a.kernel
-    fetch_kib, write_kib = counter(a.fetch, "FETCH_SIZE"), counter(a.write, "WRITE_SIZE")
+    form = a.form if a.form is not None else {"f16f6": "<0, true, true", "f16f8": "<0, true, false", "bf16x3": "<0, false, false"}[a.precision]
+    fetch_kib, write_kib = counter(a.fetch, "FETCH_SIZE", form), counter(a.write, "WRITE_SIZE", form)
     nbytes = (2.0 * fetch_kib + write_kib) * 1024.0
     try:
         with open(bench.TRAFFIC_FILE) as fh:
@@ -46,7 +55,7 @@ def main():
     except OSError:
         tr = {}
     key = bench.conv_source_key(a.source)
-    tr[key] = {"kernel": f"{KERNEL} (the build bench.py runs by default)", "hbm_bytes_per_launch": round(nbytes), "batch": a.batch, "precision": a.precision,
+    tr[key] = {"kernel": f"{KERNEL}{form}, ...> (the build bench.py runs by default; launch-weighted over its residual / no-residual forms)", "hbm_bytes_per_launch": round(nbytes), "batch": a.batch, "precision": a.precision,
                "fetch_size_kib": fetch_kib, "write_size_kib": write_kib,
                "formula": "(2*FETCH_SIZE + WRITE_SIZE) KiB, mean over the launches of `python bench.py`",
                "source": f"{os.path.relpath(a.fetch, ROOT)} + {os.path.relpath(a.write, ROOT)}"}
