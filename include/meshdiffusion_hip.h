@@ -322,17 +322,21 @@ int md_conv3_wino_f8(const void* t_in, const void* wpk, float* out, const float*
                      int32_t D, int32_t H, int32_t W, void* stream);
 /*
  * Training (ABI 15): the data-gradient convs of a step in the f16f6 arithmetic.
+ * md_absmax: amax_bits[0] = max(amax_bits[0], max |x|) as the bit pattern of the float (the caller zeroes the word; x 16-byte aligned).
  * md_wino_prep_dual_f6: as md_wino_prep_dual for ONE raw fp32 part (an output gradient; c % 16 == 0, W | 256), except that T is the
- *   f16f6 operand of md_conv3_wino_f6 of `tscale` x the tensor (tscale a power of two: gradient magnitudes lifted into the fp16
- *   plane's normal range); U (md_wgrad_wino's operand) and sums are those of the unscaled tensor, bit-identical to md_wino_prep_dual's.
- * md_conv3_wino_f6_scaled: md_conv3_wino_f6 whose result is multiplied by out_scale (= 1 / tscale, exact).
+ *   f16f6 operand of md_conv3_wino_f6 of 2^k x the tensor (gradient magnitudes lifted into the fp16 plane's normal range, saturated
+ *   at its ends): amax_bits != NULL: k from the word md_absmax filled for this tensor (max |x| 2^k in [16, 32)); NULL: 2^k = tscale.
+ *   U (md_wgrad_wino's operand) and sums are those of the unscaled tensor, bit-identical to md_wino_prep_dual's.
+ * md_conv3_wino_f6_scaled: md_conv3_wino_f6 whose result is multiplied by out_scale (exact: a power of two) and, with amax_bits, by
+ *   the inverse of the lift the operand pass derived from the same word.
  * The weights: an MD_PACK_WINO_F6 job of md_pack_batch (fixed pre-scale, `flip` for the data-gradient orientation).
  */
-int md_wino_prep_dual_f6(const float* x, int32_t c, void* t_out, void* u_out, float* sums, float tscale, int32_t batch, int32_t D,
-                         int32_t H, int32_t W, void* stream);
+int md_absmax(const float* x, int64_t n, uint32_t* amax_bits, void* stream);
+int md_wino_prep_dual_f6(const float* x, int32_t c, void* t_out, void* u_out, float* sums, float tscale, const uint32_t* amax_bits,
+                         int32_t batch, int32_t D, int32_t H, int32_t W, void* stream);
 int md_conv3_wino_f6_scaled(const void* t_in, const void* wpk, float* out, const float* bias, int64_t bias_bstride,
                             const float* residual, int64_t res_bstride, double* stats, int32_t batch, int32_t cin, int32_t cout,
-                            int32_t D, int32_t H, int32_t W, float out_scale, void* stream);
+                            int32_t D, int32_t H, int32_t W, float out_scale, const uint32_t* amax_bits, void* stream);
 
 /*
  * The same convolution in the "f16f6" arithmetic: as f16f8, the two cross terms from MX block-scaled OCP e2m3 images (a K block = 16

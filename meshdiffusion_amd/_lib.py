@@ -91,8 +91,9 @@ SIGNATURES = {
     "md_wino_weight_bytes_f8": (_I64, [_I32, _I32]),
     "md_wino_pack_weights_f8": (C.c_int, [_P, _P, _P, _I32, _I32, _I64, _I64, _P]),
     "md_conv3_wino_f8": (C.c_int, [_P, _P, _P, _P, _I64, _P, _I64, _P, _I32, _I32, _I32, _I32, _I32, _I32, _P]),
-    "md_wino_prep_dual_f6": (C.c_int, [_P, _I32, _P, _P, _P, _F, _I32, _I32, _I32, _I32, _P]),
-    "md_conv3_wino_f6_scaled": (C.c_int, [_P, _P, _P, _P, _I64, _P, _I64, _P, _I32, _I32, _I32, _I32, _I32, _I32, _F, _P]),
+    "md_absmax": (C.c_int, [_P, _I64, _P, _P]),
+    "md_wino_prep_dual_f6": (C.c_int, [_P, _I32, _P, _P, _P, _F, _P, _I32, _I32, _I32, _I32, _P]),
+    "md_conv3_wino_f6_scaled": (C.c_int, [_P, _P, _P, _P, _I64, _P, _I64, _P, _I32, _I32, _I32, _I32, _I32, _I32, _F, _P, _P]),
     "md_wino_prep_f6": (C.c_int, [_P, _P, _I32, _I32, _P, _I32, _I32, _P, _P, _I32, _I32, _I32, _I32, _P]),
     "md_wino_pack_weights_f6": (C.c_int, [_P, _P, _P, _I32, _I32, _I64, _I64, _P]),
     "md_conv3_wino_f6": (C.c_int, [_P, _P, _P, _P, _I64, _P, _I64, _P, _I32, _I32, _I32, _I32, _I32, _I32, _P]),

@@ -199,6 +199,7 @@ struct WnArgs {
   int64_t bias_bstride, res_bstride;
   int batch, cin, cout, D, H, W;
   float out_scale;         // F8: multiplies the weights' descale (1, or 1 / tscale of md_wino_prep_dual_f6: a power of two)
+  const uint32_t* amax;    // F8, may be null: the operand was lifted by 2^md_dgrad_lift_log2(amax[0]) (md_wino_prep_dual_f6's dynamic form)
 };
 
 // ABL (timing only, results invalid; -DMD_BUILD_ABLATIONS, tools/bench_wino.py): bit 0 no halo traffic, bit 1 halo traffic in the
@@ -446,6 +447,7 @@ __global__ __launch_bounds__(WN_THREADS) void md_conv3_wino_kernel(const WnArgs 
       }
       if constexpr (W8_PRO_FENCE) zero_acc();
       descale = A.hdr[2] * A.out_scale;
+      if (A.amax != nullptr) descale *= ldexpf(1.f, -md_dgrad_lift_log2(A.amax[0]));
       if constexpr (W8_PRO_FENCE) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int k = 0; k < WN_NDMA; ++k) halo_store8(0, k, h0[k]);
@@ -954,7 +956,8 @@ extern "C" int md_wino_pack_weights_f6(const float* w, const float* eq, void* wp
 
 static int md_conv3_wino_f8_launch(bool f6, const void* t_in, const void* wpk, float* out, const float* bias, int64_t bias_bstride,
                                    const float* residual, int64_t res_bstride, double* stats, int32_t batch, int32_t cin,
-                                   int32_t cout, int32_t D, int32_t H, int32_t W, void* stream, float out_scale = 1.0f) {
+                                   int32_t cout, int32_t D, int32_t H, int32_t W, void* stream, float out_scale = 1.0f,
+                                   const uint32_t* amax = nullptr) {
   if (!t_in || !wpk || !out || batch <= 0) return MD_ERR_BAD_ARG;
   if (cin <= 0 || cout <= 0 || (cin % 32) || (cout % 128)) return MD_ERR_UNSUPPORTED;
   if (D <= 0 || H <= 0 || W <= 0 || (D % WN_TZ) || (H % WN_TY) || (W % WN_TX)) return MD_ERR_UNSUPPORTED;
@@ -962,7 +965,7 @@ static int md_conv3_wino_f8_launch(bool f6, const void* t_in, const void* wpk, f
   WnArgs a;
   a.T = (const uint4*)t_in; a.wpk = (const uint4*)wpk; a.out = out; a.bias = bias; a.residual = residual; a.stats = stats;
   a.hdr = (const float*)((const unsigned char*)wpk + (int64_t)cout * cin * 36 * 4);
-  a.out_scale = out_scale;
+  a.out_scale = out_scale; a.amax = amax;
   a.bias_bstride = bias_bstride; a.res_bstride = res_bstride;
   a.batch = batch; a.cin = cin; a.cout = cout; a.D = D; a.H = H; a.W = W;
   const int tiles = (D / WN_TZ) * (H / WN_TY) * (W / WN_TX);
@@ -995,9 +998,10 @@ extern "C" int md_conv3_wino_f6(const void* t_in, const void* wpk, float* out, c
 
 extern "C" int md_conv3_wino_f6_scaled(const void* t_in, const void* wpk, float* out, const float* bias, int64_t bias_bstride,
                                        const float* residual, int64_t res_bstride, double* stats, int32_t batch, int32_t cin,
-                                       int32_t cout, int32_t D, int32_t H, int32_t W, float out_scale, void* stream) {
+                                       int32_t cout, int32_t D, int32_t H, int32_t W, float out_scale, const uint32_t* amax_bits, void* stream) {
   if (!(out_scale > 0.f)) return MD_ERR_BAD_ARG;
-  return md_conv3_wino_f8_launch(true, t_in, wpk, out, bias, bias_bstride, residual, res_bstride, stats, batch, cin, cout, D, H, W, stream, out_scale);
+  return md_conv3_wino_f8_launch(true, t_in, wpk, out, bias, bias_bstride, residual, res_bstride, stats, batch, cin, cout, D, H, W, stream, out_scale,
+                                 amax_bits);
 }
 
 extern "C" int md_conv3_wino(const void* t_in, const void* wpk, float* out, const float* bias, int64_t bias_bstride,
@@ -1010,7 +1014,7 @@ extern "C" int md_conv3_wino(const void* t_in, const void* wpk, float* out, cons
   WnArgs a;
   a.T = (const uint4*)t_in; a.wpk = (const uint4*)wpk; a.out = out; a.bias = bias; a.residual = residual; a.stats = stats;
   a.hdr = nullptr;
-  a.out_scale = 1.0f;
+  a.out_scale = 1.0f; a.amax = nullptr;
   a.bias_bstride = bias_bstride; a.res_bstride = res_bstride;
   a.batch = batch; a.cin = cin; a.cout = cout; a.D = D; a.H = H; a.W = W;
   const int tiles = (D / WN_TZ) * (H / WN_TY) * (W / WN_TX);

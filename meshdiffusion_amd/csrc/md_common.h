@@ -155,6 +155,15 @@ __device__ __forceinline__ float md_wave_sum(float v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+// Dynamic power-of-two lift of a training data gradient (md_absmax -> md_wino_prep_dual_f6 -> md_conv3_wino_f6_scaled): the exponent k with
+// max |dy| * 2^k in [16, 32) -- after the Winograd input transform (x2) still 10 binades under the fp16 maximum, and the fp16 plane stays
+// normal for elements down to 2^-19 of the largest.  Operand pass and conv derive k from the same word, so they agree bit for bit.
+__device__ __forceinline__ int md_dgrad_lift_log2(uint32_t amax_bits) {
+  const float amax = __uint_as_float(amax_bits);
+  if (!(amax > 0.f) || !(amax < 3e38f)) return 0;
+  const int k = 4 - ilogbf(amax);
+  return k < -60 ? -60 : (k > 60 ? 60 : k);
+}
 __device__ __forceinline__ float md_wave_max(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));

@@ -141,6 +141,32 @@ extern "C" int md_masked_sq_err(const float* eps_hat, const float* noise, const 
   return MD_OK;
 }
 
+// md_absmax: amax_bits[0] = max(amax_bits[0], max |x|) as the float's bit pattern (non-negative floats order like their bits); NaN never
+// wins, +inf does.  The caller zeroes the word.  One streaming read; used for the dynamic lift of the f16f6 data-gradient convs.
+__global__ __launch_bounds__(256) void md_absmax_kernel(const float* __restrict__ x, int64_t n4, int64_t n, uint32_t* __restrict__ amax_bits) {
+  float m = 0.f;
+  const f32x4* x4 = (const f32x4*)x;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const f32x4 v = x4[i];
+    m = fmaxf(m, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+  }
+  if (blockIdx.x == 0)
+    for (int64_t i = n4 * 4 + threadIdx.x; i < n; i += 256) m = fmaxf(m, fabsf(x[i]));
+  m = md_wave_max(m);
+  if ((threadIdx.x & 63) == 0) atomicMax(amax_bits, __float_as_uint(m));
+}
+
+extern "C" int md_absmax(const float* x, int64_t n, uint32_t* amax_bits, void* stream) {
+  if (!x || !amax_bits || n <= 0 || ((uintptr_t)x & 15)) return MD_ERR_BAD_ARG;
+  const int64_t n4 = n / 4;
+  int64_t blocks = (n4 + 256 * 8 - 1) / (256 * 8);
+  blocks = blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks);
+  MD_HIP_CLEAR_ERROR();
+  hipLaunchKernelGGL(md_absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, n4, n, amax_bits);
+  MD_HIP_CHECK_LAUNCH();
+  return MD_OK;
+}
+
 extern "C" int md_grad_sqnorm(const float* g, int64_t n, double* out, void* stream) {
   if (!g || !out || n <= 0 || ((uintptr_t)g & 15)) return MD_ERR_BAD_ARG;
   int blocks = grid_for(n / 4);

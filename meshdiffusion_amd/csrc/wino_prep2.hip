@@ -208,9 +208,12 @@ template <bool DUAL>
 __global__ __launch_bounds__(256) void md_wino_prep2_f6_kernel(const float* __restrict__ x1, const float* __restrict__ x2, int c1, int c2,
                                                                const float* __restrict__ ac, int silu, int ups, uint4* __restrict__ T, int batch,
                                                                int D, int H, int W, const float* __restrict__ eq, uint4* __restrict__ U,
-                                                               float* __restrict__ sums, float tscale) {
+                                                               float* __restrict__ sums, float tscale, const uint32_t* __restrict__ amax_bits) {
   __shared__ __attribute__((aligned(16))) float act[2 * P2_GROUP];
   __shared__ float wsum[4][16];                    // DUAL with sums: [wave][channel]
+  if constexpr (DUAL) {
+    if (amax_bits != nullptr) tscale = ldexpf(1.f, md_dgrad_lift_log2(amax_bits[0]));      // the dynamic lift (md_absmax of this tensor)
+  }
   const int tid = threadIdx.x;
   const int Wp = W >> 1;
   const int64_t P = (int64_t)D * H * W, Ph = P >> 1;
@@ -312,8 +315,8 @@ __global__ __launch_bounds__(256) void md_wino_prep2_f6_kernel(const float* __re
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         t[e] = f == 0 ? d[0][e] - d[2][e] : f == 1 ? d[1][e] + d[2][e] : f == 2 ? d[2][e] - d[1][e] : d[1][e] - d[3][e];
-        // the lift, saturated at the fp16 plane's range: a gradient element beyond 6e4 / tscale (tscale = 64: ~1e3, four orders of
-        // magnitude above a healthy run's) is clipped instead of turning the whole data gradient into inf / NaN
+        // the lift (dynamic: max |dy| lands in [16, 32); or the caller's constant), saturated at the fp16 plane's range so that a
+        // constant lift can clip an element but never turn the whole data gradient into inf / NaN
         if constexpr (DUAL) t[e] = fminf(fmaxf(t[e] * tscale, -60000.f), 60000.f);
       }
       uint4 h0, h1, r0, r1;
@@ -406,22 +409,22 @@ extern "C" int md_wino_prep_f6(const float* x1, const float* x2, int32_t c1, int
   if (blocks > 0x7fffffff) return MD_ERR_UNSUPPORTED;
   MD_HIP_CLEAR_ERROR();
   hipLaunchKernelGGL(md_wino_prep2_f6_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x1, x2, c1, c2, ac, silu, ups,
-                     (uint4*)t_out, batch, D, H, W, eq, (uint4*)nullptr, (float*)nullptr, 1.0f);
+                     (uint4*)t_out, batch, D, H, W, eq, (uint4*)nullptr, (float*)nullptr, 1.0f, (const uint32_t*)nullptr);
   MD_HIP_CHECK_LAUNCH();
   return MD_OK;
 }
 
-extern "C" int md_wino_prep_dual_f6(const float* x, int32_t c, void* t_out, void* u_out, float* sums, float tscale, int32_t batch, int32_t D,
-                                    int32_t H, int32_t W, void* stream) {
+extern "C" int md_wino_prep_dual_f6(const float* x, int32_t c, void* t_out, void* u_out, float* sums, float tscale, const uint32_t* amax_bits,
+                                    int32_t batch, int32_t D, int32_t H, int32_t W, void* stream) {
   if (!x || !t_out || !u_out || batch <= 0 || c <= 0 || (c & 15)) return MD_ERR_BAD_ARG;
-  if (D <= 0 || H <= 0 || W <= 0 || (W & 1) || !(tscale > 0.f)) return MD_ERR_BAD_ARG;
+  if (D <= 0 || H <= 0 || W <= 0 || (W & 1) || (!amax_bits && !(tscale > 0.f))) return MD_ERR_BAD_ARG;
   const int64_t P = (int64_t)D * H * W;
   if ((P2_POS % W) || (P % P2_POS)) return MD_ERR_UNSUPPORTED;
   const int64_t blocks = (int64_t)batch * (c / 16) * (P / P2_POS);
   if (blocks > 0x7fffffff) return MD_ERR_UNSUPPORTED;
   MD_HIP_CLEAR_ERROR();
   hipLaunchKernelGGL(md_wino_prep2_f6_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, (const float*)nullptr, c, 0,
-                     (const float*)nullptr, 0, 0, (uint4*)t_out, batch, D, H, W, (const float*)nullptr, (uint4*)u_out, sums, tscale);
+                     (const float*)nullptr, 0, 0, (uint4*)t_out, batch, D, H, W, (const float*)nullptr, (uint4*)u_out, sums, tscale, amax_bits);
   MD_HIP_CHECK_LAUNCH();
   return MD_OK;
 }

@@ -488,8 +488,26 @@ class WinoWeightF8:
 # two: gradient magnitudes into the fp16 plane's normal range, divided out again by the conv's launch), their weights are packed by the
 # step's md_pack_batch table with a fixed pre-scale.  A/B switch: MD_DGRAD_F6=0 = bf16x3 data gradients (rounds 2-5).
 DGRAD_F6 = os.environ.get("MD_DGRAD_F6", "1") == "1"
-DGRAD_TSCALE = 2.0 ** int(os.environ.get("MD_DGRAD_TSCALE_LOG2", "6"))      # fp16 normal range of the lifted gradient: 1e-6 .. 1e3
+# the lift of the data gradient: "dyn" (default) = per launch from the tensor's own maximum (md_absmax: one more read of dy, no host
+# round trip: operand pass and conv both derive the exponent from the same device word); an integer = the constant 2^that (A/B)
+DGRAD_LIFT = os.environ.get("MD_DGRAD_LIFT", "dyn")
+DGRAD_TSCALE = 2.0 ** int(DGRAD_LIFT) if DGRAD_LIFT != "dyn" else 64.0
 DGRAD_WSCALE_LOG2 = 8
+_AMAX_SLOTS = {}
+
+
+def absmax_word(x):
+    """int32 [1] device word holding max |x| of the fp32 tensor as a float bit pattern (md_absmax) -- for wino_prep(dual, f8="f6", amax=...)
+    and conv3_wino(amax=...).  Words come out of a zeroed arena per (device, stream), refilled when used up."""
+    lib = _lib.load()
+    key = (x.device.index, torch.cuda.current_stream(x.device).cuda_stream)
+    arena = _AMAX_SLOTS.get(key)
+    if arena is None or arena[1] >= arena[0].numel():
+        arena = _AMAX_SLOTS[key] = [torch.zeros(1024, dtype=torch.int32, device=x.device), 0]
+    word = arena[0][arena[1]:arena[1] + 1]
+    arena[1] += 1
+    check(lib.md_absmax(_ptr(x), x.numel(), _ptr(word), _stream()), "md_absmax")
+    return word
 
 
 class WinoWeightF6Dgrad:
@@ -628,7 +646,7 @@ def wino_f8_ok(S, drop=None, keep=False, parts=None, normalised=True):
     return WINO_F8
 
 
-def wino_prep(parts, ac, silu, ups, B, S, drop=None, keep=False, dual=False, sums=None, f8=False, eq=None, tscale=1.0):
+def wino_prep(parts, ac, silu, ups, B, S, drop=None, keep=False, dual=False, sums=None, f8=False, eq=None, tscale=1.0, amax=None):
     """fp32 F32B parts (+ folded GroupNorm affine, SiLU, nearest-x2 upsampling) -> transformed split operand T.
     drop = (p, seed): training dropout after SiLU, the mask gn_apply(drop=...) produces for the same pair.
     keep: T goes to its own tensor instead of the shared scratch buffer (training forward: the Winograd weight gradient of the
@@ -654,7 +672,7 @@ def wino_prep(parts, ac, silu, ups, B, S, drop=None, keep=False, dual=False, sum
         # unscaled gradient (md_wgrad_wino), sums = its channel sums
         assert f8 == "f6" and len(parts) == 1 and ac is None and not (ups or keep or drop or eq is not None) and 256 % S == 0
         u = _wino_scratch(nbytes // 2, dev, slot="u")
-        check(lib.md_wino_prep_dual_f6(_ptr(parts[0][0]), cin, _ptr(t), _ptr(u), _ptr(sums), float(tscale), B, S, S, S, _stream()),
+        check(lib.md_wino_prep_dual_f6(_ptr(parts[0][0]), cin, _ptr(t), _ptr(u), _ptr(sums), float(tscale), _ptr(amax), B, S, S, S, _stream()),
               "md_wino_prep_dual_f6")
     elif f8:
         assert not (dual or keep or drop), "the f16f8 / f16f6 operand is an inference format"
@@ -707,7 +725,8 @@ def wgrad_wino(u_dy, t_act, B, co, ci, S, dw):
 WINO_VARIANT = int(os.environ.get("MD_WINO_VARIANT", "0"))
 
 
-def conv3_wino(ww, t, B, S, *, bias=None, bias_bstride=0, residual=None, res_bstride=0, stats=None, out=None, variant=None, out_scale=1.0):
+def conv3_wino(ww, t, B, S, *, bias=None, bias_bstride=0, residual=None, res_bstride=0, stats=None, out=None, variant=None, out_scale=1.0,
+               amax=None):
     lib = _lib.load()
     P = S ** 3
     if out is None:
@@ -719,10 +738,11 @@ def conv3_wino(ww, t, B, S, *, bias=None, bias_bstride=0, residual=None, res_bst
         want = ww.fmt if f8 else False
         if t_fmt != want or getattr(t, "_md_eq", 0) != ((ww.eq.data_ptr() if ww.eq is not None else 0) if f8 else 0):
             raise _lib.MeshDiffusionHipError(f"conv3_wino: operand format {t_fmt!r} / equaliser does not belong to these weights ({want!r})")
-    if f8 and out_scale != 1.0:
+    if f8 and (out_scale != 1.0 or amax is not None):
         assert ww.fmt == "f6"
         check(lib.md_conv3_wino_f6_scaled(_ptr(t), _ptr(ww.data), _ptr(out), _ptr(bias), bias_bstride, _ptr(residual), res_bstride,
-                                          _ptr(stats), B, ww.kdim, ww.rows, S, S, S, float(out_scale), _stream()), "md_conv3_wino_f6_scaled")
+                                          _ptr(stats), B, ww.kdim, ww.rows, S, S, S, float(out_scale), _ptr(amax), _stream()),
+              "md_conv3_wino_f6_scaled")
     elif f8:
         fn = lib.md_conv3_wino_f6 if ww.fmt == "f6" else lib.md_conv3_wino_f8
         check(fn(_ptr(t), _ptr(ww.data), _ptr(out), _ptr(bias), bias_bstride, _ptr(residual), res_bstride,

@@ -213,10 +213,14 @@ def conv3_backward(layer, name, conv, dy, act_s16, B, S_out, ups=0, stride=1, ne
         if fused_sums:      # the operand pass over dy also adds up its channels: no md_channel_sums pass
             bs = bias_sums if bias_sums is not None else torch.zeros((B, co), dtype=torch.float32, device=dev)
         # round 6: the data-gradient conv in f16f6 (hip_ops.DGRAD_F6): the dual operand pass writes T in that format, lifted by a
-        # power of two; U (the weight gradient's operand) and the channel sums are those of the bf16x3 path, bit for bit
+        # power of two that follows the tensor's own maximum; U (the weight gradient's operand) and the channel sums are those of
+        # the bf16x3 path, bit for bit
         f6 = ops.DGRAD_F6 and need_dx and co % 32 == 0 and ci % 128 == 0 and 256 % S_out == 0
+        amax = None
         if f6:
-            t_dy, u_dy = ops.wino_prep([(dy, co)], None, False, False, B, S_out, dual=True, sums=bs, f8="f6", tscale=ops.DGRAD_TSCALE)
+            if ops.DGRAD_LIFT == "dyn":
+                amax = ops.absmax_word(dy)          # the lift follows this tensor's own largest element (device-side: no host sync)
+            t_dy, u_dy = ops.wino_prep([(dy, co)], None, False, False, B, S_out, dual=True, sums=bs, f8="f6", tscale=ops.DGRAD_TSCALE, amax=amax)
         else:
             t_dy, u_dy = ops.wino_prep([(dy, co)], None, False, False, B, S_out, dual=True, sums=bs)
         if fused_sums:
@@ -225,7 +229,8 @@ def conv3_backward(layer, name, conv, dy, act_s16, B, S_out, ups=0, stride=1, ne
         if not need_dx:
             return None
         if f6:
-            dx = ops.conv3_wino(dgrad_wino_weight_f6(layer, name, conv), t_dy, B, S_out, out_scale=1.0 / ops.DGRAD_TSCALE)
+            dx = ops.conv3_wino(dgrad_wino_weight_f6(layer, name, conv), t_dy, B, S_out,
+                                out_scale=1.0 if amax is not None else 1.0 / ops.DGRAD_TSCALE, amax=amax)
         else:
             dx = ops.conv3_wino(dgrad_wino_weight(layer, name, conv), t_dy, B, S_out)
         if ups:

@@ -343,10 +343,12 @@ def test_flat_optimizer_state_follows_replaced_parameter_storage(hip_lib):
 
 
 def test_res64_batch8_training_gradients_winograd_vs_direct_kernels(hip_lib):
-    """the whole res64 loss + backward at the bench / training batch (B = 8), once with the Winograd
+    """the whole res64 loss + backward at the bench / training batch (B = 8), with the Winograd
     forward and data-gradient convs (64^3, 32^3 AND 16^3 levels at this batch) and once with the direct kernels
     (MD_WINO=0, the build pinned to the reference's autograd by `res64` / `res64_b2` above): loss and all 494 parameter
-    gradients must agree to 5e-5."""
+    gradients must agree to 5e-5 in the same arithmetic (bf16x3 data gradients: hip_ops.DGRAD_F6 off).  Round 6: the shipped
+    configuration runs the data-gradient convs of the Winograd layers in f16f6 (1.7e-5 per conv, accumulating along the ~20
+    convs between the loss and the stem): all gradients together stay under 5e-5, the worst single tensor under 1e-4."""
     from oracle.gen_golden import fixed_draws, train_step_inputs
     from meshdiffusion_amd import hip_ops, synth
     from meshdiffusion_amd.config import get_config_res64
@@ -363,13 +365,19 @@ def test_res64_batch8_training_gradients_winograd_vs_direct_kernels(hip_lib):
     sde = sde_lib.VPSDE(cfg.model.beta_min, cfg.model.beta_max, cfg.model.num_scales, device="cuda")
     loss_fn = losses.get_ddpm_loss_fn(sde, train=True, mask=mask.cuda())
     runs = {}
-    keep = hip_ops.WINO
+    keep, keep_f6 = hip_ops.WINO, hip_ops.DGRAD_F6
     try:
-        for wino in (True, False):
-            hip_ops.WINO = wino
-            seen = []
+        for key, wino, f6 in (("wino_f6", True, True), ("wino", True, False), ("direct", False, False)):
+            hip_ops.WINO, hip_ops.DGRAD_F6 = wino, f6
+            seen, seen_f6 = [], []
             real = hip_ops.conv3_wino
-            hip_ops.conv3_wino = lambda ww, t, B_, S_, **kw: (seen.append(S_), real(ww, t, B_, S_, **kw))[1]
+
+            def spy(ww, t, B_, S_, **kw):
+                seen.append(S_)
+                if isinstance(ww, hip_ops.WinoWeightF6Dgrad):
+                    seen_f6.append(S_)
+                return real(ww, t, B_, S_, **kw)
+            hip_ops.conv3_wino = spy
             try:
                 for p in model.parameters():
                     p.grad = None
@@ -378,25 +386,30 @@ def test_res64_batch8_training_gradients_winograd_vs_direct_kernels(hip_lib):
                 loss.backward()
             finally:
                 hip_ops.conv3_wino = real
-            runs[wino] = (float(loss.detach()), {n: p.grad.detach().cpu().clone() for n, p in model.module.named_parameters()
-                                                 if p.grad is not None}, sorted(set(seen)))
+            runs[key] = (float(loss.detach()), {n: p.grad.detach().cpu().clone() for n, p in model.module.named_parameters()
+                                                if p.grad is not None}, sorted(set(seen)), len(seen_f6))
     finally:
-        hip_ops.WINO = keep
-    (l1, g1, s1), (l0, g0, s0) = runs[True], runs[False]
-    assert s1 == [16, 32, 64] and s0 == [], (s1, s0)
-    assert abs(l1 - l0) <= 2e-6 * abs(l0), (l1, l0)
-    assert g1.keys() == g0.keys() and len(g0) == 494
+        hip_ops.WINO, hip_ops.DGRAD_F6 = keep, keep_f6
+    (l0, g0, s0, n0) = runs["direct"]
+    assert s0 == [] and n0 == 0
+    assert len(g0) == 494
     gsq = sum(float(g.double().square().sum()) for g in g0.values())
     ntot = sum(g.numel() for g in g0.values())
-    num, worst = 0.0, ("", 0.0)
-    for n in g0:
-        d = float((g1[n].double() - g0[n].double()).square().sum())
-        num += d
-        # per tensor: relative to its own norm, floored at the norm an average-sized entry would give this tensor
-        floor = (gsq / ntot * g0[n].numel()) ** 0.5 * 1e-2
-        e = d ** 0.5 / max(float(g0[n].double().norm()), floor)
-        if e > worst[1]:
-            worst = (n, e)
-    print(f"res64 B=8 training gradients, Winograd vs direct kernels: loss {l1:.6f} / {l0:.6f}, all gradients rel-L2 "
-          f"{(num / gsq) ** 0.5:.3e}, worst tensor {worst}")
-    assert (num / gsq) ** 0.5 < 5e-5 and worst[1] < 5e-5
+    for key, bar_all, bar_worst in (("wino", 5e-5, 5e-5), ("wino_f6", 5e-5, 1e-4)):
+        l1, g1, s1, n1 = runs[key]
+        assert s1 == [16, 32, 64], s1
+        assert (n1 >= 20) if key == "wino_f6" else (n1 == 0), n1          # the f16f6 data-gradient launches really ran / really did not
+        assert abs(l1 - l0) <= 2e-6 * abs(l0), (l1, l0)
+        assert g1.keys() == g0.keys()
+        num, worst = 0.0, ("", 0.0)
+        for n in g0:
+            d = float((g1[n].double() - g0[n].double()).square().sum())
+            num += d
+            # per tensor: relative to its own norm, floored at the norm an average-sized entry would give this tensor
+            floor = (gsq / ntot * g0[n].numel()) ** 0.5 * 1e-2
+            e = d ** 0.5 / max(float(g0[n].double().norm()), floor)
+            if e > worst[1]:
+                worst = (n, e)
+        print(f"res64 B=8 training gradients, Winograd ({'f16f6' if key == 'wino_f6' else 'bf16x3'} data gradients) vs direct kernels: loss "
+              f"{l1:.6f} / {l0:.6f}, all gradients rel-L2 {(num / gsq) ** 0.5:.3e}, worst tensor {worst}")
+        assert (num / gsq) ** 0.5 < bar_all and worst[1] < bar_worst

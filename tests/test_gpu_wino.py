@@ -208,41 +208,49 @@ def test_conv3_wino_rejects_unsupported_shapes(ops):
 _ = np
 
 
-@pytest.mark.parametrize("mag", [1.0, 1e-3, 3e-6])
-def test_conv3_wino_data_gradient_f16f6(ops, mag):
-    """Round 6, training backward: the data-gradient conv of a layer on the Winograd path in f16f6 -- md_wino_prep_dual_f6 (T = the
-    f16f6 operand of tscale x dy; U and the channel sums those of md_wino_prep_dual, bit for bit), the flipped f16f6 fragments from an
-    MD_PACK_WINO_F6 job of md_pack_batch (fixed pre-scale), md_conv3_wino_f6_scaled.  Against torch float64 at gradient magnitudes from
-    1 down to 3e-6 (the lift 2^6 keeps the fp16 plane normal down to ~1e-6; beyond ~1e3 it saturates instead of overflowing)."""
+@pytest.mark.parametrize("lift", ["dyn", "const64"])
+@pytest.mark.parametrize("mag", [1.0, 1e-3, 3e-6, 1e-9])
+def test_conv3_wino_data_gradient_f16f6(ops, mag, lift):
+    """Round 6, training backward: the data-gradient conv of a layer on the Winograd path in f16f6 -- md_absmax + md_wino_prep_dual_f6
+    (T = the f16f6 operand of 2^k x dy with max |dy| 2^k in [16, 32); U and the channel sums those of md_wino_prep_dual, bit for bit),
+    the flipped f16f6 fragments from an MD_PACK_WINO_F6 job of md_pack_batch (fixed pre-scale), md_conv3_wino_f6_scaled.  Against torch
+    float64 at gradient magnitudes from 1 down to 1e-9: the dynamic lift is flat in the magnitude; the constant one (2^6, the A/B
+    form) loses the fp16 plane below ~1e-6."""
     B, S, ci, co = 2, 16, 128, 160
     w = _rand((co, ci, 3, 3, 3), 70, 0.05)
     dy = _rand((B, co, S, S, S), 71) * mag
-    parts = [(ops.ncdhw_to_f32b(dy.cuda()), co)]
+    dyb = ops.ncdhw_to_f32b(dy.cuda())
+    parts = [(dyb, co)]
     sums0, sums1 = torch.zeros((B, co), device="cuda"), torch.zeros((B, co), device="cuda")
     _, u0 = ops.wino_prep(parts, None, False, False, B, S, dual=True, sums=sums0)
     u0 = u0.clone()
-    t, u1 = ops.wino_prep(parts, None, False, False, B, S, dual=True, sums=sums1, f8="f6", tscale=ops.DGRAD_TSCALE)
+    amax = ops.absmax_word(dyb) if lift == "dyn" else None
+    if amax is not None:
+        assert float(amax.view(torch.float32).item()) == float(dy.abs().max())
+    t, u1 = ops.wino_prep(parts, None, False, False, B, S, dual=True, sums=sums1, f8="f6", tscale=64.0, amax=amax)
     assert torch.equal(u0.view(torch.int16), u1.view(torch.int16))
     assert rel_l2(sums1.cpu(), sums0.cpu()) < 1e-6
     ww = ops.WinoWeightF6Dgrad(w.cuda(), "cuda")
     assert (ww.rows, ww.kdim) == (ci, co)
-    dx = ops.f32b_to_ncdhw(ops.conv3_wino(ww, t, B, S, out_scale=1.0 / ops.DGRAD_TSCALE), (S, S, S)).cpu()
+    dx = ops.f32b_to_ncdhw(ops.conv3_wino(ww, t, B, S, out_scale=1.0 if amax is not None else 1.0 / 64.0, amax=amax), (S, S, S)).cpu()
     ref = torch.nn.grad.conv3d_input((B, ci, S, S, S), w.double(), dy.double(), padding=1)
     e = rel_l2(dx, ref)
-    # the same through the bf16x3 path, and the packed fragments against the forward-orientation packer on the flipped tensor
     t3 = ops.wino_prep(parts, None, False, False, B, S)
     dx3 = ops.f32b_to_ncdhw(ops.conv3_wino(ops.WinoWeight(w.cuda(), "cuda", kind="conv_dgrad"), t3, B, S), (S, S, S)).cpu()
-    print(f"f16f6 data gradient (|dy| ~ {mag:g}): vs torch fp64 {e:.2e}; bf16x3 {rel_l2(dx3, ref):.2e}")
-    assert e < 4e-5 and rel_l2(dx3, ref) < TOL_MFMA
-    wt = torch.flip(w, dims=(2, 3, 4)).permute(1, 0, 2, 3, 4).contiguous()              # W'[ci][co][t] = W[co][ci][26 - t], materialised
-    t_plain = ops.wino_prep(parts, None, False, False, B, S, f8="f6")
-    dx_plain = ops.f32b_to_ncdhw(ops.conv3_wino(ops.WinoWeightF8(wt.cuda(), "cuda", "f6"), t_plain, B, S), (S, S, S)).cpu()
-    assert rel_l2(dx_plain, ref) < (4e-5 if mag >= 1e-3 else 1.0)                        # the unscaled operand degrades at tiny magnitudes: why tscale exists
-    if mag == 1.0:      # far outside a healthy run: the lift saturates at the fp16 range -- clipped elements, never inf / NaN
+    print(f"f16f6 data gradient (|dy| ~ {mag:g}, lift {lift}): vs torch fp64 {e:.2e}; bf16x3 {rel_l2(dx3, ref):.2e}")
+    assert rel_l2(dx3, ref) < TOL_MFMA
+    if lift == "dyn" or mag >= 3e-6:
+        assert e < 4e-5
+    if mag == 1.0:
+        # the packed fragments against the forward-orientation packer on the materialised flipped tensor W'[ci][co][t] = W[co][ci][26 - t]
+        wt = torch.flip(w, dims=(2, 3, 4)).permute(1, 0, 2, 3, 4).contiguous()
+        t_plain = ops.wino_prep(parts, None, False, False, B, S, f8="f6")
+        dx_plain = ops.f32b_to_ncdhw(ops.conv3_wino(ops.WinoWeightF8(wt.cuda(), "cuda", "f6"), t_plain, B, S), (S, S, S)).cpu()
+        assert rel_l2(dx_plain, ref) < 4e-5
+        # a constant lift far outside its range saturates at the fp16 ends -- clipped elements, never inf / NaN
         big = [(ops.ncdhw_to_f32b((dy * 1e4).cuda()), co)]
-        tb, _ = ops.wino_prep(big, None, False, False, B, S, dual=True, sums=None, f8="f6", tscale=ops.DGRAD_TSCALE)
-        dxb = ops.conv3_wino(ww, tb, B, S, out_scale=1.0 / ops.DGRAD_TSCALE)
-        assert bool(torch.isfinite(dxb).all())
+        tb, _ = ops.wino_prep(big, None, False, False, B, S, dual=True, sums=None, f8="f6", tscale=64.0)
+        assert bool(torch.isfinite(ops.conv3_wino(ww, tb, B, S, out_scale=1.0 / 64.0)).all())
 
 
 def test_wino_prep_dual_second_output_bit_exact(ops):
