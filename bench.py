@@ -575,7 +575,7 @@ def res128_step(dev, steps=3, warmup=2):
     sd = synth.sensitised_state_dict(model.module.state_dict(), seed=99, grid_mask=synth.synthetic_grid_mask(R))
     model.module.load_state_dict(sd, strict=True)
     del sd
-    calibration = mutils.calibrate_model(model, cfg, batch=1)
+    calibration = mutils.calibrate_model(model, cfg, batch=B)      # at the measured batch: a level below the Winograd floor at B = 1 would go unmeasured
     sde = sde_lib.VPSDE(cfg.model.beta_min, cfg.model.beta_max, cfg.model.num_scales, device=dev)
     st = sampling.AncestralStepper(sde, (B, 4, R, R, R), device=dev, grid_mask=synth.synthetic_grid_mask(R).view(1, R, R, R).to(dev))
     fn = mutils.get_model_fn(model)

@@ -582,7 +582,9 @@ int md_gn_bwd_finalize(const double* sums, const float* params, const float* gam
 int md_gn_bwd_apply(const float* x, const float* dy, const float* params, const float* coef, float* dx, int32_t batch,
                     int32_t C, int64_t P, int32_t c_total, int32_t c_off, int32_t dy_ctotal, int32_t silu,
                     int32_t accumulate, float drop_p, uint64_t drop_seed, const float* residual, float* ch_sums,
-                    void* stream);
+                    uint32_t* amax_bits, void* stream);
+                    /* amax_bits (ABI 15, may be NULL): zeroed word receiving max |dx| of this call as md_absmax would (the lift of the
+                     * f16f6 data-gradient conv that consumes dx: saves that conv's separate md_absmax pass) */
                     /* residual (may be NULL, ignored when accumulate): F32B like dx, dx = residual + gradient (the identity
                      * shortcut of a ResnetBlock without a separate copy); ch_sums (may be NULL): float [B][c_total],
                      * += per-(sample, channel) sum of the gradient written for this part (bias / FiLM gradients). */

@@ -125,7 +125,7 @@ SIGNATURES = {
                            _I64, _P]),
     "md_gn_bwd_stats": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I64, _I32, _I32, _I32, _I32, _F, _U64, _P]),
     "md_gn_bwd_finalize": (C.c_int, [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I64, _P]),
-    "md_gn_bwd_apply": (C.c_int, [_P, _P, _P, _P, _P, _I32, _I32, _I64, _I32, _I32, _I32, _I32, _I32, _F, _U64, _P, _P, _P]),
+    "md_gn_bwd_apply": (C.c_int, [_P, _P, _P, _P, _P, _I32, _I32, _I64, _I32, _I32, _I32, _I32, _I32, _F, _U64, _P, _P, _P, _P]),
     "md_channel_sums": (C.c_int, [_P, _P, _I32, _I32, _I64, _P]),
     "md_s16b_transpose": (C.c_int, [_P, _P, _I32, _I32, _I32, _P]),
     "md_softmax_keys_bwd": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _F, _P]),

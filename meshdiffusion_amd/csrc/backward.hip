@@ -247,10 +247,12 @@ __global__ __launch_bounds__(GB_BLOCK) void md_gn_bwd_apply_kernel(const float* 
                                                                    float* __restrict__ dx, int C, int64_t P, int c_total,
                                                                    int c_off, int dy_ctotal, int silu, int accumulate,
                                                                    uint32_t thr16, float drop_scale, uint64_t seed,
-                                                                   const float* __restrict__ residual, float* __restrict__ ch_sums) {
+                                                                   const float* __restrict__ residual, float* __restrict__ ch_sums,
+                                                                   uint32_t* __restrict__ amax_bits) {
   const int cg = blockIdx.y, b = blockIdx.z;
   const int tid = threadIdx.x, half = tid & 1;
   const int64_t p0 = (int64_t)blockIdx.x * GB_CHUNK;
+  float amax = 0.f;                                   // max |dx| of what this thread writes (amax_bits: the f16f6 data-gradient conv's lift)
   const int64_t xo = (((int64_t)b * (C / 8) + cg) * P) * 8;
   const f32x4* xp = (const f32x4*)(x + xo);
   f32x4* op = (f32x4*)(dx + xo);
@@ -288,7 +290,12 @@ __global__ __launch_bounds__(GB_BLOCK) void md_gn_bwd_apply_kernel(const float* 
         cs[e] += g;
       }
       op[pos * 2 + half] = o;
+      amax = fmaxf(amax, fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3]))));
     }
+  }
+  if (amax_bits) {   // as md_absmax would find it in a separate pass over dx
+    amax = md_wave_max(amax);
+    if ((tid & 63) == 0) atomicMax(amax_bits, __float_as_uint(amax));
   }
   if (ch_sums) {   // per-(sample, channel) sums of the GroupNorm input gradient (bias / FiLM gradients of the producer)
 #pragma unroll
@@ -328,14 +335,14 @@ extern "C" int md_gn_bwd_finalize(const double* sums, const float* params, const
 extern "C" int md_gn_bwd_apply(const float* x, const float* dy, const float* params, const float* coef, float* dx, int32_t batch,
                                int32_t C, int64_t P, int32_t c_total, int32_t c_off, int32_t dy_ctotal, int32_t silu,
                                int32_t accumulate, float drop_p, uint64_t drop_seed, const float* residual, float* ch_sums,
-                               void* stream) {
+                               uint32_t* amax_bits, void* stream) {
   if (!(drop_p >= 0.f && drop_p < 1.f)) return MD_ERR_BAD_ARG;
   if (!x || !dy || !params || !coef || !dx || batch <= 0 || C <= 0 || (C % 8) || (c_off % 8) || c_off + C > c_total) return MD_ERR_BAD_ARG;
   dim3 grid((unsigned)((P + GB_CHUNK - 1) / GB_CHUNK), (unsigned)(C / 8), (unsigned)batch);
   MD_HIP_CLEAR_ERROR();
   hipLaunchKernelGGL(md_gn_bwd_apply_kernel, grid, dim3(GB_BLOCK), 0, (hipStream_t)stream, x, dy, params, coef, dx, C, P, c_total,
                      c_off, dy_ctotal, silu, accumulate, md_drop_thr16(drop_p), 1.0f / (1.0f - drop_p), (uint64_t)drop_seed, residual,
-                     ch_sums);
+                     ch_sums, amax_bits);
   MD_HIP_CHECK_LAUNCH();
   return MD_OK;
 }

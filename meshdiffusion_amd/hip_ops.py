@@ -496,16 +496,23 @@ DGRAD_WSCALE_LOG2 = 8
 _AMAX_SLOTS = {}
 
 
-def absmax_word(x):
-    """int32 [1] device word holding max |x| of the fp32 tensor as a float bit pattern (md_absmax) -- for wino_prep(dual, f8="f6", amax=...)
-    and conv3_wino(amax=...).  Words come out of a zeroed arena per (device, stream), refilled when used up."""
-    lib = _lib.load()
-    key = (x.device.index, torch.cuda.current_stream(x.device).cuda_stream)
+def amax_slot(device):
+    """A zeroed int32 [1] device word out of the per-(device, stream) arena (refilled when used up)."""
+    device = torch.device(device)
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
     arena = _AMAX_SLOTS.get(key)
     if arena is None or arena[1] >= arena[0].numel():
-        arena = _AMAX_SLOTS[key] = [torch.zeros(1024, dtype=torch.int32, device=x.device), 0]
+        arena = _AMAX_SLOTS[key] = [torch.zeros(1024, dtype=torch.int32, device=device), 0]
     word = arena[0][arena[1]:arena[1] + 1]
     arena[1] += 1
+    return word
+
+
+def absmax_word(x):
+    """int32 [1] device word holding max |x| of the fp32 tensor as a float bit pattern (md_absmax) -- for wino_prep(dual, f8="f6", amax=...)
+    and conv3_wino(amax=...)."""
+    lib = _lib.load()
+    word = amax_slot(x.device)
     check(lib.md_absmax(_ptr(x), x.numel(), _ptr(word), _stream()), "md_absmax")
     return word
 

@@ -48,7 +48,7 @@ def _setup(config, mask_shape, local_batch=None):
     # few noise batches, rebuild the equalisers from the measurement, audit each conv against its bf16x3 form and demote the ones
     # above the bar (models/utils.calibrate_model; config.eval.calibrate = False skips it)
     if getattr(config.eval, "calibrate", True) and torch.device(config.device).type == "cuda":
-        rep = mutils.calibrate_model(score_model, config)
+        rep = mutils.calibrate_model(score_model, config, batch=shape[0])      # at the sampling batch: which convs take the Winograd path depends on it
         if rep is not None:
             print(f"calibrated the {score_model.module.hip_precision} convs: {rep['measured']} measured, worst kept {rep['worst']:.2e}, "
                   f"demoted to bf16x3: {rep['demoted']}")

@@ -118,12 +118,14 @@ def resample(t, B, C, Sc, mode, accumulate_into=None):
 # ---------------------------------------------------------------------------------------------------------
 # GroupNorm (+SiLU) backward over concatenated parts
 # ---------------------------------------------------------------------------------------------------------
-def gn_backward(parts, dy, params, gn, B, P, silu, d_into=None, drop=None, residual=None, sums_out=None):
+def gn_backward(parts, dy, params, gn, B, P, silu, d_into=None, drop=None, residual=None, sums_out=None, want_amax=False):
     """parts: forward inputs [(F32B, C)]; dy: F32B [B][Ctot][P]; returns one F32B [B][Ctot][P] gradient
     (written into / accumulated onto `d_into` when given) and accumulates gn.weight/.bias grads.
     drop=(p, seed): the forward applied dropout after the activation (same mask regenerated here).
     Single-part extras: residual (F32B): result = residual + gradient (identity shortcut, no separate copy);
-    sums_out (zeroed float [B, Ctot]): += per-(sample, channel) sums of the gradient (bias / FiLM gradients)."""
+    sums_out (zeroed float [B, Ctot]): += per-(sample, channel) sums of the gradient (bias / FiLM gradients);
+    want_amax: the result carries `_md_amax`, the device word with its max |.| (hip_ops.absmax_word's, without the extra pass) -- for
+    a consumer that is the f16f6 data-gradient conv and reads the tensor unmodified."""
     lib = _lib.load()
     dp, dseed = (float(drop[0]), int(drop[1])) if drop else (0.0, 0)
     dev = dy.device
@@ -146,13 +148,16 @@ def gn_backward(parts, dy, params, gn, B, P, silu, d_into=None, drop=None, resid
         # each part's gradient is written at its channel offset of the concatenated gradient tensor
         dx_view = dxcat.view(B, ctot // 8, P, 8)[:, off // 8:(off + c) // 8]
         if len(parts) == 1:
+            amax = ops.amax_slot(dev) if (want_amax and not acc) else None
             check(lib.md_gn_bwd_apply(_ptr(t), _ptr(dy), _ptr(params), _ptr(coef), _ptr(dxcat), B, c, P, ctot, 0, ctot,
-                                      1 if silu else 0, 1 if acc else 0, dp, dseed, _ptr(residual), _ptr(sums_out),
+                                      1 if silu else 0, 1 if acc else 0, dp, dseed, _ptr(residual), _ptr(sums_out), _ptr(amax),
                                       _stream()), "md_gn_bwd_apply")
+            if amax is not None:
+                dxcat._md_amax = amax
         else:
             tmp = dx_view.contiguous() if acc else ops.f32b_empty(B, c, P, dev)
             check(lib.md_gn_bwd_apply(_ptr(t), _ptr(dy), _ptr(params), _ptr(coef), _ptr(tmp), B, c, P, ctot, off, ctot,
-                                      1 if silu else 0, 1 if acc else 0, dp, dseed, None, None, _stream()),
+                                      1 if silu else 0, 1 if acc else 0, dp, dseed, None, None, None, _stream()),
                   "md_gn_bwd_apply")
             outs.append(tmp)
         off += c
@@ -219,7 +224,11 @@ def conv3_backward(layer, name, conv, dy, act_s16, B, S_out, ups=0, stride=1, ne
         amax = None
         if f6:
             if ops.DGRAD_LIFT == "dyn":
-                amax = ops.absmax_word(dy)          # the lift follows this tensor's own largest element (device-side: no host sync)
+                # the lift follows this tensor's own largest element (device-side: no host sync): the word its producer left with it
+                # (gn_backward(want_amax=True): the tensor comes straight from md_gn_bwd_apply), or one more read of it
+                amax = getattr(dy, "_md_amax", None)
+                if amax is None:
+                    amax = ops.absmax_word(dy)
             t_dy, u_dy = ops.wino_prep([(dy, co)], None, False, False, B, S_out, dual=True, sums=bs, f8="f6", tscale=ops.DGRAD_TSCALE, amax=amax)
         else:
             t_dy, u_dy = ops.wino_prep([(dy, co)], None, False, False, B, S_out, dual=True, sums=bs)

@@ -563,7 +563,8 @@ class ResnetBlockDDPM(HipLayer):
                                  bias_sums_out=sv.get("t1") is not None)
         dbias0 = torch.zeros((B, self.out_ch), dtype=torch.float32, device=dy.device)
         d_h = bw.gn_backward([(sv["h"], self.out_ch)], d_a1, sv["prm1"], self.GroupNorm_1, B, P, silu=True,
-                             drop=sv.get("drop"), sums_out=dbias0)[0]     # d(bias0) = channel sums of d_h, same pass
+                             drop=sv.get("drop"), sums_out=dbias0,      # d(bias0) = channel sums of d_h, same pass
+                             want_amax=ops.DGRAD_F6 and ops.DGRAD_LIFT == "dyn" and sv.get("t0") is not None)[0]
         del d_a1
         # Conv_0.bias gradient = batch sum of dbias0: the FiLM caller adds it once together with Dense_0's
         d_a0 = bw.conv3_backward(self, "w0", self.Conv_0, d_h, sv["a0"], B, S, bias_sums=False, t_act=sv.get("t0"))
