@@ -294,8 +294,10 @@ __global__ __launch_bounds__(GB_BLOCK) void md_gn_bwd_apply_kernel(const float* 
     }
   }
   if (amax_bits) {   // as md_absmax would find it in a separate pass over dx
+    // one atomic per wave at most, and none once the word already holds a larger value (a plain, possibly stale read: a stale
+    // smaller value only costs an atomic) -- 65 k same-address atomics per launch otherwise serialise in the L2
     amax = md_wave_max(amax);
-    if ((tid & 63) == 0) atomicMax(amax_bits, __float_as_uint(amax));
+    if ((tid & 63) == 0 && __float_as_uint(amax) > __builtin_nontemporal_load(amax_bits)) atomicMax(amax_bits, __float_as_uint(amax));
   }
   if (ch_sums) {   // per-(sample, channel) sums of the GroupNorm input gradient (bias / FiLM gradients of the producer)
 #pragma unroll

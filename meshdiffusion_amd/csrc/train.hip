@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256) void md_absmax_kernel(const float* __restrict_
   if (blockIdx.x == 0)
     for (int64_t k = n4 * 4 + threadIdx.x; k < n; k += 256) m = fmaxf(m, fabsf(x[k]));
   m = md_wave_max(m);
-  if ((threadIdx.x & 63) == 0) atomicMax(amax_bits, __float_as_uint(m));
+  if ((threadIdx.x & 63) == 0 && __float_as_uint(m) > __builtin_nontemporal_load(amax_bits)) atomicMax(amax_bits, __float_as_uint(m));
 }
 
 extern "C" int md_absmax(const float* x, int64_t n, uint32_t* amax_bits, void* stream) {
