@@ -447,6 +447,10 @@ def roofline(events, hip_ops, a, B, wall_prof):
             "launches": len(main), "avg_launch_ms": round(tot_t / max(len(main), 1) * 1e3, 4),
             "kernel_time_share_of_step": round(tot_t / n_steps / wall_prof, 4),
             "all_gemm_conv_time_share_of_step": round(allt / n_steps / wall_prof, 4),
+            # what bounds `frac` in practice (measured once per round with s_memtime + s_memrealtime stamps, not by this run): the kernel is
+            # power-bound -- matrix-core duty x shader clock is constant across its variants and shapes, so stall removal returns ~1/3
+            "power_bound": {"mfma_duty_x_clock_ghz": [1.14, 1.23], "mfma_peak_clock_ghz": 2.4, "shader_clock_ghz_under_kernel": [1.43, 1.69],
+                            "evidence": "profiles/r06_wino_epilogue_ab.txt (step 4); DESIGN.md section 8, round 6"},
             # the Winograd path's operand pass (GroupNorm affine + SiLU + input transform + split), HBM-bound, priced separately;
             # `with_prep` = the same algorithmic flops over conv + prep time
             "operand_prep": ({"kernel": "md_wino_prep", "bound": "hbm", "ms_per_step": round(prep_t / n_steps * 1e3, 3),
