@@ -30,6 +30,8 @@ def main():
                                                        "the bf16x3 production kernel (same box, same clocks)")
     ap.add_argument("--no-stats", action="store_true", help="launch without the GroupNorm-sum epilogue")
     ap.add_argument("--no-res", action="store_true", help="launch without the residual operand")
+    ap.add_argument("--zero-data", action="store_true", help="all-zero activations and weights: same instruction stream and duty, far less switching power -- the control "
+                                                               "experiment for the power-bound reading of the stamps (shader clock rises, cycles per workgroup do not change)")
     ap.add_argument("--dump", default=None, help="with --stamps: save the raw stamp array of every shape to <dump>_<shape>.npy")
     ap.add_argument("--stamps", action="store_true", help="variant 128 (MD_BUILD_ABLATIONS=1): per-wave s_memtime stamps of the first 1024 workgroups")
     a = ap.parse_args()
@@ -40,6 +42,8 @@ def main():
         g = torch.Generator().manual_seed(1)
         x = ops.ncdhw_to_f32b(torch.randn((B, cin, S, S, S), generator=g).to(dev))
         w = (torch.randn((cout, cin, 3, 3, 3), generator=g) * 0.03).to(dev)
+        if a.zero_data:
+            x.zero_(); w.zero_()
         bias = torch.randn((B, cout), generator=g).to(dev)
         res = ops.f32b_empty(B, cout, S ** 3, dev).normal_()
         ac = torch.stack([1.0 + 0.1 * torch.randn((B, cin), generator=g), 0.1 * torch.randn((B, cin), generator=g)], -1).contiguous().to(dev)
