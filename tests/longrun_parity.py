@@ -43,6 +43,8 @@ def main():
     ap.add_argument("--precision", default=None, help="config.model.hip_precision of the HIP path (default: the config's: f16f6)")
     ap.add_argument("--weights", default="sensitised", choices=["sensitised", "trained_like"],
                     help="synth.sensitised_state_dict (i.i.d.) or the adversarial synth.trained_like_state_dict")
+    ap.add_argument("--calibrate", action="store_true", help="models.utils.calibrate_model at the run's batch before sampling (what evaler does "
+                                                              "after restore_checkpoint): measured equalisers, Upsample convs on the reduced-precision path")
     ap.add_argument("--oracle-samples", default=None,
                     help="comma-separated sample indices: the HIP path runs the whole batch (the graded B = 8 launches), the fp32 oracle "
                          "only these samples of it on the same noise (samples are independent: GroupNorm is per sample) -- a 999-step "
@@ -62,6 +64,11 @@ def main():
     else:
         sd = synth.sensitised_state_dict(model.module.state_dict(), seed=1234, grid_mask=synth.synthetic_grid_mask(R))
     model.module.load_state_dict(sd, strict=True)
+    a.calibration = None
+    if a.calibrate:
+        rep = mutils.calibrate_model(model, cfg, batch=a.batch)
+        a.calibration = None if rep is None else dict(measured=rep["measured"], worst=rep["worst"], demoted=[list(d[:2]) for d in rep["demoted"]])
+        print("calibrated:", a.calibration, flush=True)
     sd_gpu = {k: v.to(dev) for k, v in sd.items()}
     del sd
     ocfg = synth.oracle_cfg(cfg)
@@ -126,6 +133,7 @@ def one_seed(a, seed, st, model_fn, sd_gpu, ocfg, shape, dev, mask):
     from meshdiffusion_amd import hip_ops
     return {"config": a.config, "batch": a.batch, "steps": a.steps, "seed": seed, "partner": a.partner,
             "hip_precision": hip_ops.FORCE_PRECISION or a.hip_precision, "weights": a.weights, "oracle_samples": sel,
+            "calibration": a.calibration,
             "final_x_mean_rel_l2": log[-1]["x_mean_rel_l2"],
             "target": 1e-3, "hip_s_per_step": t_h / a.steps, "oracle_gpu_s_per_step": t_o / a.steps, "trace": log}
 
