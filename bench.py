@@ -323,8 +323,8 @@ def main():
             "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
             "parity": "B = 8, calibrated model, trained-like weights: 200 ancestral steps vs the fp32 oracle 1.8e-5 (tests/test_gpu_graded.py, driver-run); "
-                      "999 steps (uncalibrated, builder-run) 1.7e-5 (profiles/r05_longrun_999step_b8_f16f6_trained_like_vs_oracle.json), 1.9e-5 on the "
-                      "i.i.d. weights (profiles/r04_longrun_*); one U-Net evaluation vs the unmodified reference on the trained-like weights "
+                      "all 999 steps (builder-run) 1.87e-5 (profiles/r06_longrun_999step_b8_f16f6_calibrated_trained_like_vs_oracle.json; uncalibrated, "
+                      "round 5: 1.7e-5), 1.9e-5 on the i.i.d. weights (profiles/r04_longrun_*); one U-Net evaluation vs the unmodified reference on the trained-like weights "
                       "4.6-5.4e-5 (tests/golden/unet_res64_trained.npz); DESIGN.md sections 3 and 5 (target 1e-3 rel-L2 on sampled grids)",
             "dtype": {"bf16x3": "bf16x3 (split-bf16 MFMA operands, fp32 accumulate/IO)",
                                             "fp16x2": "fp16x2 (weights split fp16, activations fp16, fp32 accumulate/IO)",

@@ -209,7 +209,8 @@ def run_conv3(pw, act_s16, B, S_out, *, bias=None, bias_bstride=0, residual=None
             t3 = ops.wino_prep(b_f32["parts"], b_f32.get("ac"), b_f32.get("silu"), ups, B, S_out)
             ref = ops.conv3_wino(wino(), t3, B, S_out, bias=bias, bias_bstride=bias_bstride, residual=residual, res_bstride=res_bstride or 0)
             ops.AUDIT.append(dict(owner=getattr(wino, "owner", None), site=getattr(wino, "site", None), fmt=f8, cin=pw.kdim, cout=pw.rows,
-                                  S=S_out, rel_l2=float(((out.double() - ref.double()).norm() / ref.double().norm().clamp_min(1e-300)).item())))
+                                  S=S_out, rel_l2=float((torch.linalg.vector_norm(out - ref, dtype=torch.float64)
+                                                         / torch.linalg.vector_norm(ref, dtype=torch.float64).clamp_min(1e-300)).item())))
             del t3, ref
         if stats is not None:
             out._md_sums = stats
