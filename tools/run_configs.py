@@ -34,6 +34,7 @@ def build(cfg, R, seed):
 
 
 def time_steps(model, cfg, B, R, steps, warm, cond=False):
+    mutils.calibrate_model(model, cfg, batch=min(B, 8))      # as evaler does after loading a checkpoint (untimed)
     sde = sde_lib.VPSDE(cfg.model.beta_min, cfg.model.beta_max, cfg.model.num_scales, device="cuda")
     mask = synth.synthetic_grid_mask(R).cuda()
     shape = (B, 4, R, R, R)
